@@ -1,0 +1,76 @@
+"""ctypes loader for libdcd_hip.so (the C ABI in include/dcd_hip.h).
+
+There is no CPU fallback: importing this module never fails, but the first call of `lib()`
+raises if the shared library has not been built (`make -C dcd_amd/csrc` or `__graft_entry__.build()`).
+"""
+import ctypes
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libdcd_hip.so")
+_LIB = None
+
+c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                               ctypes.c_size_t, ctypes.c_int64)
+
+# name -> (restype, argtypes); mirrors include/dcd_hip.h one to one
+SIGNATURES = {
+    "dcd_version": (ctypes.c_char_p, []),
+    "dcd_dcn_v2_workspace_bytes": (c_size_t, [c_int] * 14),
+    "dcd_dcn_v2_forward": (c_int, [c_void_p] * 7 + [c_int] * 15 + [c_void_p, c_size_t]),
+    "dcd_dcn_v2_backward": (c_int, [c_void_p] * 12 + [c_int] * 15 + [c_void_p, c_size_t]),
+    "dcd_edge_depth_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int]
+                               + [c_void_p] * 3),
+    "dcd_edge_depth_backward": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int]
+                                + [c_void_p] * 2),
+    "dcd_focal_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_float, c_float, c_void_p, c_void_p]),
+    "dcd_giou_loss": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p, c_void_p, c_void_p]),
+    "dcd_nms_hm": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_void_p]),
+    "dcd_heatmap_topk": (c_int, [c_void_p, c_void_p] + [c_int] * 6 + [c_void_p] * 5 + [c_void_p, c_size_t]),
+    "dcd_heatmap_topk_workspace_bytes": (c_size_t, [c_int] * 5),
+    "dcd_poi_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "dcd_poi_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+}
+
+STATUS = {1: "bad argument", 2: "workspace too small", 3: "kernel launch failed"}
+
+
+class DcdHipError(RuntimeError):
+    pass
+
+
+def lib():
+    global _LIB
+    if _LIB is None:
+        if not os.path.exists(LIB_PATH):
+            raise DcdHipError(
+                "libdcd_hip.so is not built (%s missing). The DGDE hot path has no CPU fallback; "
+                "build it with `make -C dcd_amd/csrc` or `__graft_entry__.build()`." % LIB_PATH)
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(handle, name)
+            fn.restype = res
+            fn.argtypes = args
+        _LIB = handle
+    return _LIB
+
+
+def check(status, what):
+    if status != 0:
+        raise DcdHipError("%s failed: %s (status %d)" % (what, STATUS.get(status, "unknown"), status))
+
+
+def ptr(t):
+    """Device pointer of a tensor (None -> NULL)."""
+    return None if t is None else t.data_ptr()
+
+
+def stream_of(t):
+    import torch
+    return torch.cuda.current_stream(t.device).cuda_stream
+
+
+def require_cuda(*tensors):
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise DcdHipError("dcd_amd ops run on the GPU only (got a %s tensor); there is no CPU path" % t.device)

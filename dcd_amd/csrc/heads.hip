@@ -1,0 +1,616 @@
+// heads.hip -- loss / decode / edge-depth kernels of the DGDE hot path for gfx950.
+//
+// These ops are HBM-trivial and launch-latency bound in the reference (tens of thousands of tiny
+// PyTorch kernels per step); each becomes ONE launch here.
+//   edge depth : one workgroup per object, keypoints in LDS, 2628 pairs, bitonic top-k in LDS
+//   focal loss : grid-stride fused loss + gradient, wave shuffle reduction, one atomic per block
+//   GIoU       : one lane per box, closed-form gradient
+//   heat map   : 3x3 NMS + radix-select top-K, one workgroup per (image, class)
+//   POI gather : direct strided gather from NCHW (no NHWC copy)
+
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dcd_hip.h"
+
+namespace {
+
+constexpr int EDGE_MAXK = 128;
+constexpr int EDGE_THREADS = 512;
+
+// pair index q (row-major upper triangle, i<j) -> (i, j)
+__device__ __forceinline__ void pair_from_index(int q, int K, int &i, int &j)
+{
+    // row i starts at S(i) = i*(2K-i-1)/2
+    float kf = (float)(2 * K - 1);
+    int ii = (int)floorf((kf - sqrtf(kf * kf - 8.f * (float)q)) * 0.5f);
+    if (ii < 0) ii = 0;
+    if (ii > K - 2) ii = K - 2;
+    while (ii > 0 && ii * (2 * K - ii - 1) / 2 > q) --ii;
+    while ((ii + 1) * (2 * K - ii - 2) / 2 <= q) ++ii;
+    i = ii;
+    j = q - ii * (2 * K - ii - 1) / 2 + ii + 1;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Edge-constraint depth solve, forward.  DGDE/model/anno_encoder.py:326-390, GMW/main.py:373-416.
+// ---------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(EDGE_THREADS) void edge_depth_fwd(const float *__restrict__ kps, const float *__restrict__ kps3d,
+                                                               const float *__restrict__ rot_y, const float *__restrict__ Pm,
+                                                               const uint8_t *__restrict__ kmask, int K, int topk, float zmin,
+                                                               float zmax, int normalized, int sub_b3, float *__restrict__ depth,
+                                                               int32_t *__restrict__ pair_idx, float *__restrict__ pair_mask)
+{
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem_raw[];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int npairs = K * (K - 1) / 2;
+    int npad = 1;
+    while (npad < npairs) npad <<= 1;
+
+    float *sv = (float *)smem_raw;            // v' per keypoint
+    float *sh1 = sv + EDGE_MAXK;              // Y
+    float *sh2 = sh1 + EDGE_MAXK;             // v' * C
+    float *sz = sh2 + EDGE_MAXK;              // z per pair          [npairs]
+    unsigned long long *skey = (unsigned long long *)(sz + ((npairs + 1) & ~1));  // sort keys [npad] (topk only)
+
+    const float *Pn = Pm + (size_t)n * 12;
+    const float fy = Pn[5], cy = Pn[6], b3 = Pn[11];
+    const float rot = rot_y[n];
+    const float sn = sinf(rot), cs = cosf(rot);
+
+    for (int k = tid; k < K; k += EDGE_THREADS) {
+        const float v = kps[((size_t)n * K + k) * 2 + 1];
+        const float vn = normalized ? v : __fdiv_rn(__fsub_rn(v, cy), fy);
+        const float X = kps3d[((size_t)n * K + k) * 3 + 0];
+        const float Y = kps3d[((size_t)n * K + k) * 3 + 1];
+        const float Z = kps3d[((size_t)n * K + k) * 3 + 2];
+        const float C = __fsub_rn(__fmul_rn(X, sn), __fmul_rn(Z, cs));
+        sv[k] = vn;
+        sh1[k] = Y;
+        sh2[k] = __fmul_rn(vn, C);
+    }
+    __syncthreads();
+
+    for (int q = tid; q < (topk ? npad : npairs); q += EDGE_THREADS) {
+        if (q < npairs) {
+            int i, j;
+            pair_from_index(q, K, i, j);
+            const float hm = __fadd_rn(__fsub_rn(sh1[i], sh1[j]), __fsub_rn(sh2[i], sh2[j]));
+            const float dv = fabsf(__fsub_rn(sv[i], sv[j]));
+            float z = __fdiv_rn(fabsf(hm), fmaxf(dv, 1e-10f));
+            z = fminf(fmaxf(z, zmin), zmax);
+            sz[q] = z;
+            if (topk) skey[q] = ((unsigned long long)__float_as_uint(dv) << 32) | (unsigned)(~(unsigned)q);
+        } else {
+            skey[q] = 0ull;
+        }
+    }
+    __syncthreads();
+
+    const float sub = sub_b3 ? b3 : 0.f;
+    if (!topk) {
+        for (int q = tid; q < npairs; q += EDGE_THREADS) depth[(size_t)n * npairs + q] = sz[q] - sub;
+        return;
+    }
+
+    // bitonic sort, descending by (|dv|, lower pair index first)
+    for (int size = 2; size <= npad; size <<= 1) {
+        for (int stride = size >> 1; stride > 0; stride >>= 1) {
+            for (int t = tid; t < (npad >> 1); t += EDGE_THREADS) {
+                const int lo = ((t / stride) * stride * 2) + (t % stride);
+                const int hi = lo + stride;
+                const bool desc = ((lo & size) == 0);
+                const unsigned long long a = skey[lo], b = skey[hi];
+                if ((a < b) == desc) {
+                    skey[lo] = b;
+                    skey[hi] = a;
+                }
+            }
+            __syncthreads();
+        }
+    }
+
+    for (int r = tid; r < topk; r += EDGE_THREADS) {
+        const unsigned q = ~(unsigned)(skey[r] & 0xffffffffull);
+        depth[(size_t)n * topk + r] = sz[q] - sub;
+        pair_idx[(size_t)n * topk + r] = (int32_t)q;
+        if (pair_mask) {
+            int i, j;
+            pair_from_index((int)q, K, i, j);
+            const float mi = kmask ? (kmask[(size_t)n * K + i] ? 1.f : 0.f) : 1.f;
+            const float mj = kmask ? (kmask[(size_t)n * K + j] ? 1.f : 0.f) : 1.f;
+            pair_mask[(size_t)n * topk + r] = mi * mj;
+        }
+    }
+}
+
+// Backward: d depth / d (v, X, Y, Z).  Autograd semantics of abs / clamp_min / clamp / gather.
+__global__ __launch_bounds__(256) void edge_depth_bwd(const float *__restrict__ kps, const float *__restrict__ kps3d,
+                                                      const float *__restrict__ rot_y, const float *__restrict__ Pm,
+                                                      const float *__restrict__ gdepth, const int32_t *__restrict__ pair_idx,
+                                                      int K, int topk, float zmin, float zmax, int normalized,
+                                                      float *__restrict__ gkps, float *__restrict__ gkps3d)
+{
+    __shared__ float sv[EDGE_MAXK], sy[EDGE_MAXK], sc[EDGE_MAXK];
+    __shared__ float gv[EDGE_MAXK], gy[EDGE_MAXK], gc[EDGE_MAXK];
+    const int n = blockIdx.x, tid = threadIdx.x;
+    const int npairs = K * (K - 1) / 2;
+    const int M = topk ? topk : npairs;
+    const float *Pn = Pm + (size_t)n * 12;
+    const float fy = Pn[5], cy = Pn[6];
+    const float rot = rot_y[n];
+    const float sn = sinf(rot), cs = cosf(rot);
+    for (int k = tid; k < K; k += 256) {
+        const float v = kps[((size_t)n * K + k) * 2 + 1];
+        sv[k] = normalized ? v : (v - cy) / fy;
+        const float X = kps3d[((size_t)n * K + k) * 3 + 0];
+        sy[k] = kps3d[((size_t)n * K + k) * 3 + 1];
+        const float Z = kps3d[((size_t)n * K + k) * 3 + 2];
+        sc[k] = X * sn - Z * cs;
+        gv[k] = gy[k] = gc[k] = 0.f;
+    }
+    __syncthreads();
+    for (int r = tid; r < M; r += 256) {
+        const float g = gdepth[(size_t)n * M + r];
+        if (g == 0.f) continue;
+        const int q = topk ? pair_idx[(size_t)n * M + r] : r;
+        int i, j;
+        pair_from_index(q, K, i, j);
+        const float A = (sy[i] - sy[j]) + (sv[i] * sc[i] - sv[j] * sc[j]);
+        const float D = sv[i] - sv[j];
+        const float aD = fabsf(D), den = fmaxf(aD, 1e-10f);
+        const float z = fabsf(A) / den;
+        if (z < zmin || z > zmax) continue;  // clamp saturated: no gradient
+        const float sA = (A > 0.f) ? 1.f : (A < 0.f ? -1.f : 0.f);
+        const float gA = g * sA / den;
+        float gD = 0.f;
+        if (aD >= 1e-10f) {
+            const float sD = (D > 0.f) ? 1.f : (D < 0.f ? -1.f : 0.f);
+            gD = -g * fabsf(A) / (den * den) * sD;
+        }
+        atomicAdd(&gy[i], gA);
+        atomicAdd(&gy[j], -gA);
+        atomicAdd(&gv[i], gA * sc[i] + gD);
+        atomicAdd(&gv[j], -gA * sc[j] - gD);
+        atomicAdd(&gc[i], gA * sv[i]);
+        atomicAdd(&gc[j], -gA * sv[j]);
+    }
+    __syncthreads();
+    for (int k = tid; k < K; k += 256) {
+        gkps[((size_t)n * K + k) * 2 + 0] = 0.f;
+        gkps[((size_t)n * K + k) * 2 + 1] = normalized ? gv[k] : gv[k] / fy;
+        gkps3d[((size_t)n * K + k) * 3 + 0] = gc[k] * sn;
+        gkps3d[((size_t)n * K + k) * 3 + 1] = gy[k];
+        gkps3d[((size_t)n * K + k) * 3 + 2] = -gc[k] * cs;
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Penalty-reduced focal loss.  DGDE/model/layers/focal_loss.py:57-86.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float powi_or_f(float x, float e)
+{
+    if (e == 2.f) return x * x;
+    if (e == 4.f) { const float x2 = x * x; return x2 * x2; }
+    if (e == 1.f) return x;
+    return powf(x, e);
+}
+
+__device__ __forceinline__ float wave_sum(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void focal_loss_kernel(const float *__restrict__ pred, const float *__restrict__ target,
+                                                         int64_t n, float alpha, float beta, float *__restrict__ out,
+                                                         float *__restrict__ gpred)
+{
+    float loss = 0.f, npos = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const float praw = pred[i], t = target[i];
+        const float p = fminf(fmaxf(praw, 1e-10f), 1.f - 1e-10f);
+        const bool inside = (praw >= 1e-10f) && (praw <= 1.f - 1e-10f);  // clamp passes gradient inside only
+        float l = 0.f, g = 0.f;
+        if (t == 1.f) {
+            const float omp = 1.f - p, lg = logf(p);
+            l = -lg * powi_or_f(omp, alpha);
+            g = -powi_or_f(omp, alpha) / p + alpha * lg * powi_or_f(omp, alpha - 1.f);
+            npos += 1.f;
+        } else if (t < 1.f && t >= 0.f) {
+            const float w = powi_or_f(1.f - t, beta), lg = logf(1.f - p);
+            l = -lg * powi_or_f(p, alpha) * w;
+            g = w * (powi_or_f(p, alpha) / (1.f - p) - alpha * lg * powi_or_f(p, alpha - 1.f));
+        }
+        loss += l;
+        if (gpred) gpred[i] = inside ? g : 0.f;
+    }
+    loss = wave_sum(loss);
+    npos = wave_sum(npos);
+    __shared__ float sl[4], sp[4];
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    if (lane == 0) { sl[wave] = loss; sp[wave] = npos; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        atomicAdd(out + 0, sl[0] + sl[1] + sl[2] + sl[3]);
+        atomicAdd(out + 1, sp[0] + sp[1] + sp[2] + sp[3]);
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// GIoU on (l,t,r,b).  DGDE/model/layers/iou_loss.py:12-49.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ void min_grad(float a, float b, float g, float &ga, float &gb)
+{   // torch.min(a, b) backward: the smaller gets g, ties split evenly
+    if (a < b) ga += g; else if (b < a) gb += g; else { ga += 0.5f * g; gb += 0.5f * g; }
+}
+__device__ __forceinline__ void max_grad(float a, float b, float g, float &ga, float &gb)
+{
+    if (a > b) ga += g; else if (b > a) gb += g; else { ga += 0.5f * g; gb += 0.5f * g; }
+}
+
+__global__ void giou_kernel(const float *__restrict__ pred, const float *__restrict__ target, int N, float *__restrict__ losses,
+                            float *__restrict__ ious, float *__restrict__ gpred)
+{
+    const int i = blockIdx.x * blockDim.x + threadIdx.x;
+    if (i >= N) return;
+    const float pl = pred[i * 4 + 0], pt = pred[i * 4 + 1], pr = pred[i * 4 + 2], pb = pred[i * 4 + 3];
+    const float tl = target[i * 4 + 0], tt = target[i * 4 + 1], tr = target[i * 4 + 2], tb = target[i * 4 + 3];
+    const float ta = (tl + tr) * (tt + tb);
+    const float pa = (pl + pr) * (pt + pb);
+    const float wi = fminf(pl, tl) + fminf(pr, tr);
+    const float gwi = fmaxf(pl, tl) + fmaxf(pr, tr);
+    const float hi = fminf(pb, tb) + fminf(pt, tt);
+    const float ghi = fmaxf(pb, tb) + fmaxf(pt, tt);
+    const float ac = gwi * ghi + 1e-7f;
+    const float ai = wi * hi;
+    const float au = ta + pa - ai;
+    const float iou = (ai + 1.f) / (au + 1.f);
+    const float giou = iou - (ac - au) / ac;
+    losses[i] = 1.f - giou;
+    ious[i] = iou;
+    if (!gpred) return;
+    // loss = 1 - iou + (ac - au)/ac = 2 - iou - au/ac
+    // d loss = -d iou - d(au)/ac + au/ac^2 d(ac)
+    const float d_ai_iou = 1.f / (au + 1.f), d_au_iou = -(ai + 1.f) / ((au + 1.f) * (au + 1.f));
+    // in terms of (ai, au, ac):
+    const float g_ai = -d_ai_iou;                 // via iou
+    const float g_au = -d_au_iou - 1.f / ac;      // via iou and via au/ac
+    const float g_ac = au / (ac * ac);
+    // au = ta + pa - ai  ->  g_pa = g_au, g_ai_total = g_ai - g_au
+    const float g_pa = g_au, g_ai_t = g_ai - g_au;
+    const float g_wi = g_ai_t * hi, g_hi = g_ai_t * wi;
+    const float g_gwi = g_ac * ghi, g_ghi = g_ac * gwi;
+    float gl = g_pa * (pt + pb), gr = g_pa * (pt + pb), gt = g_pa * (pl + pr), gb = g_pa * (pl + pr), dummy = 0.f;
+    min_grad(pl, tl, g_wi, gl, dummy);
+    min_grad(pr, tr, g_wi, gr, dummy);
+    min_grad(pb, tb, g_hi, gb, dummy);
+    min_grad(pt, tt, g_hi, gt, dummy);
+    max_grad(pl, tl, g_gwi, gl, dummy);
+    max_grad(pr, tr, g_gwi, gr, dummy);
+    max_grad(pb, tb, g_ghi, gb, dummy);
+    max_grad(pt, tt, g_ghi, gt, dummy);
+    gpred[i * 4 + 0] = gl;
+    gpred[i * 4 + 1] = gt;
+    gpred[i * 4 + 2] = gr;
+    gpred[i * 4 + 3] = gb;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Heat-map NMS + top-K.  DGDE/model/layers/utils.py:45-100.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float nms_value(const float *__restrict__ hm, int H, int W, int idx)
+{
+    const int y = idx / W, x = idx - y * W;
+    const float v = hm[idx];
+    float mx = v;
+#pragma unroll
+    for (int dy = -1; dy <= 1; ++dy)
+#pragma unroll
+        for (int dx = -1; dx <= 1; ++dx) {
+            const int yy = y + dy, xx = x + dx;
+            if (yy >= 0 && yy < H && xx >= 0 && xx < W) mx = fmaxf(mx, hm[yy * W + xx]);
+        }
+    return (mx == v) ? v : v * 0.f;  // hm * (hmax == hm).float()
+}
+
+// order-preserving float -> uint key (larger float -> larger key), handles negatives
+__device__ __forceinline__ unsigned f2key(float f)
+{
+    const unsigned u = __float_as_uint(f);
+    return (u & 0x80000000u) ? ~u : (u | 0x80000000u);
+}
+
+__global__ void nms_hm_kernel(const float *__restrict__ heat, int H, int W, int64_t total, float *__restrict__ out)
+{
+    const int HW = H * W;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t plane = i / HW;
+        out[i] = nms_value(heat + plane * HW, H, W, (int)(i - plane * HW));
+    }
+}
+
+constexpr int TOPK_THREADS = 1024;
+constexpr int TOPK_MAXK = 128;
+
+// One workgroup per (image, class): radix-select the K-th largest key, collect, rank-sort.
+__global__ __launch_bounds__(TOPK_THREADS) void heatmap_topk_class(const float *__restrict__ heat, int H, int W, int K, int fuse_nms,
+                                                                   float *__restrict__ cls_scores, int *__restrict__ cls_inds)
+{
+    __shared__ unsigned hist[256];
+    __shared__ unsigned s_prefix, s_remaining, s_cnt_gt, s_cnt_eq;
+    __shared__ float cand_v[TOPK_MAXK];
+    __shared__ int cand_i[TOPK_MAXK];
+    __shared__ int eq_list[TOPK_MAXK];
+    const int HW = H * W, tid = threadIdx.x;
+    const float *hm = heat + (size_t)blockIdx.x * HW;
+
+    unsigned prefix = 0, remaining = (unsigned)K;  // find the K-th largest key
+    for (int pass = 3; pass >= 0; --pass) {
+        if (tid < 256) hist[tid] = 0;
+        __syncthreads();
+        const unsigned himask = (pass == 3) ? 0u : (0xffffffffu << ((pass + 1) * 8));
+        for (int i = tid; i < HW; i += TOPK_THREADS) {
+            const unsigned key = f2key(fuse_nms ? nms_value(hm, H, W, i) : hm[i]);
+            if ((key & himask) == (prefix & himask)) atomicAdd(&hist[(key >> (pass * 8)) & 255u], 1u);
+        }
+        __syncthreads();
+        if (tid == 0) {
+            unsigned rem = remaining, d = 255;
+            for (;; --d) {
+                if (hist[d] >= rem || d == 0) break;
+                rem -= hist[d];
+            }
+            s_prefix = prefix | (d << (pass * 8));
+            s_remaining = rem;
+        }
+        __syncthreads();
+        prefix = s_prefix;
+        remaining = s_remaining;
+        __syncthreads();
+    }
+    // prefix == key of the K-th largest; `remaining` of the elements equal to it are needed (lowest index first)
+    if (tid == 0) { s_cnt_gt = 0; s_cnt_eq = 0; }
+    __syncthreads();
+    for (int base = 0; base < HW; base += TOPK_THREADS) {
+        const int i = base + tid;
+        if (i < HW) {
+            const float v = fuse_nms ? nms_value(hm, H, W, i) : hm[i];
+            const unsigned key = f2key(v);
+            if (key > prefix) {
+                const unsigned slot = atomicAdd(&s_cnt_gt, 1u);
+                cand_v[slot] = v;
+                cand_i[slot] = i;
+            } else if (key == prefix) {
+                const unsigned slot = atomicAdd(&s_cnt_eq, 1u);
+                if (slot < (unsigned)TOPK_MAXK) eq_list[slot] = i;  // may overflow; resolved below
+            }
+        }
+        __syncthreads();
+        // stop scanning for equal elements once enough low-index ones are collected (uniform decision)
+    }
+    __syncthreads();
+    const unsigned ngt = s_cnt_gt;  // == K - remaining
+    // equal elements: need the `remaining` lowest indices.  Recount deterministically by rank.
+    const float eqv = (prefix & 0x80000000u) ? __uint_as_float(prefix & 0x7fffffffu) : __uint_as_float(~prefix);
+    if (s_cnt_eq <= (unsigned)TOPK_MAXK) {
+        // rank the collected equal indices
+        const unsigned ne = s_cnt_eq;
+        if (tid < (int)ne) {
+            const int mine = eq_list[tid];
+            unsigned rank = 0;
+            for (unsigned e = 0; e < ne; ++e) rank += (eq_list[e] < mine) ? 1u : 0u;
+            if (rank < remaining) { cand_v[ngt + rank] = eqv; cand_i[ngt + rank] = mine; }
+        }
+    } else {
+        // many ties (e.g. zeros after NMS): take the first `remaining` in index order with a serial-prefix scan
+        __shared__ unsigned s_taken;
+        if (tid == 0) s_taken = 0;
+        __syncthreads();
+        for (int base = 0; base < HW && s_taken < remaining; base += TOPK_THREADS) {
+            const int i = base + tid;
+            bool iseq = false;
+            if (i < HW) iseq = f2key(fuse_nms ? nms_value(hm, H, W, i) : hm[i]) == prefix;
+            // block-wide exclusive count of iseq among lower tids
+            const unsigned long long bal = __ballot(iseq);
+            const int lane = tid & 63, wave = tid >> 6;
+            __shared__ unsigned wcnt[TOPK_THREADS / 64];
+            if (lane == 0) wcnt[wave] = (unsigned)__popcll(bal);
+            __syncthreads();
+            unsigned before = s_taken;
+            for (int w = 0; w < wave; ++w) before += wcnt[w];
+            before += (unsigned)__popcll(bal & ((1ull << lane) - 1ull));
+            if (iseq && before < remaining) { cand_v[ngt + before] = eqv; cand_i[ngt + before] = i; }
+            __syncthreads();
+            if (tid == 0) {
+                unsigned tot = 0;
+                for (int w = 0; w < TOPK_THREADS / 64; ++w) tot += wcnt[w];
+                s_taken += tot;
+            }
+            __syncthreads();
+        }
+    }
+    __syncthreads();
+    // rank sort the K candidates: value descending, index ascending
+    if (tid < K) {
+        const float v = cand_v[tid];
+        const int ix = cand_i[tid];
+        int rank = 0;
+        for (int e = 0; e < K; ++e) {
+            const float ve = cand_v[e];
+            rank += (ve > v || (ve == v && cand_i[e] < ix)) ? 1 : 0;
+        }
+        cls_scores[(size_t)blockIdx.x * K + rank] = v;
+        cls_inds[(size_t)blockIdx.x * K + rank] = ix;
+    }
+}
+
+// Merge the per-class lists of one image: top-K over C*K (utils.py:86-98).
+__global__ void heatmap_topk_merge(const float *__restrict__ cls_scores, const int *__restrict__ cls_inds, int C, int K, int W,
+                                   float *__restrict__ scores, int64_t *__restrict__ inds, float *__restrict__ clses,
+                                   float *__restrict__ ys, float *__restrict__ xs)
+{
+    const int b = blockIdx.x, n = C * K;
+    const float *sc = cls_scores + (size_t)b * n;
+    const int *si = cls_inds + (size_t)b * n;
+    for (int e = threadIdx.x; e < n; e += blockDim.x) {
+        const float v = sc[e];
+        int rank = 0;
+        for (int f = 0; f < n; ++f) rank += (sc[f] > v || (sc[f] == v && f < e)) ? 1 : 0;
+        if (rank < K) {
+            const int idx = si[e];
+            scores[(size_t)b * K + rank] = v;
+            inds[(size_t)b * K + rank] = idx;
+            clses[(size_t)b * K + rank] = (float)e / (float)K;   // reference: true division (utils.py:91)
+            ys[(size_t)b * K + rank] = (float)(idx / W);
+            xs[(size_t)b * K + rank] = (float)(idx % W);
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// POI gather / scatter.  DGDE/model/layers/utils.py:120-145.
+// ---------------------------------------------------------------------------------------------
+__global__ void poi_gather_kernel(const float *__restrict__ feat, const int64_t *__restrict__ index, int C, int HW, int M,
+                                  int64_t total, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t bm = i / C;
+        const int64_t b = bm / M;
+        const int64_t idx = index[bm];
+        out[i] = (idx >= 0 && idx < HW) ? feat[((size_t)b * C + c) * HW + idx] : 0.f;
+    }
+}
+
+__global__ void poi_scatter_kernel(const float *__restrict__ gout, const int64_t *__restrict__ index, int C, int HW, int M,
+                                   int64_t total, float *__restrict__ gfeat)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int c = (int)(i % C);
+        const int64_t bm = i / C;
+        const int64_t b = bm / M;
+        const int64_t idx = index[bm];
+        if (idx >= 0 && idx < HW) atomicAdd(gfeat + ((size_t)b * C + c) * HW + idx, gout[i]);
+    }
+}
+
+inline int grid_for(int64_t n, int block) { int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
+
+}  // namespace
+
+extern "C" {
+
+const char *dcd_version(void) { return "dcd_hip 0.1 gfx950"; }
+
+int dcd_edge_depth_forward(void *stream_, const float *kps, const float *kps3d, const float *rot_y, const float *P,
+                           const uint8_t *kmask, int N, int K, int topk, float zmin, float zmax, int normalized,
+                           int sub_b3, float *depth, int32_t *pair_idx, float *pair_mask)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) return DCD_OK;
+    if (!kps || !kps3d || !rot_y || !P || !depth || N < 0 || K < 2 || K > EDGE_MAXK) return DCD_ERR_BAD_ARG;
+    const int npairs = K * (K - 1) / 2;
+    if (topk < 0 || topk > npairs) return DCD_ERR_BAD_ARG;
+    if (topk && !pair_idx) return DCD_ERR_BAD_ARG;
+    int npad = 1;
+    while (npad < npairs) npad <<= 1;
+    size_t lds = sizeof(float) * (3 * EDGE_MAXK + ((npairs + 1) & ~1)) + (topk ? sizeof(unsigned long long) * npad : 0);
+    hipLaunchKernelGGL(edge_depth_fwd, dim3(N), dim3(EDGE_THREADS), lds, stream, kps, kps3d, rot_y, P, kmask, K, topk, zmin,
+                       zmax, normalized, sub_b3, depth, pair_idx, pair_mask);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_edge_depth_backward(void *stream_, const float *kps, const float *kps3d, const float *rot_y, const float *P,
+                            const float *grad_depth, const int32_t *pair_idx, int N, int K, int topk, float zmin,
+                            float zmax, int normalized, float *grad_kps, float *grad_kps3d)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) return DCD_OK;
+    if (!kps || !kps3d || !rot_y || !P || !grad_depth || !grad_kps || !grad_kps3d || N < 0 || K < 2 || K > EDGE_MAXK)
+        return DCD_ERR_BAD_ARG;
+    if (topk && !pair_idx) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(edge_depth_bwd, dim3(N), dim3(256), 0, stream, kps, kps3d, rot_y, P, grad_depth, pair_idx, K, topk,
+                       zmin, zmax, normalized, grad_kps, grad_kps3d);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_focal_loss(void *stream_, const float *pred, const float *target, int64_t n, float alpha, float beta, float *out,
+                   float *grad_pred)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!pred || !target || !out || n < 0) return DCD_ERR_BAD_ARG;
+    if (hipMemsetAsync(out, 0, 2 * sizeof(float), stream) != hipSuccess) return DCD_ERR_LAUNCH;
+    if (n == 0) return DCD_OK;
+    const int grid = grid_for(n, 256 * 4);
+    hipLaunchKernelGGL(focal_loss_kernel, dim3(grid), dim3(256), 0, stream, pred, target, n, alpha, beta, out, grad_pred);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_giou_loss(void *stream_, const float *pred, const float *target, int N, float *losses, float *ious, float *grad_pred)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) return DCD_OK;
+    if (!pred || !target || !losses || !ious || N < 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(giou_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred, target, N, losses, ious, grad_pred);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_nms_hm(void *stream_, const float *heat, int B, int C, int H, int W, float *out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (!heat || !out || B < 0 || C <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    const int64_t total = (int64_t)B * C * H * W;
+    if (total == 0) return DCD_OK;
+    hipLaunchKernelGGL(nms_hm_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, heat, H, W, total, out);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+size_t dcd_heatmap_topk_workspace_bytes(int B, int C, int H, int W, int K)
+{
+    (void)H; (void)W;
+    if (B <= 0 || C <= 0 || K <= 0) return 0;
+    return (size_t)B * C * K * (sizeof(float) + sizeof(int)) + 256;
+}
+
+int dcd_heatmap_topk(void *stream_, const float *heat, int B, int C, int H, int W, int K, int fuse_nms, float *scores,
+                     int64_t *inds, float *clses, float *ys, float *xs, void *workspace, size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (B == 0) return DCD_OK;
+    if (!heat || !scores || !inds || !clses || !ys || !xs || !workspace) return DCD_ERR_BAD_ARG;
+    if (B < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || K > TOPK_MAXK || (int64_t)H * W > (1 << 24) || K > H * W ||
+        (int64_t)C * K > 4096)
+        return DCD_ERR_BAD_ARG;
+    if (workspace_bytes < dcd_heatmap_topk_workspace_bytes(B, C, H, W, K) - 256) return DCD_ERR_WORKSPACE;
+    float *cs = (float *)workspace;
+    int *ci = (int *)(cs + (size_t)B * C * K);
+    hipLaunchKernelGGL(heatmap_topk_class, dim3(B * C), dim3(TOPK_THREADS), 0, stream, heat, H, W, K, fuse_nms, cs, ci);
+    hipLaunchKernelGGL(heatmap_topk_merge, dim3(B), dim3(256), 0, stream, cs, ci, C, K, W, scores, inds, clses, ys, xs);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_poi_gather(void *stream_, const float *feat, const int64_t *index, int B, int C, int H, int W, int M, float *out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t total = (int64_t)B * M * C;
+    if (total == 0) return DCD_OK;
+    if (!feat || !index || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(poi_gather_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, feat, index, C, H * W, M, total, out);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *index, int B, int C, int H, int W, int M,
+                        float *grad_feat)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    const int64_t total = (int64_t)B * M * C;
+    if (total == 0) return DCD_OK;
+    if (!grad_out || !index || !grad_feat || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(poi_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M, total,
+                       grad_feat);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -1,0 +1,231 @@
+"""Autograd wrappers over the C-ABI kernels that are not DCNv2 (csrc/heads.hip).
+
+Each function keeps the calling convention of the reference routine it replaces so the model code
+reads like the reference's:
+  pairs_kpts_depth        <- Anno_Encoder.decode_pairs_kpts_depth   (DGDE/model/anno_encoder.py:326-390)
+  compute_z               <- GMW compute_z                          (GMW/main.py:373-416)
+  focal_loss              <- FocalLoss.forward                      (DGDE/model/layers/focal_loss.py:57-86)
+  giou_loss               <- IOULoss.forward (loss_type 'giou')     (DGDE/model/layers/iou_loss.py:12-49)
+  nms_hm / select_topk / select_point_of_interest                   (DGDE/model/layers/utils.py:45-145)
+All of them run on the GPU only and raise if the HIP library is missing.
+"""
+import torch
+
+from . import _lib
+
+
+def _f32c(t):
+    if t.dtype != torch.float32:
+        t = t.float()
+    return t.contiguous()
+
+
+# ----------------------------------------------------------------------------------------------
+# Edge-constraint depth solver
+# ----------------------------------------------------------------------------------------------
+class _PairsDepth(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, kps, kps3d, rot_y, P, kmask, topk, zmin, zmax, normalized, sub_b3):
+        _lib.require_cuda(kps, kps3d, rot_y, P)
+        L = _lib.lib()
+        kps, kps3d, P = _f32c(kps), _f32c(kps3d), _f32c(P)
+        rot = _f32c(rot_y).reshape(-1)
+        N, K = kps.shape[0], kps.shape[1]
+        npairs = K * (K - 1) // 2
+        M = topk if topk else npairs
+        dev = kps.device
+        depth = torch.empty((N, M), dtype=torch.float32, device=dev)
+        pair_idx = torch.empty((N, M), dtype=torch.int32, device=dev) if topk else None
+        km = None
+        pmask = None
+        if kmask is not None:
+            km = kmask.to(torch.uint8).contiguous()
+            pmask = torch.empty((N, M), dtype=torch.float32, device=dev) if topk else None
+        st = L.dcd_edge_depth_forward(_lib.stream_of(kps), kps.data_ptr(), kps3d.data_ptr(), rot.data_ptr(),
+                                      P.data_ptr(), _lib.ptr(km), N, K, int(topk), float(zmin), float(zmax),
+                                      int(normalized), int(sub_b3), depth.data_ptr(), _lib.ptr(pair_idx),
+                                      _lib.ptr(pmask))
+        _lib.check(st, "dcd_edge_depth_forward")
+        ctx.save_for_backward(kps, kps3d, rot, P, pair_idx if pair_idx is not None else torch.empty(0))
+        ctx.cfg = (int(topk), float(zmin), float(zmax), int(normalized))
+        ctx.mark_non_differentiable(*[t for t in (pair_idx, pmask) if t is not None])
+        return depth, pair_idx, pmask
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gdepth, _gidx, _gmask):
+        kps, kps3d, rot, P, pair_idx = ctx.saved_tensors
+        topk, zmin, zmax, normalized = ctx.cfg
+        L = _lib.lib()
+        N, K = kps.shape[0], kps.shape[1]
+        gk = torch.empty_like(kps)
+        gk3 = torch.empty_like(kps3d)
+        gdepth = _f32c(gdepth)
+        st = L.dcd_edge_depth_backward(_lib.stream_of(kps), kps.data_ptr(), kps3d.data_ptr(), rot.data_ptr(),
+                                       P.data_ptr(), gdepth.data_ptr(), pair_idx.data_ptr() if topk else None,
+                                       N, K, topk, zmin, zmax, normalized, gk.data_ptr(), gk3.data_ptr())
+        _lib.check(st, "dcd_edge_depth_backward")
+        return gk, gk3, None, None, None, None, None, None, None, None
+
+
+def pairs_kpts_depth(kps, kps_3d, rot_y, K, training=False, kpts_2d_mask=None, num_k=1500):
+    """decode_pairs_kpts_depth: returns (depth_all, depth_mask).  Train: (N,1500) + float mask; eval: (N,2628), None."""
+    topk = num_k if training else 0
+    depth, _idx, pmask = _PairsDepth.apply(kps, kps_3d, rot_y, K, kpts_2d_mask, topk, 2.0, 80.0, 0, 1)
+    if kpts_2d_mask is not None:
+        if pmask is None:  # eval with a mask: the reference returns get_up(mask_i*mask_j) over all pairs
+            m = kpts_2d_mask.float()
+            iu = torch.triu_indices(m.shape[1], m.shape[1], offset=1, device=m.device)
+            pmask = m[:, iu[0]] * m[:, iu[1]]
+        return depth, pmask
+    return depth, None
+
+
+def compute_z(kpts_2d, kpts_3d, pred_rot, num_k=1500):
+    """GMW compute_z: K-normalised keypoints, clamp [0.1, 80], no b3; returns (Z_v_raw (N,2628), good_idx (N,1500))."""
+    N, K = kpts_2d.shape[0], kpts_2d.shape[1]
+    P = torch.zeros((N, 3, 4), dtype=torch.float32, device=kpts_2d.device)
+    P[:, 1, 1] = 1.0
+    z_all, _, _ = _PairsDepth.apply(kpts_2d, kpts_3d, pred_rot, P, None, 0, 0.1, 80.0, 1, 0)
+    with torch.no_grad():
+        _, idx, _ = _PairsDepth.apply(kpts_2d.detach(), kpts_3d.detach(), pred_rot, P, None, num_k, 0.1, 80.0, 1, 0)
+    return z_all, idx.long()
+
+
+# ----------------------------------------------------------------------------------------------
+# Losses
+# ----------------------------------------------------------------------------------------------
+class _Focal(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, prediction, target, alpha, beta):
+        _lib.require_cuda(prediction, target)
+        L = _lib.lib()
+        p, t = _f32c(prediction), _f32c(target)
+        out = torch.empty(2, dtype=torch.float32, device=p.device)
+        need_grad = prediction.requires_grad
+        g = torch.empty_like(p) if need_grad else None
+        st = L.dcd_focal_loss(_lib.stream_of(p), p.data_ptr(), t.data_ptr(), p.numel(), float(alpha), float(beta),
+                              out.data_ptr(), _lib.ptr(g))
+        _lib.check(st, "dcd_focal_loss")
+        ctx.save_for_backward(g if g is not None else torch.empty(0))
+        ctx.shape = prediction.shape
+        npos = out[1]
+        ctx.mark_non_differentiable(npos)
+        return out[0], npos
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gloss, _gnpos):
+        (g,) = ctx.saved_tensors
+        return (g * gloss).view(ctx.shape), None, None, None
+
+
+def focal_loss(prediction, target, alpha=2, beta=4):
+    """Returns (loss_sum, num_positive) like FocalLoss.forward."""
+    return _Focal.apply(prediction, target, alpha, beta)
+
+
+class _GIoU(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, target):
+        _lib.require_cuda(pred, target)
+        L = _lib.lib()
+        p, t = _f32c(pred), _f32c(target)
+        N = p.shape[0]
+        losses = torch.empty(N, dtype=torch.float32, device=p.device)
+        ious = torch.empty(N, dtype=torch.float32, device=p.device)
+        g = torch.empty_like(p) if pred.requires_grad else None
+        st = L.dcd_giou_loss(_lib.stream_of(p), p.data_ptr(), t.data_ptr(), N, losses.data_ptr(), ious.data_ptr(),
+                             _lib.ptr(g))
+        _lib.check(st, "dcd_giou_loss")
+        ctx.save_for_backward(g if g is not None else torch.empty(0))
+        ctx.mark_non_differentiable(ious)
+        return losses, ious
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, glosses, _gious):
+        (g,) = ctx.saved_tensors
+        return g * glosses.unsqueeze(1), None
+
+
+def giou_loss(pred, target):
+    """Returns (losses, ious) like IOULoss('giou').forward."""
+    return _GIoU.apply(pred, target)
+
+
+# ----------------------------------------------------------------------------------------------
+# Heat-map decode
+# ----------------------------------------------------------------------------------------------
+def nms_hm(heat_map, kernel=3, reso=1):
+    kernel = int(kernel / reso)
+    if kernel % 2 == 0:
+        kernel += 1
+    if kernel != 3:
+        raise NotImplementedError("only the 3x3 NMS of the reference configuration is implemented in HIP")
+    _lib.require_cuda(heat_map)
+    hm = _f32c(heat_map)
+    B, C, H, W = hm.shape
+    out = torch.empty_like(hm)
+    st = _lib.lib().dcd_nms_hm(_lib.stream_of(hm), hm.data_ptr(), B, C, H, W, out.data_ptr())
+    _lib.check(st, "dcd_nms_hm")
+    return out
+
+
+def select_topk(heat_map, K=100, fuse_nms=False):
+    """Returns (topk_scores, topk_inds, topk_clses, topk_ys, topk_xs), each (B, K), like the reference."""
+    _lib.require_cuda(heat_map)
+    L = _lib.lib()
+    hm = _f32c(heat_map)
+    B, C, H, W = hm.shape
+    dev = hm.device
+    scores = torch.empty((B, K), dtype=torch.float32, device=dev)
+    inds = torch.empty((B, K), dtype=torch.int64, device=dev)
+    clses = torch.empty((B, K), dtype=torch.float32, device=dev)
+    ys = torch.empty((B, K), dtype=torch.float32, device=dev)
+    xs = torch.empty((B, K), dtype=torch.float32, device=dev)
+    nbytes = L.dcd_heatmap_topk_workspace_bytes(B, C, H, W, K)
+    ws = torch.empty(max(nbytes, 1), dtype=torch.uint8, device=dev)
+    st = L.dcd_heatmap_topk(_lib.stream_of(hm), hm.data_ptr(), B, C, H, W, K, int(bool(fuse_nms)), scores.data_ptr(),
+                            inds.data_ptr(), clses.data_ptr(), ys.data_ptr(), xs.data_ptr(), ws.data_ptr(), nbytes)
+    _lib.check(st, "dcd_heatmap_topk")
+    return scores, inds, clses, ys, xs
+
+
+class _POI(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, feature_maps, index):
+        _lib.require_cuda(feature_maps, index)
+        L = _lib.lib()
+        f = _f32c(feature_maps)
+        B, C, H, W = f.shape
+        idx = index.to(torch.int64).contiguous()
+        M = idx.shape[1]
+        out = torch.empty((B, M, C), dtype=torch.float32, device=f.device)
+        st = L.dcd_poi_gather(_lib.stream_of(f), f.data_ptr(), idx.data_ptr(), B, C, H, W, M, out.data_ptr())
+        _lib.check(st, "dcd_poi_gather")
+        ctx.save_for_backward(idx)
+        ctx.shape = (B, C, H, W)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout):
+        (idx,) = ctx.saved_tensors
+        B, C, H, W = ctx.shape
+        L = _lib.lib()
+        gout = _f32c(gout)
+        gfeat = torch.zeros((B, C, H, W), dtype=torch.float32, device=gout.device)
+        st = L.dcd_poi_scatter_add(_lib.stream_of(gout), gout.data_ptr(), idx.data_ptr(), B, C, H, W, idx.shape[1],
+                                   gfeat.data_ptr())
+        _lib.check(st, "dcd_poi_scatter_add")
+        return gfeat, None
+
+
+def select_point_of_interest(batch, index, feature_maps):
+    """(B, M, C) features at the given centres; `index` is (B,M,2) points (x,y) or (B,M) linear indices."""
+    w = feature_maps.shape[3]
+    if index.dim() == 3:
+        index = index[:, :, 1] * w + index[:, :, 0]
+    index = index.reshape(batch, -1)
+    return _POI.apply(feature_maps, index)

@@ -1,0 +1,149 @@
+/*
+ * include/dcd_hip.h -- C ABI of libdcd_hip.so, the MI355X (gfx950) implementation of the DGDE hot path.
+ *
+ * Every entry point is `extern "C"`, takes plain device pointers, sizes and a HIP stream
+ * (passed as void* so the header needs no HIP include), enqueues work on that stream without
+ * any host synchronisation, and returns an int status:
+ *     0 = DCD_OK, 1 = DCD_ERR_BAD_ARG (shape / null pointer / unsupported value),
+ *     2 = DCD_ERR_WORKSPACE (workspace too small), 3 = DCD_ERR_LAUNCH (hipGetLastError != success).
+ * Nothing is printed; the caller raises.  All tensors are contiguous fp32 NCHW unless stated.
+ *
+ * Each function cites the reference interface it replaces (paths relative to /root/reference).
+ */
+#ifndef DCD_HIP_H
+#define DCD_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define DCD_OK 0
+#define DCD_ERR_BAD_ARG 1
+#define DCD_ERR_WORKSPACE 2
+#define DCD_ERR_LAUNCH 3
+
+/* Library / build identification: returns e.g. "dcd_hip 0.1 gfx950". */
+const char *dcd_version(void);
+
+/* ------------------------------------------------------------------------------------------------
+ * DCNv2 (modulated deformable convolution).
+ * Replaces `_ext.dcn_v2_forward` / `_ext.dcn_v2_backward`
+ *   DGDE/model/backbone/DCNv2/DCN/src/dcn_v2.h:9-46, :48-92            (dispatch)
+ *   DGDE/model/backbone/DCNv2/DCN/src/cuda/dcn_v2_cuda.cu:42-172, :206-341 (host)
+ *   DGDE/model/backbone/DCNv2/DCN/src/cuda/dcn_v2_im2col_cuda.cu:125-327   (kernels)
+ * and the three extern "C" launchers in cuda/dcn_v2_im2col_cuda.h:68-99 (fused away: no column buffer).
+ *
+ * input  (B,Cin,H,W)            weight (Cout,Cin,kh,kw)       bias (Cout)
+ * offset (B,dg*2*kh*kw,Ho,Wo)   interleaved (dh,dw) per tap   mask (B,dg*kh*kw,Ho,Wo)
+ * output / grad_output (B,Cout,Ho,Wo), Ho = (H+2ph-(dh*(kh-1)+1))/sh+1, likewise Wo.
+ *
+ * precision: 0 = DCD_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
+ *            1 = DCD_PREC_BF16X3 split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16,
+ *                                fp32 accumulate; ~2^-16 relative per product)
+ * workspace: device scratch of at least dcd_dcn_v2_workspace_bytes(...) bytes, 256-byte aligned,
+ *            owned by the caller; contents are dead after the call's kernels complete.
+ * ---------------------------------------------------------------------------------------------- */
+#define DCD_PREC_F32 0
+#define DCD_PREC_BF16X3 1
+
+size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
+                                  int ph, int pw, int dh, int dw, int dg);
+
+int dcd_dcn_v2_forward(void *stream, const float *input, const float *weight, const float *bias,
+                       const float *offset, const float *mask, float *output, int B, int Cin, int H, int W,
+                       int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh, int dw, int dg,
+                       int precision, void *workspace, size_t workspace_bytes);
+
+/* All five gradients are fully overwritten (the callee zero-fills what it accumulates into).
+ * grad_input uses fp32 atomics, like the reference's col2im (order-nondeterministic sums). */
+int dcd_dcn_v2_backward(void *stream, const float *input, const float *weight, const float *bias,
+                        const float *offset, const float *mask, const float *grad_output, float *grad_input,
+                        float *grad_offset, float *grad_mask, float *grad_weight, float *grad_bias, int B,
+                        int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
+                        int dw, int dg, int precision, void *workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------------
+ * Edge-constraint depth solver.
+ * Replaces Anno_Encoder.decode_pairs_kpts_depth + get_up  (DGDE/model/anno_encoder.py:313-390),
+ * PostProcessor.compute_pairs_kpts_depth                  (DGDE/model/head/detector_infer.py:215-225)
+ * and GMW compute_z                                        (GMW/main.py:373-416).
+ *
+ * kps (N,K,2) image pixels; kps3d (N,K,3) object frame; rot_y (N); P (N,3,4) projection matrices;
+ * kmask (N,K) uint8 or NULL.  npairs = K*(K-1)/2 pairs enumerated row-major over the upper triangle.
+ *   z_ij = |(Y_i-Y_j) + (v'_i C_i - v'_j C_j)| / max(|v'_i - v'_j|, 1e-10), clamped to [zmin,zmax],
+ *   v' = (v - P[1][2]) / P[1][1] (or v itself if normalized != 0), C = X sin(rot) - Z cos(rot).
+ * topk == 0 : depth (N,npairs) in pair order                (eval; anno_encoder.py:383-384)
+ * topk  > 0 : the topk pairs with the largest |v'_i-v'_j|, ordered like torch.topk (descending value,
+ *             ties by lower pair index first); depth (N,topk), pair_idx (N,topk) int32,
+ *             pair_mask (N,topk) float = kmask_i*kmask_j (only if kmask)      (anno_encoder.py:377-382)
+ * Finally subtracts P[2][3] when sub_b3 != 0 (anno_encoder.py:385; not in GMW).
+ * K <= 128.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_edge_depth_forward(void *stream, const float *kps, const float *kps3d, const float *rot_y,
+                           const float *P, const uint8_t *kmask, int N, int K, int topk, float zmin,
+                           float zmax, int normalized, int sub_b3, float *depth, int32_t *pair_idx,
+                           float *pair_mask);
+
+/* Backward of the above w.r.t. kps (v coordinate only; u does not enter) and kps3d.
+ * grad_depth (N,M) with M = topk ? topk : npairs; pair_idx as produced by the forward (NULL if topk==0).
+ * grad_kps (N,K,2) and grad_kps3d (N,K,3) are overwritten.  No gradient flows through the clamp's
+ * saturated branch, the top-k selection, or max(.,1e-10) when saturated (autograd semantics). */
+int dcd_edge_depth_backward(void *stream, const float *kps, const float *kps3d, const float *rot_y,
+                            const float *P, const float *grad_depth, const int32_t *pair_idx, int N, int K,
+                            int topk, float zmin, float zmax, int normalized, float *grad_kps,
+                            float *grad_kps3d);
+
+/* ------------------------------------------------------------------------------------------------
+ * Penalty-reduced focal loss.  Replaces FocalLoss.forward (DGDE/model/layers/focal_loss.py:57-86).
+ * pred, target: n elements.  out[0] = loss sum, out[1] = number of positives (target == 1).
+ * grad_pred (n) may be NULL; if given it receives d(loss_sum)/d(pred) (to be scaled by the caller).
+ * `out` must be zero-filled by the callee (it is) -- two floats.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_focal_loss(void *stream, const float *pred, const float *target, int64_t n, float alpha, float beta,
+                   float *out, float *grad_pred);
+
+/* ------------------------------------------------------------------------------------------------
+ * GIoU loss on (l,t,r,b) distances.  Replaces IOULoss.forward (DGDE/model/layers/iou_loss.py:12-49).
+ * pred, target (N,4) -> losses (N) = 1 - giou, ious (N); grad_pred (N,4) optional = d losses_i / d pred_i.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_giou_loss(void *stream, const float *pred, const float *target, int N, float *losses, float *ious,
+                  float *grad_pred);
+
+/* ------------------------------------------------------------------------------------------------
+ * Heat-map decode: 3x3 max-pool NMS and per-image top-K.
+ * Replaces nms_hm (DGDE/model/layers/utils.py:45-58) and select_topk (:61-100).
+ *
+ * dcd_nms_hm: out = heat * (maxpool3x3(heat) == heat), same shape (B,C,H,W).
+ *
+ * dcd_heatmap_topk: heat (B,C,H,W) -> scores (B,K) descending, inds (B,K) int64 = y*W+x of the winner,
+ * clses (B,K) float = (c*K + rank_in_class)/K as the reference's true division yields (utils.py:91),
+ * ys = floor(ind / W), xs = ind % W as float (utils.py:80-81).  fuse_nms != 0 applies the 3x3 NMS on
+ * the fly (one launch for PostProcessor's nms_hm -> select_topk, detector_infer.py:102-106);
+ * fuse_nms == 0 ranks `heat` as given (select_topk semantics).
+ * Ties: lower linear index first (torch.topk leaves tie order unspecified; pinned by tests).
+ * Requires K <= 128, K <= H*W, C*K <= 4096 and H*W <= 2^24.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_nms_hm(void *stream, const float *heat, int B, int C, int H, int W, float *out);
+int dcd_heatmap_topk(void *stream, const float *heat, int B, int C, int H, int W, int K, int fuse_nms,
+                     float *scores, int64_t *inds, float *clses, float *ys, float *xs, void *workspace,
+                     size_t workspace_bytes);
+size_t dcd_heatmap_topk_workspace_bytes(int B, int C, int H, int W, int K);
+
+/* ------------------------------------------------------------------------------------------------
+ * Point-of-interest gather.  Replaces select_point_of_interest (DGDE/model/layers/utils.py:120-145)
+ * without the NCHW->NHWC copy.  feat (B,C,H,W), index (B,M) int64 linear y*W+x -> out (B,M,C).
+ * Backward scatters grad_out (B,M,C) into grad_feat (B,C,H,W) with atomics (duplicate indices add);
+ * grad_feat must be zero-filled by the caller.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_poi_gather(void *stream, const float *feat, const int64_t *index, int B, int C, int H, int W, int M,
+                   float *out);
+int dcd_poi_scatter_add(void *stream, const float *grad_out, const int64_t *index, int B, int C, int H, int W,
+                        int M, float *grad_feat);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* DCD_HIP_H */

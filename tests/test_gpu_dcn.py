@@ -1,0 +1,164 @@
+"""GPU parity: HIP DCNv2 (through the C ABI, dcd_amd._ext) vs the CPU oracle on identical inputs.
+
+Tolerance: north_star asks for 1e-3 relative in fp32.  The f32 MFMA path is an exact-fp32 fmaf chain, so
+it is held to 2e-5 of the output scale (summation-order noise only); the bound is written in `close()`.
+"""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+def close(got, ref, rel, what):
+    got = got.detach().float().cpu()
+    ref = ref.detach().float().cpu()
+    assert got.shape == ref.shape, (what, got.shape, ref.shape)
+    scale = ref.abs().max().item() + 1e-12
+    err = (got - ref).abs().max().item()
+    assert err <= rel * scale, "%s: max abs err %.3e vs scale %.3e (rel %.2e > %.1e)" % (what, err, scale, err / scale, rel)
+
+
+def make_case(B, C, Co, H, W, dg=1, k=3, off_scale=2.0, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 2 * dg * k * k, H, W, generator=g) * off_scale
+    m = torch.sigmoid(torch.randn(B, dg * k * k, H, W, generator=g))
+    w = torch.randn(Co, C, k, k, generator=g) / (C * k * k) ** 0.5
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, H, W, generator=g)
+    return x, w, b, off, m, gy
+
+
+CASES = [
+    # B, C, Co, H, W, dg, off_scale      (reference test shapes: DCN/testcpu.py:15-17; DGDE layer shapes scaled down)
+    (2, 2, 2, 4, 4, 1, 2.0),
+    (2, 5, 4, 7, 9, 1, 3.0),
+    (1, 64, 64, 24, 40, 1, 2.0),
+    (2, 128, 64, 12, 20, 1, 2.0),
+    (1, 256, 128, 6, 10, 1, 1.0),
+    (2, 64, 32, 9, 11, 2, 2.0),      # deformable_groups = 2 (DCN/testcpu.py:172-173)
+    (1, 6, 3, 5, 6, 3, 6.0),         # odd channels per group, samples far outside the image
+    (1, 96, 320, 8, 8, 1, 1.0),      # Cout > 256: streamed dY path
+]
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_oracle(cuda, oracle_dcn, case):
+    from dcd_amd import _ext
+    B, C, Co, H, W, dg, osc = case
+    x, w, b, off, m, _ = make_case(B, C, Co, H, W, dg, off_scale=osc)
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    got = _ext.dcn_v2_forward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    close(got, ref, 2e-5, "forward %s" % (case,))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_matches_oracle(cuda, oracle_dcn, case):
+    from dcd_amd import _ext
+    B, C, Co, H, W, dg, osc = case
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, dg, off_scale=osc, seed=1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    got = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda),
+                               3, 3, 1, 1, 1, 1, 1, 1, dg)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, 5e-5, "%s %s" % (name, case))
+
+
+@pytest.mark.parametrize("geom", [(3, 3, 2, 2, 1, 1, 1, 1), (3, 3, 1, 1, 2, 2, 2, 2), (1, 1, 1, 1, 0, 0, 1, 1),
+                                  (3, 1, 1, 2, 1, 0, 1, 1)])
+def test_general_geometry(cuda, oracle_dcn, geom):
+    """stride / dilation / non-square kernels: the reference op supports them (dcn_v2_cuda.cu:86-87)."""
+    from dcd_amd import _ext
+    kh, kw, sh, sw, ph, pw, dh, dw = geom
+    B, C, Co, H, W = 2, 8, 6, 11, 13
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 2 * kh * kw, Ho, Wo, generator=g) * 2
+    m = torch.rand(B, kh * kw, Ho, Wo, generator=g)
+    w = torch.randn(Co, C, kh, kw, generator=g) * 0.2
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    args = (kh, kw, sh, sw, ph, pw, dh, dw, 1)
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, *args)
+    got = _ext.dcn_v2_forward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), *args)
+    close(got, ref, 2e-5, "forward geom %s" % (geom,))
+    refg = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *args)
+    gotg = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda), *args)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gotg, refg):
+        close(g_, r_, 5e-5, "%s geom %s" % (name, geom))
+
+
+def test_zero_offset_known_answer(cuda):
+    """The reference's check_zero_offset (DCN/testcpu.py:32-67): identity weight, mask 0.5 -> 2*out == in."""
+    from dcd_amd import _ext
+    torch.manual_seed(0)
+    N, inC, H, W, outC = 2, 2, 4, 4, 2
+    w = torch.zeros(outC, inC, 3, 3)
+    for p in range(inC):
+        w[p, p, 1, 1] = 1.0
+    x = torch.randn(N, inC, H, W)
+    off = torch.zeros(N, 18, H, W)
+    m = torch.sigmoid(torch.zeros(N, 9, H, W))
+    out = _ext.dcn_v2_forward(x.to(cuda), w.to(cuda), torch.zeros(outC, device=cuda), off.to(cuda), m.to(cuda),
+                              3, 3, 1, 1, 1, 1, 1, 1, 1)
+    assert (x - 2 * out.cpu()).abs().max().item() < 1e-10
+
+
+def test_boundary_samples(cuda, oracle_dcn):
+    """Samples landing in (-1,0) and (H-1,H): partially outside, must follow the open-interval rule
+    (cuda/dcn_v2_im2col_cuda.cu:180) and the per-corner bounds (:38-48)."""
+    from dcd_amd import _ext
+    B, C, Co, H, W = 1, 4, 4, 6, 7
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=3)
+    off.zero_()
+    off[:, 0::2] = torch.tensor([-0.5, -1.0, -1.5, 0.25, 6.5, 5.99, -0.999, 5.0, 7.0]).view(1, 9, 1, 1)
+    off[:, 1::2] = torch.tensor([-0.5, -0.25, 7.5, 6.99, -1.0, 0.5, -0.999, 6.0, -2.0]).view(1, 9, 1, 1)
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    got = _ext.dcn_v2_forward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    close(got, ref, 2e-5, "boundary forward")
+    refg = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    gotg = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda),
+                                3, 3, 1, 1, 1, 1, 1, 1, 1)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gotg, refg):
+        close(g_, r_, 5e-5, "boundary " + name)
+
+
+def test_full_size_layer_properties(cuda, oracle_dcn):
+    """BASELINE size (64->64 @ 96x320, bs 8): size-independent properties instead of a full oracle run.
+    (1) linearity in the weights, (2) image 0 of the batch equals a batch-1 run compared with the oracle,
+    (3) <dY, dcn(x)> adjoint identity between forward and grad_weight/grad_bias."""
+    from dcd_amd import _ext
+    B, C, Co, H, W = 8, 64, 64, 96, 320
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=7)
+    xd, wd, bd, od, md, gd = (t.to(cuda) for t in (x, w, b, off, m, gy))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    y = _ext.dcn_v2_forward(xd, wd, bd, od, md, *a)
+    y2 = _ext.dcn_v2_forward(xd, 2 * wd, 2 * bd, od, md, *a)
+    close(y2, 2 * y, 1e-5, "linearity in (W,b)")
+    ref0 = oracle_dcn.dcn_v2_forward(x[:1], w, b, off[:1], m[:1], *a)
+    close(y[:1], ref0, 2e-5, "image 0 vs oracle")
+    grads = _ext.dcn_v2_backward(xd, wd, bd, od, md, gd, *a)
+    # <dY, y> = <dW, W> + <db, b>  because y is linear in (W, b)
+    lhs = (gd.double() * y.double()).sum().item()
+    rhs = (grads[3].double() * wd.double()).sum().item() + (grads[4].double() * bd.double()).sum().item()
+    assert abs(lhs - rhs) <= 1e-4 * max(abs(lhs), 1.0), (lhs, rhs)
+    refg = oracle_dcn.dcn_v2_backward(x[:1], w, b, off[:1], m[:1], gy[:1], *a)
+    g1 = _ext.dcn_v2_backward(xd[:1].contiguous(), wd, bd, od[:1].contiguous(), md[:1].contiguous(),
+                              gd[:1].contiguous(), *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), g1, refg):
+        close(g_, r_, 1e-4, "full-size image 0 " + name)
+
+
+def test_errors_raise(cuda):
+    from dcd_amd import _ext
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(1, 4, 4, 5, 5))
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x, w[:, :3].contiguous(), b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x, w, b, off, m, 5, 5, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_forward(x.cpu(), w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+    with pytest.raises(RuntimeError):
+        _ext.dcn_v2_backward(x.transpose(2, 3), w, b, off, m, gy, 3, 3, 1, 1, 1, 1, 1, 1, 1)

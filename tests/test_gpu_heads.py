@@ -1,0 +1,259 @@
+"""GPU parity: edge-depth solver, focal, GIoU, heat-map decode and POI gather (C ABI via dcd_amd.ops)
+against the numpy oracle (oracle/heads_oracle.py) on identical seeded inputs.
+
+Bars: indices (top-k pair sets, heat-map winners) bit-exact; floating point within 1e-3 relative
+(north_star), with the actual bound written next to each assert.
+"""
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+P2 = np.array([[721.5377, 0, 609.5593, 44.85728], [0, 721.5377, 172.854, 0.2163791], [0, 0, 1, 0.002745884]],
+              dtype=np.float32)
+
+
+def synth_objects(N, K=73, seed=0, noise=0.0):
+    """Objects with exact projections: returns kps (N,K,2), kps3d (N,K,3), rot (N,1), P, z."""
+    rng = np.random.RandomState(seed)
+    z = rng.uniform(8, 50, N).astype(np.float32)
+    x = (rng.uniform(-0.25, 0.25, N) * z).astype(np.float32)
+    y = np.full(N, 1.0, np.float32)
+    dims = np.stack([rng.normal(3.9, 0.3, N), rng.normal(1.5, 0.1, N), rng.normal(1.6, 0.1, N)], 1).astype(np.float32)
+    rot = rng.uniform(-np.pi, np.pi, N).astype(np.float32)
+    k3 = (rng.uniform(-0.5, 0.5, (N, K, 3)) * dims[:, None, :]).astype(np.float32)
+    c, s = np.cos(rot)[:, None], np.sin(rot)[:, None]
+    Xc = k3[:, :, 0] * c + k3[:, :, 2] * s + x[:, None]
+    Yc = k3[:, :, 1] + y[:, None]
+    Zc = -k3[:, :, 0] * s + k3[:, :, 2] * c + z[:, None]
+    u = (P2[0, 0] * Xc + P2[0, 2] * Zc + P2[0, 3]) / (Zc + P2[2, 3])
+    v = (P2[1, 1] * Yc + P2[1, 2] * Zc + P2[1, 3]) / (Zc + P2[2, 3])
+    kps = np.stack([u, v], -1).astype(np.float32)
+    kps += rng.normal(0, noise, kps.shape).astype(np.float32)
+    P = np.tile(P2[None], (N, 1, 1))
+    return kps, k3, rot[:, None], P, z
+
+
+@pytest.mark.parametrize("N,K", [(12, 73), (1, 73), (5, 10), (3, 128), (40, 73)])
+def test_edge_depth_eval(cuda, N, K):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    kps, k3, rot, P, _ = synth_objects(N, K, seed=N + K, noise=0.5)
+    ref, _, _ = ho.pairs_kpts_depth(kps, k3, rot, P, training=False)
+    got, gm = ops.pairs_kpts_depth(*(torch.from_numpy(a).to(cuda) for a in (kps, k3, rot, P)), training=False)
+    assert gm is None and tuple(got.shape) == (N, K * (K - 1) // 2)
+    # bound: 2e-4 relative (device vs host sin/cos, amplified by cancellation in the pair differences); north_star allows 1e-3
+    np.testing.assert_allclose(got.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+@pytest.mark.parametrize("N", [12, 1, 33])
+def test_edge_depth_train_topk_exact(cuda, N):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    K = 73
+    kps, k3, rot, P, _ = synth_objects(N, K, seed=N, noise=0.3)
+    rng = np.random.RandomState(N)
+    mask = rng.rand(N, K) > 0.2
+    ref, rmask, ridx = ho.pairs_kpts_depth(kps, k3, rot, P, kmask=mask, training=True)
+    t = [torch.from_numpy(a).to(cuda) for a in (kps, k3, rot, P)]
+    depth, idx, pmask = ops._PairsDepth.apply(t[0], t[1], t[2], t[3], torch.from_numpy(mask).to(cuda), 1500, 2.0, 80.0, 0, 1)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx), "top-1500 pair indices must be bit-exact"
+    assert np.array_equal(pmask.cpu().numpy(), rmask)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+def test_edge_depth_ties_lower_index_first(cuda):
+    """Many identical v (degenerate keypoints) -> ties in |dv|; rule: lower pair index first."""
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    kps, k3, rot, P, _ = synth_objects(4, 73, seed=9)
+    kps[:, 20:, 1] = kps[:, 20:21, 1]          # 53 keypoints share one row -> 1378 pairs with dv == 0
+    ref, _, ridx = ho.pairs_kpts_depth(kps, k3, rot, P, training=True)
+    t = [torch.from_numpy(a).to(cuda) for a in (kps, k3, rot, P)]
+    depth, idx, _ = ops._PairsDepth.apply(t[0], t[1], t[2], t[3], None, 1500, 2.0, 80.0, 0, 1)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
+def test_edge_depth_recovers_true_depth(cuda):
+    """Domain property at any size: on exact projections the mean over pairs is the object depth."""
+    from dcd_amd import ops
+    kps, k3, rot, P, z = synth_objects(64, 73, seed=3, noise=0.0)
+    got, _ = ops.pairs_kpts_depth(*(torch.from_numpy(a).to(cuda) for a in (kps, k3, rot, P)), training=True)
+    est = got.mean(1).cpu().numpy()
+    assert np.max(np.abs(est - z) / z) < 2e-2
+
+
+def test_edge_depth_backward_matches_autograd(cuda):
+    """Gradient w.r.t. kps and kps3d vs torch autograd of the restated formula (float64 on CPU).
+    Eval mode uses random output weights; train mode uses sum() so the top-k ORDER cannot matter."""
+    from dcd_amd import ops
+    N, K = 6, 73
+    kps, k3, rot, P, _ = synth_objects(N, K, seed=5, noise=0.4)
+    for training in (False, True):
+        a = torch.from_numpy(kps).to(cuda).requires_grad_()
+        b = torch.from_numpy(k3).to(cuda).requires_grad_()
+        d, _ = ops.pairs_kpts_depth(a, b, torch.from_numpy(rot).to(cuda), torch.from_numpy(P).to(cuda), training=training)
+        gen = torch.Generator().manual_seed(1)
+        gw = torch.ones(d.shape) if training else torch.randn(d.shape, generator=gen)
+        (d * gw.to(cuda)).sum().backward()
+        A = torch.from_numpy(kps).double().requires_grad_()
+        Bk = torch.from_numpy(k3).double().requires_grad_()
+        Pt = torch.from_numpy(P).double()
+        r = torch.from_numpy(rot).double()
+        v = (A[:, :, 1] - Pt[:, None, 1, 2]) / Pt[:, None, 1, 1]
+        C = Bk[:, :, 0] * torch.sin(r) - Bk[:, :, 2] * torch.cos(r)
+        H2 = v * C
+        iu = torch.triu_indices(K, K, 1)
+        hm = (Bk[:, iu[0], 1] - Bk[:, iu[1], 1]) + (H2[:, iu[0]] - H2[:, iu[1]])
+        dv = (v[:, iu[0]] - v[:, iu[1]]).abs()
+        zz = (hm.abs() / dv.clamp_min(1e-10)).clamp_min(2.0).clamp_max(80.0)
+        if training:
+            _, idx = torch.topk(dv, 1500, dim=-1)
+            zz = zz.gather(-1, idx)
+        (zz * gw.double()).sum().backward()
+        for got, ref, nm in ((a.grad, A.grad, "kps"), (b.grad, Bk.grad, "kps3d")):
+            ref = ref.float()
+            err = (got.cpu() - ref).abs().max().item()
+            scale = ref.abs().max().item()
+            assert err <= 1e-3 * scale, (nm, training, err, scale)   # 1e-3 relative (north_star)
+
+
+def test_compute_z_gmw(cuda):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    kps, k3, rot, P, _ = synth_objects(7, 73, seed=2, noise=0.2)
+    kn = kps.copy()
+    kn[:, :, 0] = (kps[:, :, 0] - P2[0, 2]) / P2[0, 0]
+    kn[:, :, 1] = (kps[:, :, 1] - P2[1, 2]) / P2[1, 1]
+    ref, _, _ = ho.pairs_kpts_depth(kn, k3, rot, P, training=False, zmin=0.1, normalized=True, sub_b3=False)
+    _, _, ridx = ho.pairs_kpts_depth(kn, k3, rot, P, training=True, zmin=0.1, normalized=True, sub_b3=False)
+    z, idx = ops.compute_z(torch.from_numpy(kn).to(cuda), torch.from_numpy(k3).to(cuda), torch.from_numpy(rot).to(cuda))
+    np.testing.assert_allclose(z.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+    assert np.array_equal(idx.cpu().numpy(), ridx)
+
+
+# ---------------------------------------------------------------------------------------------
+def heat_and_target(B, H, W, seed):
+    rng = np.random.RandomState(seed)
+    pred = 1 / (1 + np.exp(-rng.normal(-2, 1.5, (B, 1, H, W))))
+    pred = np.clip(pred, 1e-4, 1 - 1e-4).astype(np.float32)
+    tgt = np.zeros((B, 1, H, W), np.float32)
+    yy, xx = np.mgrid[0:H, 0:W]
+    for b in range(B):
+        for _ in range(6):
+            cy, cx, s = rng.randint(0, H), rng.randint(0, W), rng.uniform(1, 4)
+            g = np.exp(-((yy - cy) ** 2 + (xx - cx) ** 2) / (2 * s * s)).astype(np.float32)
+            tgt[b, 0] = np.maximum(tgt[b, 0], g)
+            tgt[b, 0, cy, cx] = 1.0
+    return pred, tgt
+
+
+@pytest.mark.parametrize("shape", [(2, 96, 320), (8, 96, 320), (1, 5, 7)])
+def test_focal_loss(cuda, shape):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    pred, tgt = heat_and_target(*shape, seed=shape[0])
+    ref_loss, ref_np = ho.focal_loss(pred, tgt)
+    p = torch.from_numpy(pred).to(cuda).requires_grad_()
+    loss, npos = ops.focal_loss(p, torch.from_numpy(tgt).to(cuda), 2, 4)
+    assert npos.item() == ref_np
+    assert abs(loss.item() - ref_loss) <= 1e-4 * abs(ref_loss)          # bound 1e-4 relative
+    loss.backward()
+    # gradient vs torch autograd of the reference formula (CPU float64)
+    pt = torch.from_numpy(pred).double().requires_grad_()
+    tt = torch.from_numpy(tgt).double()
+    pc = pt.clamp(1e-10, 1 - 1e-10)
+    l = -(torch.log(pc) * (1 - pc) ** 2 * (tt == 1)) - torch.log(1 - pc) * pc ** 2 * (1 - tt) ** 4 * ((tt < 1) & (tt >= 0))
+    l.sum().backward()
+    err = (p.grad.cpu().double() - pt.grad).abs().max().item()
+    assert err <= 1e-4 * pt.grad.abs().max().item()
+
+
+def test_giou_loss(cuda):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    rng = np.random.RandomState(0)
+    pred = rng.uniform(0, 30, (64, 4)).astype(np.float32)
+    tgt = rng.uniform(0.5, 30, (64, 4)).astype(np.float32)
+    pred[:4] = 0.0                                    # relu'd predictions are often exactly zero
+    rl, ri = ho.giou_loss(pred, tgt)
+    p = torch.from_numpy(pred).to(cuda).requires_grad_()
+    losses, ious = ops.giou_loss(p, torch.from_numpy(tgt).to(cuda))
+    np.testing.assert_allclose(losses.detach().cpu().numpy(), rl, rtol=1e-5, atol=1e-6)
+    np.testing.assert_allclose(ious.cpu().numpy(), ri, rtol=1e-5, atol=1e-6)
+    losses.sum().backward()
+    pt = torch.from_numpy(pred).double().requires_grad_()
+    tt = torch.from_numpy(tgt).double()
+    ta = (tt[:, 0] + tt[:, 2]) * (tt[:, 1] + tt[:, 3])
+    pa = (pt[:, 0] + pt[:, 2]) * (pt[:, 1] + pt[:, 3])
+    wi = torch.min(pt[:, 0], tt[:, 0]) + torch.min(pt[:, 2], tt[:, 2])
+    gw = torch.max(pt[:, 0], tt[:, 0]) + torch.max(pt[:, 2], tt[:, 2])
+    hi = torch.min(pt[:, 3], tt[:, 3]) + torch.min(pt[:, 1], tt[:, 1])
+    gh = torch.max(pt[:, 3], tt[:, 3]) + torch.max(pt[:, 1], tt[:, 1])
+    ac = gw * gh + 1e-7
+    ai = wi * hi
+    au = ta + pa - ai
+    iou = (ai + 1) / (au + 1)
+    (1 - (iou - (ac - au) / ac)).sum().backward()
+    err = (p.grad.cpu().double() - pt.grad).abs().max().item()
+    assert err <= 1e-4 * pt.grad.abs().max().item() + 1e-7
+
+
+@pytest.mark.parametrize("B,C,H,W,K", [(2, 1, 96, 320, 50), (16, 1, 96, 320, 50), (2, 3, 24, 40, 50), (1, 1, 8, 8, 50),
+                                      (3, 1, 96, 320, 100)])
+def test_heatmap_decode_exact(cuda, B, C, H, W, K):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    rng = np.random.RandomState(B * 7 + C)
+    heat = np.clip(1 / (1 + np.exp(-rng.normal(-2, 1.5, (B, C, H, W)))), 1e-4, 1 - 1e-4).astype(np.float32)
+    # inject ties: plateaus of equal values and duplicated peaks
+    heat[:, :, 3:5, 3:6] = 0.77
+    heat[:, :, H - 1, W - 1] = 0.9
+    heat[:, :, 0, 0] = 0.9
+    ref_nms = ho.nms_hm(heat)
+    h = torch.from_numpy(heat).to(cuda)
+    got_nms = ops.nms_hm(h)
+    assert np.array_equal(got_nms.cpu().numpy(), ref_nms), "nms_hm must be bit-exact"
+    ref = ho.select_topk(ref_nms, K)
+    for fused in (False, True):
+        got = ops.select_topk(h if fused else got_nms, K, fuse_nms=fused)
+        for g_, r_, nm in zip(got, ref, ("scores", "inds", "clses", "ys", "xs")):
+            assert np.array_equal(g_.cpu().numpy(), r_), "%s (fused=%s) must be bit-exact" % (nm, fused)
+
+
+def test_heatmap_few_maxima(cuda):
+    """Fewer than K non-zero maxima: zeros fill the tail in index order."""
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    heat = np.zeros((2, 1, 96, 320), np.float32)
+    heat[0, 0, 10, 10] = 0.5
+    heat[0, 0, 50, 300] = 0.7
+    heat[1, 0, 95, 319] = 0.3
+    ref = ho.select_topk(ho.nms_hm(heat), 50)
+    got = ops.select_topk(torch.from_numpy(heat).to(cuda), 50, fuse_nms=True)
+    for g_, r_ in zip(got, ref):
+        assert np.array_equal(g_.cpu().numpy(), r_)
+
+
+def test_poi_gather_and_scatter(cuda):
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    rng = np.random.RandomState(4)
+    B, C, H, W, M = 3, 415, 24, 40, 40
+    feat = rng.normal(size=(B, C, H, W)).astype(np.float32)
+    pts = np.stack([rng.randint(0, W, (B, M)), rng.randint(0, H, (B, M))], -1).astype(np.int32)
+    pts[:, 1] = pts[:, 0]                              # duplicate centres must accumulate in backward
+    ref = ho.select_point_of_interest(pts.astype(np.int64), feat)
+    f = torch.from_numpy(feat).to(cuda).requires_grad_()
+    got = ops.select_point_of_interest(B, torch.from_numpy(pts).to(cuda), f)
+    assert np.array_equal(got.detach().cpu().numpy(), ref)
+    gen = torch.Generator().manual_seed(0)
+    go = torch.randn(got.shape, generator=gen)
+    got.backward(go.to(cuda))
+    ft = torch.from_numpy(feat).requires_grad_()
+    idx = torch.from_numpy((pts[:, :, 1] * W + pts[:, :, 0]).astype(np.int64))
+    r = ft.permute(0, 2, 3, 1).reshape(B, H * W, C).gather(1, idx[:, :, None].expand(B, M, C))
+    r.backward(go)
+    assert (f.grad.cpu() - ft.grad).abs().max().item() < 1e-5
