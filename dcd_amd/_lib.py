@@ -30,6 +30,7 @@ SIGNATURES = {
     "dcd_heatmap_topk_workspace_bytes": (c_size_t, [c_int] * 5),
     "dcd_poi_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "dcd_poi_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
+    "dcd_iou3d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
 }
 
 STATUS = {1: "bad argument", 2: "workspace too small", 3: "kernel launch failed"}

@@ -496,6 +496,69 @@ __global__ void poi_scatter_kernel(const float *__restrict__ gout, const int64_t
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// 3-D IoU of box pairs (logging metric).  DGDE/model/layers/iou_loss.py:99-136 (shapely there):
+// bird's-eye-view overlap of the two bottom rectangles (corners 0..3, x-z plane) by Sutherland-Hodgman
+// clipping, times the overlap of the height intervals.  One lane per pair.
+// ---------------------------------------------------------------------------------------------
+__device__ __forceinline__ float poly_area(const float *px, const float *py, int n)
+{
+    float a = 0.f;
+    for (int i = 0; i < n; ++i) {
+        const int j = (i + 1 == n) ? 0 : i + 1;
+        a += px[i] * py[j] - px[j] * py[i];
+    }
+    return 0.5f * fabsf(a);
+}
+
+__global__ void iou3d_kernel(const float *__restrict__ A, const float *__restrict__ B, int N, float *__restrict__ iou)
+{
+    const int n = blockIdx.x * blockDim.x + threadIdx.x;
+    if (n >= N) return;
+    const float *a = A + (size_t)n * 24, *b = B + (size_t)n * 24;
+    float ax[4], az[4], bx[4], bz[4];
+    float min_ha = 0.f, max_ha = 0.f, min_hb = 0.f, max_hb = 0.f;
+    for (int k = 0; k < 4; ++k) {
+        ax[k] = a[k * 3 + 0]; az[k] = a[k * 3 + 2];
+        bx[k] = b[k * 3 + 0]; bz[k] = b[k * 3 + 2];
+        min_ha -= a[k * 3 + 1]; max_ha -= a[(k + 4) * 3 + 1];
+        min_hb -= b[k * 3 + 1]; max_hb -= b[(k + 4) * 3 + 1];
+    }
+    min_ha *= 0.25f; max_ha *= 0.25f; min_hb *= 0.25f; max_hb *= 0.25f;
+    const float h_overlap = fmaxf(0.f, fminf(max_ha, max_hb) - fmaxf(min_ha, min_hb));
+    // clip polygon a by the four edges of b
+    float px[16], py[16], qx[16], qy[16];
+    int np = 4;
+    for (int k = 0; k < 4; ++k) { px[k] = ax[k]; py[k] = az[k]; }
+    float orient = 0.f;
+    for (int k = 0; k < 4; ++k) { const int j = (k + 1) & 3; orient += bx[k] * bz[j] - bx[j] * bz[k]; }
+    const float sgn = orient >= 0.f ? 1.f : -1.f;
+    for (int e = 0; e < 4 && np > 0; ++e) {
+        const int e2 = (e + 1) & 3;
+        const float ex = bx[e2] - bx[e], ez = bz[e2] - bz[e];
+        int nq = 0;
+        for (int k = 0; k < np; ++k) {
+            const int j = (k + 1 == np) ? 0 : k + 1;
+            const float sk = sgn * (ex * (py[k] - bz[e]) - ez * (px[k] - bx[e]));
+            const float sj = sgn * (ex * (py[j] - bz[e]) - ez * (px[j] - bx[e]));
+            if (sk >= 0.f) { qx[nq] = px[k]; qy[nq] = py[k]; ++nq; }
+            if ((sk >= 0.f) != (sj >= 0.f)) {
+                const float t = sk / (sk - sj);
+                qx[nq] = px[k] + t * (px[j] - px[k]);
+                qy[nq] = py[k] + t * (py[j] - py[k]);
+                ++nq;
+            }
+        }
+        np = nq;
+        for (int k = 0; k < np; ++k) { px[k] = qx[k]; py[k] = qy[k]; }
+    }
+    const float overlap = (np >= 3) ? poly_area(px, py, np) : 0.f;
+    const float o3 = overlap * h_overlap;
+    const float uni = poly_area(ax, az, 4) * (max_ha - min_ha) + poly_area(bx, bz, 4) * (max_hb - min_hb) - o3;
+    iou[n] = o3 / uni;
+}
+
 inline int grid_for(int64_t n, int block) { int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
 }  // namespace
@@ -610,6 +673,15 @@ int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *ind
     if (!grad_out || !index || !grad_feat || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(poi_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M, total,
                        grad_feat);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_iou3d(void *stream_, const float *pred_corners, const float *target_corners, int N, float *iou)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    if (N == 0) return DCD_OK;
+    if (!pred_corners || !target_corners || !iou || N < 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(iou3d_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred_corners, target_corners, N, iou);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

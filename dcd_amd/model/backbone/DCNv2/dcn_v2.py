@@ -1,0 +1,96 @@
+"""DCNv2 modules on top of the HIP backend (mirrors DGDE/model/backbone/DCNv2/dcn_v2.py:16-128).
+
+`_DCNv2` calls `_backend.dcn_v2_forward/backward` with the reference's positional arguments; `_backend` is
+`dcd_amd._ext` (the C-ABI binding).  There is no CPU implementation: a CPU tensor raises.
+State-dict keys are the reference's: `weight`, `bias`, `conv_offset_mask.{weight,bias}`.
+"""
+import math
+
+import torch
+from torch import nn
+from torch.autograd import Function
+from torch.autograd.function import once_differentiable
+from torch.nn.modules.utils import _pair
+
+from dcd_amd import _ext as _backend
+
+
+class _DCNv2(Function):
+    @staticmethod
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+        ctx.stride = _pair(stride)
+        ctx.padding = _pair(padding)
+        ctx.dilation = _pair(dilation)
+        ctx.kernel_size = _pair(weight.shape[2:4])
+        ctx.deformable_groups = deformable_groups
+        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask,
+                                         ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
+                                         ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1],
+                                         ctx.deformable_groups)
+        ctx.save_for_backward(input, offset, mask, weight, bias)
+        return output
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        input, offset, mask, weight, bias = ctx.saved_tensors
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
+            input.contiguous(), weight.contiguous(), bias, offset, mask, grad_output,
+            ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
+            ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.deformable_groups)
+        return grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None
+
+
+dcn_v2_conv = _DCNv2.apply
+
+
+class DCNv2(nn.Module):
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__()
+        self.in_channels = in_channels
+        self.out_channels = out_channels
+        self.kernel_size = _pair(kernel_size)
+        self.stride = _pair(stride)
+        self.padding = _pair(padding)
+        self.dilation = _pair(dilation)
+        self.deformable_groups = deformable_groups
+        self.weight = nn.Parameter(torch.empty(out_channels, in_channels, *self.kernel_size))
+        self.bias = nn.Parameter(torch.empty(out_channels))
+        self.reset_parameters()
+
+    def reset_parameters(self):
+        # U(-1/sqrt(fan_in), 1/sqrt(fan_in)) weight, zero bias (dcn_v2.py:75-81)
+        fan_in = self.in_channels * self.kernel_size[0] * self.kernel_size[1]
+        bound = 1.0 / math.sqrt(fan_in)
+        self.weight.data.uniform_(-bound, bound)
+        self.bias.data.zero_()
+
+    def forward(self, input, offset, mask):
+        taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        assert offset.shape[1] == 2 * taps and mask.shape[1] == taps
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                           self.deformable_groups)
+
+
+class DCN(DCNv2):
+    """DCNv2 that predicts its own offsets and mask with a zero-initialised conv (dcn_v2.py:97-128)."""
+
+    def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
+        super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
+        taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
+        self.conv_offset_mask = nn.Conv2d(self.in_channels, 3 * taps, kernel_size=self.kernel_size,
+                                          stride=self.stride, padding=self.padding, bias=True)
+        self.init_offset()
+
+    def init_offset(self):
+        self.conv_offset_mask.weight.data.zero_()
+        self.conv_offset_mask.bias.data.zero_()
+
+    def forward(self, input):
+        out = self.conv_offset_mask(input)
+        taps2 = out.shape[1] // 3 * 2
+        # chunk(3) then cat(o1, o2) is the identity on the first 2/3 of the channels (dcn_v2.py:120-121)
+        offset = out[:, :taps2]
+        mask = torch.sigmoid(out[:, taps2:])
+        return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
+                           self.deformable_groups)

@@ -1,0 +1,156 @@
+"""Prediction head (mirrors `_predictor`, DGDE/model/head/detector_predictor.py:18-203).
+
+Module names / shapes equal the reference's so state dicts are interchangeable:
+`class_head` (3x3 conv, BN, ReLU, 1x1 conv), `reg_features[i]` (3x3 conv, BN, ReLU), `reg_heads[i][j]` (1x1 conv),
+`trunc_heatmap_conv`, `trunc_offset_conv` (Conv1d k3 replicate-pad, BN1d, [ReLU], Conv1d k1).
+Differences in execution only: the per-image Python scatter loop of the edge fusion (:193-196, one host sync per
+image) is a single masked `index_put_(accumulate=True)`.
+"""
+import numpy as np
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from dcd_amd.model import registry
+from dcd_amd.model.layers.utils import sigmoid_hm
+from dcd_amd.model.make_layers import group_norm, _fill_fc_weights
+from dcd_amd.model.backbone.DCNv2.dcn_v2 import DCN
+
+
+@registry.PREDICTOR.register("Base_Predictor")
+class _predictor(nn.Module):
+    def __init__(self, cfg, in_channels):
+        super().__init__()
+        classes = cfg.DATASETS.MAX_CLASSES_NUM
+        if classes != len(cfg.DATASETS.DETECT_CLASSES):
+            print('ATTENTION, classes!=len(cfg.DATASETS.DETECT_CLASSES)', classes, len(cfg.DATASETS.DETECT_CLASSES))
+
+        self.regression_head_cfg = cfg.MODEL.HEAD.REGRESSION_HEADS
+        self.regression_channel_cfg = cfg.MODEL.HEAD.REGRESSION_CHANNELS
+        self.output_width = cfg.INPUT.WIDTH_TRAIN // cfg.MODEL.BACKBONE.DOWN_RATIO
+        self.output_height = cfg.INPUT.HEIGHT_TRAIN // cfg.MODEL.BACKBONE.DOWN_RATIO
+        self.head_conv = cfg.MODEL.HEAD.NUM_CHANNEL
+        self.active_func = cfg.MODEL.HEAD.ACTIVE_FUNC
+
+        use_norm = cfg.MODEL.HEAD.USE_NORMALIZATION
+        if use_norm == 'BN':
+            self.norm_func = nn.BatchNorm2d
+        elif use_norm == 'GN':
+            self.norm_func = lambda c: group_norm(c, cfg.MODEL.GROUP_NORM.NUM_GROUPS)
+        else:
+            self.norm_func = nn.Identity
+        self.bn_momentum = cfg.MODEL.HEAD.BN_MOMENTUM
+
+        self.deeper_head = cfg.MODEL.HEAD.DEEPER_HEAD
+        self.stacked_convs = cfg.MODEL.HEAD.STACKED_CONVS
+        self.dcn_on_last_conv = cfg.MODEL.HEAD.DCN_ON_LAST_CONV
+        self.in_channels = in_channels
+        trunk_in = self.head_conv if self.deeper_head else self.in_channels
+
+        # --- classification branch
+        if self.deeper_head:
+            self.cls_head_pre = self._deep_stem()
+        self.class_head = nn.Sequential(
+            nn.Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
+            self.norm_func(self.head_conv), self._get_active_func(),
+            nn.Conv2d(self.head_conv, classes, kernel_size=1, padding=0, bias=True))
+        self.class_head[-1].bias.data.fill_(- np.log(1 / cfg.MODEL.HEAD.INIT_P - 1))
+
+        # --- regression branches: one 3x3 feature conv per head group, one 1x1 conv per key
+        if self.deeper_head:
+            self.reg_head_pre = self._deep_stem()
+        self.reg_features = nn.ModuleList()
+        self.reg_heads = nn.ModuleList()
+        for idx, keys in enumerate(self.regression_head_cfg):
+            self.reg_features.append(nn.Sequential(
+                nn.Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
+                self.norm_func(self.head_conv), self._get_active_func()))
+            heads = nn.ModuleList()
+            for key_index, key in enumerate(keys):
+                out_head = nn.Conv2d(self.head_conv, self.regression_channel_cfg[idx][key_index], kernel_size=1,
+                                     padding=0, bias=True)
+                if key.find('uncertainty') >= 0 and cfg.MODEL.HEAD.UNCERTAINTY_INIT:
+                    torch.nn.init.xavier_normal_(out_head.weight, gain=0.01)
+                if key == '3d_offset':   # the edge fusion is applied to this branch
+                    self.offset_index = [idx, key_index]
+                _fill_fc_weights(out_head, 0)
+                heads.append(out_head)
+            self.reg_heads.append(heads)
+
+        # --- edge (truncation) feature fusion
+        self.enable_edge_fusion = cfg.MODEL.HEAD.ENABLE_EDGE_FUSION
+        self.edge_fusion_kernel_size = cfg.MODEL.HEAD.EDGE_FUSION_KERNEL_SIZE
+        self.edge_fusion_relu = cfg.MODEL.HEAD.EDGE_FUSION_RELU
+        if self.enable_edge_fusion:
+            norm1d = nn.BatchNorm1d if cfg.MODEL.HEAD.EDGE_FUSION_NORM == 'BN' else nn.Identity
+            k = self.edge_fusion_kernel_size
+
+            def edge_branch(out_ch):
+                act = nn.ReLU(inplace=True) if self.edge_fusion_relu else nn.Identity()
+                return nn.Sequential(
+                    nn.Conv1d(self.head_conv, self.head_conv, kernel_size=k, padding=k // 2, padding_mode='replicate'),
+                    norm1d(self.head_conv), act, nn.Conv1d(self.head_conv, out_ch, kernel_size=1))
+            self.trunc_heatmap_conv = edge_branch(classes)
+            self.trunc_offset_conv = edge_branch(2)
+
+    def _get_active_func(self):
+        if self.active_func == 'relu':
+            return nn.ReLU(inplace=True)
+        if self.active_func == 'leaky_relu':
+            return nn.LeakyReLU(inplace=True)
+        raise ValueError('No such activate func')
+
+    def _deep_stem(self):
+        """Optional conv + DCN stem used when MODEL.HEAD.DEEPER_HEAD is set (detector_predictor.py:134-151)."""
+        return nn.Sequential(
+            nn.Conv2d(self.in_channels, self.head_conv, kernel_size=3, padding=1, bias=False),
+            self.norm_func(self.head_conv), self._get_active_func(),
+            DCN(self.head_conv, self.head_conv, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1),
+            self.norm_func(self.head_conv), self._get_active_func())
+
+    def _edge_fusion(self, feature_cls, reg_feature, output_cls, output_reg, targets):
+        """Sample both feature maps along the image border, run the two Conv1d branches and add the result back
+        at the border cells (detector_predictor.py:172-196)."""
+        b = feature_cls.shape[0]
+        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])          # B x K x 2 (x, y)
+        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)       # B x 1
+        out_w = torch.stack([t.get_field("final_output_w") for t in targets]).float().view(-1, 1, 1)
+        out_h = torch.stack([t.get_field("final_output_h") for t in targets]).float().view(-1, 1, 1)
+
+        grid = edge_indices.view(b, -1, 1, 2).float()
+        grid = torch.stack((grid[..., 0] / (out_w - 1) * 2 - 1, grid[..., 1] / (out_h - 1) * 2 - 1), dim=-1)
+        fused = torch.cat((feature_cls, reg_feature), dim=1)
+        edge_features = F.grid_sample(fused, grid.type_as(fused), align_corners=True).squeeze(-1)
+        edge_cls_output = self.trunc_heatmap_conv(edge_features[:, :self.head_conv, ...])
+        edge_offset_output = self.trunc_offset_conv(edge_features[:, self.head_conv:, ...])
+
+        K = edge_indices.shape[1]
+        valid = (torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens).to(edge_cls_output.dtype)
+        bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
+        yi = edge_indices[:, :, 1].long().view(b, 1, K)
+        xi = edge_indices[:, :, 0].long().view(b, 1, K)
+        for out, vals in ((output_cls, edge_cls_output), (output_reg, edge_offset_output)):
+            ci = torch.arange(out.shape[1], device=out.device).view(1, -1, 1)
+            out.index_put_((bi, ci, yi, xi), vals * valid.unsqueeze(1), accumulate=True)
+
+    def forward(self, features, targets):
+        feat_cls_in = self.cls_head_pre(features) if self.deeper_head else features
+        feature_cls = self.class_head[:-1](feat_cls_in)
+        output_cls = self.class_head[-1](feature_cls)
+
+        feat_reg_in = self.reg_head_pre(features) if self.deeper_head else features
+        output_regs = []
+        for i, feat_layer in enumerate(self.reg_features):
+            reg_feature = feat_layer(feat_reg_in)
+            for j, out_head in enumerate(self.reg_heads[i]):
+                output_reg = out_head(reg_feature)
+                if self.enable_edge_fusion and i == self.offset_index[0] and j == self.offset_index[1]:
+                    self._edge_fusion(feature_cls, reg_feature, output_cls, output_reg, targets)
+                output_regs.append(output_reg)
+
+        output_cls = sigmoid_hm(output_cls)
+        return {'cls': output_cls.float(), 'reg': torch.cat(output_regs, dim=1).float()}
+
+
+def make_predictor(cfg, in_channels):
+    return registry.PREDICTOR[cfg.MODEL.HEAD.PREDICTOR](cfg, in_channels)

@@ -229,3 +229,14 @@ def select_point_of_interest(batch, index, feature_maps):
         index = index[:, :, 1] * w + index[:, :, 0]
     index = index.reshape(batch, -1)
     return _POI.apply(feature_maps, index)
+
+
+def iou_3d(pred_corners, target_corners):
+    """(N,8,3) x (N,8,3) -> (N) 3-D IoU (BEV rectangle overlap x height overlap); no gradient."""
+    _lib.require_cuda(pred_corners, target_corners)
+    a, b = _f32c(pred_corners.detach()), _f32c(target_corners.detach())
+    N = a.shape[0]
+    out = torch.empty(N, dtype=torch.float32, device=a.device)
+    st = _lib.lib().dcd_iou3d(_lib.stream_of(a), a.data_ptr(), b.data_ptr(), N, out.data_ptr())
+    _lib.check(st, "dcd_iou3d")
+    return out

@@ -143,6 +143,13 @@ int dcd_poi_gather(void *stream, const float *feat, const int64_t *index, int B,
 int dcd_poi_scatter_add(void *stream, const float *grad_out, const int64_t *index, int B, int C, int H, int W,
                         int M, float *grad_feat);
 
+/* ------------------------------------------------------------------------------------------------
+ * 3-D IoU of N box pairs (a logging metric of the train step).  Replaces get_iou_3d
+ * (DGDE/model/layers/iou_loss.py:99-136, a per-object shapely loop on the host).
+ * corners (N,8,3): 0..3 bottom face, 4..7 top face, camera frame (y down).  iou (N).
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corners, int N, float *iou);
+
 #ifdef __cplusplus
 }
 #endif
