@@ -1,0 +1,250 @@
+#!/usr/bin/env python3
+"""DGDE train-step benchmark on MI355X:  images/sec at global batch 8, 384x1280, fp32 (BASELINE.json configs[1]).
+
+  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+
+A step = forward + 13-term loss + backward + gradient all-reduce (RCCL, N>1) + grad clip + AdamW, on a synthetic
+KITTI-shaped batch that is resident in HBM before the timed region.  The batch named by the metric (8 images) is
+split over the ranks like the reference does (IMS_PER_BATCH // world, DGDE/data/build.py:63-67), so the total work is
+fixed: "scaling": "strong"  (`--scaling weak` keeps 8 images per GPU instead).
+
+One JSON line on rank 0.  Besides the driver's contract it carries
+  roofline     -- DCNv2 forward+backward of the 16 DLA-34 DCN layers: algorithmic bytes (computed
+                  from the layer list below) / time of those calls measured with events on the launch stream, inside the
+                  timed steps; peak = 8 TB/s HBM (north_star's yardstick).  `mfma` repeats it against the matrix peak.
+  cpu_baseline -- the same train step on the host cores with the CPU oracle (oracle/, "port") on a bounded sample.
+"""
+import argparse
+import json
+import os
+import subprocess
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+# (Cin, Cout, H, W, count) of the 16 DCN layers at 384x1280
+DCN_LAYERS = [(512, 256, 12, 40, 1), (256, 256, 24, 80, 1), (256, 128, 24, 80, 2), (128, 128, 48, 160, 2),
+              (128, 64, 48, 160, 4), (64, 64, 96, 320, 5), (256, 64, 24, 80, 1)]
+HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0}
+
+
+def dcn_algorithmic(batch):
+    """(bytes fwd+bwd, GEMM flops fwd+bwd) of the 16 layers: every operand read once, every result written once,
+    no column buffer."""
+    by = fl = 0
+    for cin, cout, h, w, n in DCN_LAYERS:
+        hw = h * w
+        fwd = 4 * (batch * hw * (cin + 27 + cout) + 9 * cin * cout + cout)
+        bwd = 4 * (batch * hw * (cin + 27 + cout) + 9 * cin * cout) + 4 * (batch * hw * (cin + 27) + 9 * cin * cout + cout)
+        by += n * (fwd + bwd)
+        fl += n * 3 * 2 * batch * cout * 9 * cin * hw
+    return by, fl
+
+
+class DcnTimer:
+    """Wraps dcd_amd._ext.dcn_v2_forward/backward with event pairs recorded on the current (= launch) stream."""
+
+    def __init__(self, torch, ext):
+        self.torch, self.ext = torch, ext
+        self.pairs = []
+        self.enabled = False
+        self._f, self._b = ext.dcn_v2_forward, ext.dcn_v2_backward
+        ext.dcn_v2_forward = self._wrap(self._f)
+        ext.dcn_v2_backward = self._wrap(self._b)
+
+    def _wrap(self, fn):
+        def timed(*a, **k):
+            if not self.enabled:
+                return fn(*a, **k)
+            e0, e1 = self.torch.cuda.Event(enable_timing=True), self.torch.cuda.Event(enable_timing=True)
+            e0.record()
+            out = fn(*a, **k)
+            e1.record()
+            self.pairs.append((e0, e1))
+            return out
+        return timed
+
+    def total_ms(self):
+        return sum(a.elapsed_time(b) for a, b in self.pairs)
+
+
+def build_everything(args, device, world, local_rank):
+    import torch
+    from dcd_amd import _ext
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, wrap_distributed
+    from dcd_amd.model.detector import KeypointDetector
+
+    _ext.set_precision(args.precision)
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg)
+    init_like_trained(model, std=0.01, seed=0)
+    model = model.to(device).train()
+    optimizer = build_optimizer(model, cfg)
+    model = wrap_distributed(model, cfg, local_rank)
+    per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
+    rank = int(os.environ.get("RANK", 0))
+    images, targets = make_batch(per_rank, seed=100 + rank, n_objects=args.objects, device=device)
+    return cfg, model, optimizer, images, targets, per_rank
+
+
+def run_gpu(args):
+    import torch
+    import torch.distributed as dist
+    from dcd_amd import _ext
+    from dcd_amd.engine.trainer import train_step
+
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
+            args.gpus, world, args.gpus))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
+    torch.backends.cudnn.benchmark = True
+
+    cfg, model, optimizer, images, targets, per_rank = build_everything(args, device, world, local_rank)
+    timer = DcnTimer(torch, _ext)
+    clip = cfg.SOLVER.GRAD_NORM_CLIP
+
+    for _ in range(args.warmup):
+        train_step(model, optimizer, images, targets, clip)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    fence()
+    timer.enabled = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        train_step(model, optimizer, images, targets, clip)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timer.enabled = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    global_batch = per_rank * world
+    dcn_ms = timer.total_ms() / max(args.steps, 1)                      # per step, this rank's share of the batch
+    by, fl = dcn_algorithmic(per_rank)
+    out = None
+    if rank == 0:
+        out = {
+            "metric": "images/sec DGDE train step (bs=8, 384x1280)", "value": global_batch * args.steps / elapsed,
+            "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": "DGDE train bs=%d fp32 on %dxMI355X, synthetic KITTI 384x1280 + random kpts_ann "
+                                   "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (global_batch, world, args.objects),
+                       "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
+                       "parallelism": "dp%d" % world, "dcn_precision": args.precision,
+                       "sync_bn": bool(world > 1)},
+            "roofline": {"bound": "hbm", "kernel": "DCNv2 fwd+bwd, 16 layers, batch %d per GPU" % per_rank,
+                         "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
+                         "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
+                         "traffic": load_traffic(per_rank), "algorithmic_bytes": by, "ms_per_step": dcn_ms,
+                         "calls_per_step": len(timer.pairs) // max(args.steps, 1)},
+            "roofline_mfma": {"bound": "mfma", "achieved": fl / 1e12 / (dcn_ms / 1e3) if dcn_ms > 0 else None,
+                              "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
+                              "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[args.precision] if dcn_ms > 0 else None,
+                              "flops": fl},
+        }
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def load_traffic(per_rank):
+    """HBM bytes per step of the DCN kernels from the PMC pass (profiles/dcn_traffic.json, written by
+    tools/pmc_traffic.py after a separate `rocprofv3 --pmc` run), or None when that pass has not been made."""
+    path = os.path.join(ROOT, "profiles", "dcn_traffic.json")
+    try:
+        with open(path) as f:
+            d = json.load(f)
+        return d.get("bytes_per_step_batch%d" % per_rank)
+    except (OSError, ValueError):
+        return None
+
+
+def cpu_baseline_child(args):
+    """Runs in a child process: the same train step on the host cores with the oracle patched in (kind "port")."""
+    import torch
+    from dcd_amd import ops
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step
+    from dcd_amd.model.backbone.DCNv2 import dcn_v2
+    from dcd_amd.model.detector import KeypointDetector
+    from oracle import dcn_oracle, torch_ops
+    for name in ("pairs_kpts_depth", "compute_z", "focal_loss", "giou_loss", "nms_hm", "select_topk",
+                 "select_point_of_interest", "iou_3d"):
+        setattr(ops, name, getattr(torch_ops, name))
+    dcn_v2._backend = dcn_oracle
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).train()
+    init_like_trained(model)
+    opt = build_optimizer(model, cfg)
+    images, targets = make_batch(args.cpu_batch, seed=100, n_objects=args.objects)
+    t0 = time.perf_counter()
+    train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    dt = time.perf_counter() - t0
+    print(json.dumps({"value": args.cpu_batch / dt, "unit": "images/s", "cores": torch.get_num_threads(),
+                      "kind": "port", "host_cpus": os.cpu_count(),
+                      "sample": "1 full DGDE train step (fwd+loss+bwd+AdamW) at bs=%d, 384x1280, %d objects/image, "
+                                "oracle DCNv2 (C, OpenMP) + PyTorch CPU convs; %.1f s" % (args.cpu_batch, args.objects, dt)}))
+
+
+def cpu_baseline(args):
+    cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-batch", str(args.cpu_batch),
+           "--objects", str(args.objects)]
+    env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
+    try:
+        res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
+        line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
+        return json.loads(line)
+    except Exception as e:  # a missing baseline must not kill the GPU number
+        return {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=8, help="global batch (strong) or per-GPU batch (weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--objects", type=int, default=6)
+    ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-batch", type=int, default=1)
+    ap.add_argument("--cpu-timeout", type=int, default=420)
+    ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    args = ap.parse_args()
+    if args.cpu_baseline_child:
+        cpu_baseline_child(args)
+        return
+    out = run_gpu(args)
+    if out is not None:
+        if args.gpus == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(args)
+        print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

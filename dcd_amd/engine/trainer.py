@@ -1,0 +1,102 @@
+"""Train-step pieces the benchmark and a `tools/plain_train_net.py`-style driver need.
+
+Mirrors the semantics of the reference's harness without copying it:
+  build_optimizer  <- DGDE/solver/__init__.py:10-62   AdamW(betas=(0.9,0.99), wd), bias parameters at lr x BIAS_LR_FACTOR
+  build_scheduler  <- DGDE/solver/__init__.py:64-92   step decay (LambdaLR) + cosine warm-up from lr/DIV_FACTOR
+  wrap_distributed <- DGDE/tools/plain_train_net.py:54-62   SyncBN conversion + DDP (one process per GPU, RCCL)
+  train_step       <- DGDE/engine/trainer.py:121-155  forward, sum of losses, backward, clip, optimizer step
+"""
+import math
+
+import torch
+from torch import nn
+
+from dcd_amd.utils import comm
+
+
+def build_optimizer(model, cfg):
+    """Same per-parameter learning rates as the reference (one group per parameter there); parameters are pooled
+    into two groups (weights, biases) so the optimizer runs as a handful of fused kernels instead of 290 x k."""
+    s = cfg.SOLVER
+    weights, biases = [], []
+    for name, p in model.named_parameters():
+        if p.requires_grad:
+            (biases if "bias" in name else weights).append(p)
+    groups = [{"params": weights, "lr": s.BASE_LR},
+              {"params": biases, "lr": max(s.BASE_LR, s.BASE_LR * s.BIAS_LR_FACTOR)}]
+    fused = all(p.is_cuda for p in weights + biases)
+    if s.OPTIMIZER == "adamw":
+        return torch.optim.AdamW(groups, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=fused)
+    if s.OPTIMIZER == "adam":
+        return torch.optim.Adam(groups, lr=s.BASE_LR, weight_decay=s.WEIGHT_DECAY, betas=(0.9, 0.99), fused=fused)
+    raise NotImplementedError("SOLVER.OPTIMIZER=%s" % s.OPTIMIZER)
+
+
+class CosineWarmupLR(torch.optim.lr_scheduler.LRScheduler):
+    """lr(t) = eta_min + (base - eta_min) * (1 - cos(pi t / T_max)) / 2 (DGDE/solver/learning_schedules_fastai.py)."""
+
+    def __init__(self, optimizer, T_max, eta_min=0.0, last_epoch=-1):
+        self.T_max, self.eta_min = T_max, eta_min
+        super().__init__(optimizer, last_epoch)
+
+    def get_lr(self):
+        return [self.eta_min + (b - self.eta_min) * (1 - math.cos(math.pi * self.last_epoch / self.T_max)) / 2
+                for b in self.base_lrs]
+
+
+def build_scheduler(optimizer, cfg):
+    s = cfg.SOLVER
+
+    def decay(it):
+        f = 1.0
+        for step in s.STEPS:
+            if it >= step:
+                f *= s.LR_DECAY
+        return max(f, s.LR_CLIP / s.BASE_LR)
+    sched = torch.optim.lr_scheduler.LambdaLR(optimizer, decay)
+    warm = CosineWarmupLR(optimizer, T_max=s.WARMUP_STEPS, eta_min=s.BASE_LR / s.DIV_FACTOR) if s.LR_WARMUP else None
+    return sched, warm
+
+
+def wrap_distributed(model, cfg, local_rank):
+    """SyncBN (when MODEL.USE_SYNC_BN) + DistributedDataParallel over RCCL.  Unlike the reference no unused-parameter
+    search is needed (the ImageNet `fc` is never attached), and gradients live in the all-reduce buckets."""
+    if comm.get_world_size() == 1:
+        return model
+    # parameters that structurally never get a gradient (the reason the reference needs find_unused_parameters=True,
+    # besides the ImageNet `fc`): freeze them so DDP does not wait for their all-reduce.  Equivalent to the reference,
+    # whose optimizer skips parameters whose grad is None.
+    for m in model.modules():
+        if getattr(m, "dead_project", False):
+            for p in m.project.parameters():
+                p.requires_grad_(False)
+    if cfg.MODEL.USE_SYNC_BN:
+        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+    kw = dict(broadcast_buffers=False, find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=32)
+    if next(model.parameters()).is_cuda:
+        kw.update(device_ids=[local_rank], output_device=local_rank)
+    return nn.parallel.DistributedDataParallel(model, **kw)
+
+
+def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler=None, iteration=None):
+    """One optimisation step; returns (loss_dict, log_loss_dict)."""
+    loss_dict, log_loss_dict = model(images, targets)
+    losses = sum(loss_dict.values())
+    optimizer.zero_grad(set_to_none=True)
+    losses.backward()
+    if grad_norm_clip and grad_norm_clip > 0:
+        nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
+    optimizer.step()
+    if scheduler is not None:
+        scheduler.step(iteration) if iteration is not None else scheduler.step()
+    return loss_dict, log_loss_dict
+
+
+def init_like_trained(model, std=0.01, seed=0):
+    """The reference zero-initialises `conv_offset_mask`, which turns every DCN into a plain conv x 0.5; benchmarks use
+    N(0, std^2) offset/mask weights so sampling positions are non-trivial."""
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if "conv_offset_mask.weight" in name:
+                p.copy_(torch.randn(p.shape, generator=g) * std)

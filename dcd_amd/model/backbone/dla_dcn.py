@@ -84,6 +84,10 @@ class Tree(nn.Module):
         self.project = None
         if in_channels != out_channels:
             self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False), _bn(out_channels))
+        # For levels > 1 the projected residual is handed to `tree1`, which is itself a Tree and recomputes its own
+        # (dla_dcn.py:246-250 of the reference): this module's `project` then never receives a gradient.  It is still
+        # executed so its BN buffers evolve exactly as in the reference; DDP is told about it (engine/trainer.py).
+        self.dead_project = levels > 1 and self.project is not None
 
     def forward(self, x, residual=None, children=None):
         children = [] if children is None else children

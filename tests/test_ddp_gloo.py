@@ -1,0 +1,84 @@
+"""The N>1 path on CPU: two processes, gloo backend, DistributedDataParallel around the detector.
+Checks what the RCCL path relies on: (1) after a step every rank holds identical parameters, (2) the gradient each
+rank steps with is the mean of the per-rank local gradients (pure data parallelism, one exchange per step)."""
+import os
+import socket
+import sys
+
+import pytest
+import torch
+import torch.distributed as dist
+import torch.multiprocessing as mp
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _free_port():
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    # test-only: run the host logic on CPU through the oracle (the product has no CPU path)
+    from dcd_amd import ops
+    from dcd_amd.model.backbone.DCNv2 import dcn_v2
+    from oracle import dcn_oracle, torch_ops
+    for name in ("pairs_kpts_depth", "compute_z", "focal_loss", "giou_loss", "nms_hm", "select_topk",
+                 "select_point_of_interest", "iou_3d"):
+        setattr(ops, name, getattr(torch_ops, name))
+    dcn_v2._backend = dcn_oracle
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step, wrap_distributed
+    from dcd_amd.model.detector import KeypointDetector
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False,
+                        "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).train()
+    init_like_trained(model)
+    images, targets = make_batch(1, seed=10 + rank, n_objects=3, input_size=(320, 96))
+
+    # local gradient without any communication
+    loss_dict, _ = model(images, targets)
+    sum(loss_dict.values()).backward()
+    local = torch.cat([p.grad.flatten() for p in model.parameters() if p.grad is not None])
+    model.zero_grad(set_to_none=True)
+    for m in model.modules():          # undo the BN running-stat update of the probe pass
+        if isinstance(m, torch.nn.modules.batchnorm._BatchNorm):
+            m.reset_running_stats()
+    gathered = [torch.zeros_like(local) for _ in range(world)]
+    dist.all_gather(gathered, local)
+    expected = torch.stack(gathered).mean(0)
+
+    ddp = wrap_distributed(model, cfg, local_rank=rank)
+    assert isinstance(ddp, torch.nn.parallel.DistributedDataParallel)
+    opt = build_optimizer(ddp, cfg)
+    loss_dict, _ = ddp(images, targets)
+    sum(loss_dict.values()).backward()
+    got = torch.cat([p.grad.flatten() for p in ddp.parameters() if p.grad is not None])
+    err = (got - expected).abs().max().item() / expected.abs().max().item()
+    ddp.zero_grad(set_to_none=True)
+    train_step(ddp, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    flat = torch.cat([p.detach().flatten() for p in ddp.parameters()])
+    others = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(others, flat)
+    same = all(torch.equal(others[0], o) for o in others)
+    torch.save({"err": err, "same": same}, os.path.join(out_dir, "r%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(600)
+def test_ddp_world_size_2_gloo(tmp_path, oracle_dcn):
+    port = _free_port()
+    mp.spawn(_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
+        assert res["err"] < 1e-5, "DDP gradient != mean of local gradients (%g)" % res["err"]
+        assert res["same"], "parameters diverged across ranks after one step"
