@@ -111,7 +111,7 @@ def run_gpu(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
-    torch.backends.cudnn.benchmark = True
+    torch.backends.cudnn.benchmark = False     # MIOpen exhaustive find on a fresh box costs minutes; use its heuristics
 
     cfg, model, optimizer, images, targets, per_rank = build_everything(args, device, world, local_rank)
     timer = DcnTimer(torch, _ext)

@@ -47,6 +47,9 @@ def lib():
             raise DcdHipError(
                 "libdcd_hip.so is not built (%s missing). The DGDE hot path has no CPU fallback; "
                 "build it with `make -C dcd_amd/csrc` or `__graft_entry__.build()`." % LIB_PATH)
+        # PyTorch-ROCm bundles its own libamdhip64; it must be the HIP runtime already in the process when our
+        # library is loaded, otherwise the kernels register with a second runtime and every launch on a torch stream fails.
+        import torch  # noqa: F401
         handle = ctypes.CDLL(LIB_PATH)
         for name, (res, args) in SIGNATURES.items():
             fn = getattr(handle, name)

@@ -470,6 +470,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                        int precision, void *workspace, size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     Geom g;
     if (!input || !weight || !bias || !offset || !mask || !output || !workspace) return DCD_ERR_BAD_ARG;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
@@ -502,6 +503,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 {
     (void)bias;
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     Geom g;
     if (!input || !weight || !offset || !mask || !grad_output || !grad_input || !grad_offset || !grad_mask ||
         !grad_weight || !grad_bias || !workspace)

@@ -572,6 +572,7 @@ int dcd_edge_depth_forward(void *stream_, const float *kps, const float *kps3d, 
                            int sub_b3, float *depth, int32_t *pair_idx, float *pair_mask)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (N == 0) return DCD_OK;
     if (!kps || !kps3d || !rot_y || !P || !depth || N < 0 || K < 2 || K > EDGE_MAXK) return DCD_ERR_BAD_ARG;
     const int npairs = K * (K - 1) / 2;
@@ -590,6 +591,7 @@ int dcd_edge_depth_backward(void *stream_, const float *kps, const float *kps3d,
                             float zmax, int normalized, float *grad_kps, float *grad_kps3d)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (N == 0) return DCD_OK;
     if (!kps || !kps3d || !rot_y || !P || !grad_depth || !grad_kps || !grad_kps3d || N < 0 || K < 2 || K > EDGE_MAXK)
         return DCD_ERR_BAD_ARG;
@@ -603,6 +605,7 @@ int dcd_focal_loss(void *stream_, const float *pred, const float *target, int64_
                    float *grad_pred)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (!pred || !target || !out || n < 0) return DCD_ERR_BAD_ARG;
     if (hipMemsetAsync(out, 0, 2 * sizeof(float), stream) != hipSuccess) return DCD_ERR_LAUNCH;
     if (n == 0) return DCD_OK;
@@ -614,6 +617,7 @@ int dcd_focal_loss(void *stream_, const float *pred, const float *target, int64_
 int dcd_giou_loss(void *stream_, const float *pred, const float *target, int N, float *losses, float *ious, float *grad_pred)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (N == 0) return DCD_OK;
     if (!pred || !target || !losses || !ious || N < 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(giou_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred, target, N, losses, ious, grad_pred);
@@ -623,6 +627,7 @@ int dcd_giou_loss(void *stream_, const float *pred, const float *target, int N, 
 int dcd_nms_hm(void *stream_, const float *heat, int B, int C, int H, int W, float *out)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (!heat || !out || B < 0 || C <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
     const int64_t total = (int64_t)B * C * H * W;
     if (total == 0) return DCD_OK;
@@ -641,6 +646,7 @@ int dcd_heatmap_topk(void *stream_, const float *heat, int B, int C, int H, int 
                      int64_t *inds, float *clses, float *ys, float *xs, void *workspace, size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (B == 0) return DCD_OK;
     if (!heat || !scores || !inds || !clses || !ys || !xs || !workspace) return DCD_ERR_BAD_ARG;
     if (B < 0 || C <= 0 || H <= 0 || W <= 0 || K <= 0 || K > TOPK_MAXK || (int64_t)H * W > (1 << 24) || K > H * W ||
@@ -657,6 +663,7 @@ int dcd_heatmap_topk(void *stream_, const float *heat, int B, int C, int H, int 
 int dcd_poi_gather(void *stream_, const float *feat, const int64_t *index, int B, int C, int H, int W, int M, float *out)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     const int64_t total = (int64_t)B * M * C;
     if (total == 0) return DCD_OK;
     if (!feat || !index || !out || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
@@ -668,6 +675,7 @@ int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *ind
                         float *grad_feat)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     const int64_t total = (int64_t)B * M * C;
     if (total == 0) return DCD_OK;
     if (!grad_out || !index || !grad_feat || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
@@ -679,6 +687,7 @@ int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *ind
 int dcd_iou3d(void *stream_, const float *pred_corners, const float *target_corners, int N, float *iou)
 {
     hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
     if (N == 0) return DCD_OK;
     if (!pred_corners || !target_corners || !iou || N < 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(iou3d_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred_corners, target_corners, N, iou);

@@ -166,7 +166,7 @@ def name_hashed_init(model):
             elif name.endswith("running_var"):
                 t.fill_(1.0)
             elif "conv_offset_mask.weight" in name:
-                t.copy_(torch.from_numpy(rng.normal(0, 0.05, tuple(t.shape)).astype(np.float32)))
+                t.copy_(torch.from_numpy(rng.normal(0, 0.01, tuple(t.shape)).astype(np.float32)))
             elif t.dim() > 1:
                 fan_in = int(np.prod(t.shape[1:]))
                 a = 1.0 / np.sqrt(fan_in)
