@@ -88,6 +88,7 @@ struct Tap {
     float w1, w2, w3, w4;    // bilinear weights, zero for corners outside the image / invalid samples
     float lh, lw, hh, hw;    // fractional parts (for the coordinate gradient)
     float m;                 // modulation mask (0 when the sample is invalid or the pixel is padding)
+    float oh, ow;            // raw offsets of this tap
     bool c1, c2, c3, c4;     // corner validity
 };
 
@@ -121,7 +122,23 @@ __device__ __forceinline__ Tap make_tap(const float *__restrict__ off_b, const f
     s.w3 = s.c3 ? s.lh * s.hw : 0.f;
     s.w4 = s.c4 ? s.lh * s.lw : 0.f;
     s.m = sv ? m : 0.f;
+    s.oh = oh;
+    s.ow = ow;
     return s;
+}
+
+// Workgroups are dealt to the 8 XCDs round-robin by linear id (observed, speed only).  Re-map (blockIdx.x, blockIdx.y)
+// = (tile group, image) so that each XCD walks one CONTIGUOUS run of tiles: neighbouring tiles share their input halo,
+// and a run's footprint then fits that XCD's 4 MiB L2 instead of every XCD touching every image row.  Bijective for any grid.
+__device__ __forceinline__ void xcd_remap(int &bx, int &by)
+{
+    const int gx = gridDim.x, NT = gx * gridDim.y;
+    const int L = bx + gx * by;
+    const int xc = L & 7, slot = L >> 3;
+    const int q = NT >> 3, r = NT & 7;
+    const int Lp = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + slot;
+    by = Lp / gx;
+    bx = Lp - by * gx;
 }
 
 // Uniform base + 32-bit per-lane BYTE offset -> `global_load_dword v, v_off, s[base:base+1]`.
@@ -140,9 +157,10 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int tile = bx * 4 + wave;
     if (tile * 32 >= g.HoWo) return;  // wave-uniform
-    const int b = blockIdx.y;
     const int ob0 = blockIdx.z * MB;
     const int P = tile * 32 + p;
     const bool pv = P < g.HoWo;
@@ -170,26 +188,47 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
         const float *wp = wf + (size_t)seg * g.cpgp * g.Cop;              // uniform, advanced 2 rows per step
         const unsigned o1 = (unsigned)s.i1 * 4u + h * HW4, o2 = (unsigned)s.i2 * 4u + h * HW4;
         const unsigned o3 = (unsigned)s.i3 * 4u + h * HW4, o4 = (unsigned)s.i4 * 4u + h * HW4;
-        auto step = [&](const float *ipc, const float *wpc) {
-            const float v1 = ldg(ipc, o1), v2 = ldg(ipc, o2), v3 = ldg(ipc, o3), v4 = ldg(ipc, o4);
-            float a[MB];
+        // Two register stages of UN channel pairs each: the loads of stage B are in flight while stage A feeds the
+        // matrix pipe (the gather addresses depend only on the tap, never on loaded data, so they prefetch freely).
+        constexpr int UN = (MB >= 4) ? 2 : 4;
+        float va[UN][4], vb[UN][4], wa[UN][MB], wb_[UN][MB];
+        auto issue = [&](float (&v)[UN][4], float (&a)[UN][MB], int it0) {
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) a[mb] = ldg(wpc, wlane + mb * 128u);
+            for (int u = 0; u < UN; ++u) {
+                const float *ipc = (const float *)((const char *)ip + (size_t)(it0 + u) * 2 * HW4);
+                const float *wpc = (const float *)((const char *)wp + (size_t)(it0 + u) * 2 * Cop4);
+                v[u][0] = ldg(ipc, o1); v[u][1] = ldg(ipc, o2); v[u][2] = ldg(ipc, o3); v[u][3] = ldg(ipc, o4);
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) a[u][mb] = ldg(wpc, wlane + mb * 128u);
+            }
+        };
+        auto compute = [&](float (&v)[UN][4], float (&a)[UN][MB]) {
+#pragma unroll
+            for (int u = 0; u < UN; ++u) {
+                const float val = (s.w1 * v[u][0] + s.w2 * v[u][1] + s.w3 * v[u][2] + s.w4 * v[u][3]) * s.m;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], val, acc[mb], 0, 0, 0);
+            }
+        };
+        const int nfull = npair / UN;
+        int gq = 0;
+        if (nfull > 0) issue(va, wa, 0);
+        for (; gq + 1 < nfull; gq += 2) {
+            issue(vb, wb_, (gq + 1) * UN);
+            compute(va, wa);
+            if (gq + 2 < nfull) issue(va, wa, (gq + 2) * UN);
+            compute(vb, wb_);
+        }
+        if (gq < nfull) compute(va, wa);
+        for (int it = nfull * UN; it < npair; ++it) {      // remainder pairs (channel counts not divisible by 2*UN)
+            const float *ipc = (const float *)((const char *)ip + (size_t)it * 2 * HW4);
+            const float *wpc = (const float *)((const char *)wp + (size_t)it * 2 * Cop4);
+            const float v1 = ldg(ipc, o1), v2 = ldg(ipc, o2), v3 = ldg(ipc, o3), v4 = ldg(ipc, o4);
             const float val = (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * s.m;
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[mb], val, acc[mb], 0, 0, 0);
-        };
-        constexpr int UN = (MB >= 8) ? 2 : 4;
-        int it = 0;
-        for (; it + UN <= npair; it += UN) {
-#pragma unroll
-            for (int u = 0; u < UN; ++u)
-                step((const float *)((const char *)ip + (size_t)(it + u) * 2 * HW4),
-                     (const float *)((const char *)wp + (size_t)(it + u) * 2 * Cop4));
+            for (int mb = 0; mb < MB; ++mb)
+                acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldg(wpc, wlane + mb * 128u), val, acc[mb], 0, 0, 0);
         }
-        for (; it < npair; ++it)
-            step((const float *)((const char *)ip + (size_t)it * 2 * HW4),
-                 (const float *)((const char *)wp + (size_t)it * 2 * Cop4));
         ip = (const float *)((const char *)ip + (size_t)npair * 2 * HW4);
         wp = (const float *)((const char *)wp + (size_t)npair * 2 * Cop4);
         if (g.cpg & 1) {  // odd channel count: the h==1 half has no channel left (its weight row is zero padding)
@@ -216,6 +255,197 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
 }
 
 // ---------------------------------------------------------------------------------------------
+// Atomic-free grad_input.
+//
+// Measured on MI355X (tools/micro/atomics.hip): global fp32 atomics retire ~21 G cache-line requests/s
+// (305 G lane-atomics/s even when perfectly coalesced) and LDS fp32 atomics ~200 G/s chip-wide; the
+// reference's col2im scatter needs 36 atomics per (channel, pixel) = 5.2 G per bs-8 step.  So the scatter
+// is turned into a gather: every sampling position is shared by all channels of a deformable group, hence
+// the INVERSE map "input cell q, tap t -> {(output pixel p, weight)}" is built once per call
+// (dcn_build_inverse, a bounded window search, no atomics, deterministic order) and
+//     grad_input[c,q] = sum_{t,o} W[o,t,c] * G_t[o,q],     G_t[o,q] = sum_{(p,w) in list(q,t)} w * dY[o,p]
+// is evaluated exactly like the forward: the lane computes G as its MFMA B operand (dcn_bwd_input_f32).
+// Samples whose offset exceeds the search radius, and cells that collect more than INV_CAP samples of one
+// tap, fall back to atomics inside dcn_bwd_data_f32 -- correct for any input, fast for realistic offsets.
+// ---------------------------------------------------------------------------------------------
+constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
+constexpr int INV_RCAP = 3;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
+constexpr int INV_OVERFLOW = 255;
+
+struct InvLists {
+    const unsigned *absmax_bits;   // float bits of max |offset| over the call (device scalar)
+    unsigned char *cnt;            // [B][S][HW]
+    int *idx;                      // [B][S][INV_CAP][HW]
+    float *w;                      // [B][S][INV_CAP][HW]
+};
+
+__device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
+{
+    const float m = __uint_as_float(*absmax_bits);
+    int r = (m == m) ? (int)ceilf(fminf(m, 1e6f)) : INV_RCAP;
+    return r > INV_RCAP ? INV_RCAP : r;
+}
+
+__global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsigned *__restrict__ out_bits)
+{
+    float m = 0.f;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        m = fmaxf(m, fabsf(off[i]));
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
+}
+
+// one thread per (input cell q, tap segment, image)
+__global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict__ off, const float *__restrict__ msk,
+                                                         InvLists inv, Geom g)
+{
+    const int HW = g.H * g.W;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    if (q >= HW) return;
+    const int seg = blockIdx.y, b = blockIdx.z;
+    const int S = g.dg * g.KK;
+    const int t = seg % g.KK, i = t / g.kw, j = t - i * g.kw;
+    const int qy = q / g.W, qx = q - qy * g.W;
+    const int rm1 = inv_radius(inv.absmax_bits), R = rm1 + 1;
+    const float rlim = (float)rm1;
+    const float *oh_p = off + ((size_t)b * S + seg) * 2 * g.HoWo;
+    const float *ow_p = oh_p + g.HoWo;
+    const float *m_p = msk + ((size_t)b * S + seg) * g.HoWo;
+    const size_t base = ((size_t)b * S + seg) * INV_CAP * HW + q;
+    // output pixels whose un-deformed tap position lies within R of this cell
+    const int cy = qy + g.ph - i * g.dh, cx = qx + g.pw - j * g.dw;
+    int py0 = (cy - R + g.sh - 1) / g.sh, py1 = (cy + R) / g.sh;
+    int px0 = (cx - R + g.sw - 1) / g.sw, px1 = (cx + R) / g.sw;
+    if (cy - R < 0) py0 = 0;
+    if (cx - R < 0) px0 = 0;
+    if (py1 > g.Ho - 1) py1 = g.Ho - 1;
+    if (px1 > g.Wo - 1) px1 = g.Wo - 1;
+    int cnt = 0;
+    for (int py = py0; py <= py1; ++py)
+        for (int px = px0; px <= px1; ++px) {
+            const int P = py * g.Wo + px;
+            const float oh = oh_p[P], ow = ow_p[P];
+            if (!(fabsf(oh) <= rlim && fabsf(ow) <= rlim)) continue;      // far sample: atomic fallback owns it
+            const float dh_ = ((float)(py * g.sh - g.ph + i * g.dh) + oh) - (float)qy;
+            const float dw_ = ((float)(px * g.sw - g.pw + j * g.dw) + ow) - (float)qx;
+            if (fabsf(dh_) < 1.f && fabsf(dw_) < 1.f) {
+                if (cnt < INV_CAP) {
+                    inv.idx[base + (size_t)cnt * HW] = P;
+                    inv.w[base + (size_t)cnt * HW] = (1.f - fabsf(dh_)) * (1.f - fabsf(dw_)) * m_p[P];
+                }
+                ++cnt;
+            }
+        }
+    inv.cnt[((size_t)b * S + seg) * HW + q] = (unsigned char)(cnt > INV_CAP ? INV_OVERFLOW : cnt);
+}
+
+// grid = (ceil(in_tiles/4), B, ceil(total_channel_blocks/MB)); lane = (input cell l&31, output-channel parity l>>5)
+template <int MB>
+__global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict__ gy, const float *__restrict__ wb,
+                                                         InvLists inv, float *__restrict__ gin, Geom g)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int HW = g.H * g.W;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int tile = bx * 4 + wave;
+    if (tile * 32 >= HW) return;
+    const int S = g.dg * g.KK;
+    const int nblk = g.cpgp / 32;                 // channel blocks per deformable group
+    const int gb0 = blockIdx.z * MB;              // first global channel block of this wave
+    const int Q = tile * 32 + p;
+    const bool qv = Q < HW;
+    const int Qc = qv ? Q : HW - 1;
+    const int nsteps = g.Cop / 2;
+    const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    for (int seg = 0; seg < S; ++seg) {
+        const int grp = seg / g.KK;
+        // skip taps of groups this wave holds no channels of (wave-uniform)
+        if ((gb0 + MB - 1) / nblk < grp || gb0 / nblk > grp) continue;
+        int cnt = qv ? (int)inv.cnt[((size_t)b * S + seg) * HW + Qc] : 0;
+        if (cnt == INV_OVERFLOW) cnt = 0;
+        int maxc = cnt;
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+        if (maxc == 0) continue;
+        unsigned eoff[INV_CAP];
+        float ew[INV_CAP];
+        const size_t base = ((size_t)b * S + seg) * INV_CAP * HW + Qc;
+#pragma unroll
+        for (int e = 0; e < INV_CAP; ++e) {
+            eoff[e] = 0u;
+            ew[e] = 0.f;
+            if (e < maxc && e < cnt) {
+                eoff[e] = (unsigned)inv.idx[base + (size_t)e * HW] * 4u;
+                ew[e] = inv.w[base + (size_t)e * HW];
+            }
+        }
+        const unsigned wlane = ((unsigned)h * (unsigned)g.Kp + (unsigned)(seg * g.cpgp) + (unsigned)p) * 4u;
+        const unsigned Kp8 = (unsigned)g.Kp * 8u;           // two weight rows per step
+        const size_t row2 = (size_t)2 * g.HoWo;              // two dY rows per step
+        const int last_o = g.Co - 1;
+        // stage = the raw dY samples and weight operands of ONE output-channel pair; two stages alternate so that the
+        // next pair's loads are in flight while the current pair runs on the matrix pipe
+        float ga[INV_CAP], gb_[INV_CAP], wa[MB], wbx[MB];
+        auto issue = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
+            const int o = 2 * st + h;
+            const float *gp = gy_b + (size_t)(o < g.Co ? o : last_o) * g.HoWo;
+#pragma unroll
+            for (int e = 0; e < INV_CAP; ++e)
+                if (e < maxc) gv[e] = ldg(gp, eoff[e]);
+            const float *wp = (const float *)((const char *)wb + (size_t)st * Kp8);
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb) {
+                const int gbk = gb0 + mb;
+                if (gbk / nblk == grp) wv[mb] = ldg(wp, wlane + (unsigned)((gbk - grp * nblk) * 32) * 4u);
+            }
+        };
+        auto compute = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
+            float val = 0.f;
+#pragma unroll
+            for (int e = 0; e < INV_CAP; ++e)
+                if (e < maxc) val += ew[e] * gv[e];
+            val = (2 * st + h < g.Co) ? val : 0.f;
+#pragma unroll
+            for (int mb = 0; mb < MB; ++mb)
+                if ((gb0 + mb) / nblk == grp) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[mb], val, acc[mb], 0, 0, 0);
+        };
+        (void)row2;
+        issue(ga, wa, 0);
+        int st = 0;
+        for (; st + 1 < nsteps; st += 2) {
+            issue(gb_, wbx, st + 1);
+            compute(ga, wa, st);
+            if (st + 2 < nsteps) issue(ga, wa, st + 2);
+            compute(gb_, wbx, st + 1);
+        }
+        if (st < nsteps) compute(ga, wa, st);
+    }
+
+    float *gin_b = gin + (size_t)b * g.C * HW;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int gb = gb0 + mb;
+        const int grp = gb / nblk, blk = gb - grp * nblk;
+        if (grp >= g.dg) continue;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cc = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (qv && cc < g.cpg) gin_b[((size_t)grp * g.cpg + cc) * HW + Q] = acc[mb][r];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Backward w.r.t. input, offset, mask (+ bias).
 // grid = (ceil(tiles/4), B, nsplit); each z handles a contiguous range of 32-channel blocks.
 // NS = Cop/2 register-cached dY values per lane (0: stream dY from memory, any Cout).
@@ -225,13 +455,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                                                         const float *__restrict__ msk, const float *__restrict__ wb,
                                                         const float *__restrict__ gy, float *__restrict__ gin,
                                                         float *__restrict__ goff, float *__restrict__ gmsk,
-                                                        float *__restrict__ gbias, Geom g, int nsplit)
+                                                        float *__restrict__ gbias, Geom g, int nsplit, InvLists inv)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
-    const int tile = blockIdx.x * 4 + wave;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int tile = bx * 4 + wave;
     if (tile * 32 >= g.HoWo) return;
-    const int b = blockIdx.y, z = blockIdx.z;
+    const int z = blockIdx.z;
+    const float rlim = (float)inv_radius(inv.absmax_bits);
+    const int S_all = g.dg * g.KK;
     const int P = tile * 32 + p;
     const bool pv = P < g.HoWo;
     const int Pc = pv ? P : g.HoWo - 1;
@@ -293,6 +527,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
             const int seg = grp * g.KK + t;
             const Tap s = make_tap(off_b, msk_b, g, seg, t, ho, wo, Pc, pv);
             float s_m = 0.f, s_h = 0.f, s_w = 0.f;
+            // grad_input normally comes from dcn_bwd_input_f32; this kernel scatters only what the inverse lists do
+            // not cover: samples farther than the search radius, and corners that fell into an overflowed cell.
+            const bool far = !(fabsf(s.oh) <= rlim && fabsf(s.ow) <= rlim);
+            const unsigned char *cnt_p = inv.cnt + ((size_t)b * S_all + seg) * HW;
+            const bool a1 = s.c1 && (far || cnt_p[s.i1] == INV_OVERFLOW), a2 = s.c2 && (far || cnt_p[s.i2] == INV_OVERFLOW);
+            const bool a3 = s.c3 && (far || cnt_p[s.i3] == INV_OVERFLOW), a4 = s.c4 && (far || cnt_p[s.i4] == INV_OVERFLOW);
             for (int blk = blk0; blk < blk1; ++blk) {
                 f32x16 acc;
 #pragma unroll
@@ -310,23 +550,36 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     }
                 }
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int cc = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    if (cc < g.cpg) {
-                        const float *ip = in_g + (size_t)cc * HW;
-                        const float v1 = s.c1 ? ip[s.i1] : 0.f, v2 = s.c2 ? ip[s.i2] : 0.f;
-                        const float v3 = s.c3 ? ip[s.i3] : 0.f, v4 = s.c4 ? ip[s.i4] : 0.f;
-                        const float d = acc[r];
-                        s_m += d * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
-                        const float dm = d * s.m;
-                        // d/dh and d/dw of the bilinear sample (cuda/dcn_v2_im2col_cuda.cu:82-123)
-                        s_h += dm * (s.hw * (v3 - v1) + s.lw * (v4 - v2));
-                        s_w += dm * (s.hh * (v2 - v1) + s.lh * (v4 - v3));
-                        float *gp = gin_g + (size_t)cc * HW;
-                        if (s.c1) atomicAdd(gp + s.i1, dm * s.w1);
-                        if (s.c2) atomicAdd(gp + s.i2, dm * s.w2);
-                        if (s.c3) atomicAdd(gp + s.i3, dm * s.w3);
-                        if (s.c4) atomicAdd(gp + s.i4, dm * s.w4);
+                for (int r4 = 0; r4 < 4; ++r4) {
+                    // rows r = 4*r4 .. 4*r4+3 are 4 consecutive channels: issue their 16 gathers, then do the arithmetic
+                    const int cc0 = blk * 32 + 8 * r4 + 4 * h;
+                    float v[4][4];
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = cc0 + u;
+                        const float *ip = in_g + (size_t)(cc < g.cpg ? cc : 0) * HW;
+                        v[u][0] = ip[s.i1]; v[u][1] = ip[s.i2]; v[u][2] = ip[s.i3]; v[u][3] = ip[s.i4];
+                    }
+#pragma unroll
+                    for (int u = 0; u < 4; ++u) {
+                        const int cc = cc0 + u;
+                        if (cc < g.cpg) {
+                            const float v1 = s.c1 ? v[u][0] : 0.f, v2 = s.c2 ? v[u][1] : 0.f;
+                            const float v3 = s.c3 ? v[u][2] : 0.f, v4 = s.c4 ? v[u][3] : 0.f;
+                            const float d = acc[4 * r4 + u];
+                            s_m += d * (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4);
+                            const float dm = d * s.m;
+                            // d/dh and d/dw of the bilinear sample (cuda/dcn_v2_im2col_cuda.cu:82-123)
+                            s_h += dm * (s.hw * (v3 - v1) + s.lw * (v4 - v2));
+                            s_w += dm * (s.hh * (v2 - v1) + s.lh * (v4 - v3));
+                            if (a1 | a2 | a3 | a4) {
+                                float *gp = gin_g + (size_t)cc * HW;
+                                if (a1) atomicAdd(gp + s.i1, dm * s.w1);
+                                if (a2) atomicAdd(gp + s.i2, dm * s.w2);
+                                if (a3) atomicAdd(gp + s.i3, dm * s.w3);
+                                if (a4) atomicAdd(gp + s.i4, dm * s.w4);
+                            }
+                        }
                     }
                 }
             }
@@ -461,7 +714,9 @@ size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh
 {
     Geom g;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return 0;
-    return (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256;
+    // [Wf | Wb | absmax word (256 B) | inverse lists: cnt, idx, w]
+    const size_t cells = (size_t)B * dg * g.KK * H * W;
+    return (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256;
 }
 
 int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, const float *bias,
@@ -511,8 +766,16 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
     if (precision != DCD_PREC_F32) return DCD_ERR_BAD_ARG;
     const size_t nw = (size_t)g.Kp * g.Cop;
-    if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
+    if (workspace_bytes + 256 < dcd_dcn_v2_workspace_bytes(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg))
+        return DCD_ERR_WORKSPACE;
     float *wf = (float *)workspace, *wb = wf + nw;
+    const size_t cells = (size_t)B * dg * g.KK * H * W;
+    InvLists inv;
+    unsigned *absmax = (unsigned *)(wb + nw);
+    inv.absmax_bits = absmax;
+    inv.cnt = (unsigned char *)absmax + 256;
+    inv.idx = (int *)(inv.cnt + (cells + 255) / 256 * 256);
+    inv.w = (float *)(inv.idx + cells * INV_CAP);
 
     hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
                        0, stream, weight, wf, wb, g);
@@ -523,7 +786,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     int nsplit = 1;
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
 
-    hipMemsetAsync(grad_input, 0, sizeof(float) * (size_t)B * Cin * H * W, stream);
+    hipMemsetAsync(absmax, 0, sizeof(unsigned), stream);
     hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)Cout * Cin * g.KK, stream);
     hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)Cout, stream);
     if (nsplit > 1) {
@@ -531,12 +794,31 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * dg * g.KK * g.HoWo, stream);
     }
 
+    // (1) search radius from max |offset|, (2) inverse sample lists, (3) grad_input by gather + MFMA (plain stores)
+    {
+        const int64_t noff = (int64_t)B * dg * 2 * g.KK * g.HoWo;
+        int gsz = (int)((noff + 1023) / 1024);
+        if (gsz > 1024) gsz = 1024;
+        hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax);
+        const int HWin = H * W;
+        hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
+        const int in_tiles = (HWin + 31) / 32;
+        const int total_blocks = dg * nblk;
+        int mbi = total_blocks >= 8 ? 8 : total_blocks >= 4 ? 4 : total_blocks >= 2 ? 2 : 1;
+        while (mbi > 1 && (int64_t)in_tiles * B * ((total_blocks + mbi - 1) / mbi) < 1024) mbi >>= 1;
+        dim3 grid((in_tiles + 3) / 4, B, (total_blocks + mbi - 1) / mbi), block(256);
+        if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+        else if (mbi == 4) hipLaunchKernelGGL(dcn_bwd_input_f32<4>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+        else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+        else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+    }
+    // (4) grad_offset / grad_mask / grad_bias (+ atomic fallback for what the lists do not cover)
     {
         dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
         const int ns = g.Cop / 2;
 #define DCD_LAUNCH_BD(NS)                                                                                          \
     hipLaunchKernelGGL(dcn_bwd_data_f32<NS>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, \
-                       grad_offset, grad_mask, grad_bias, g, nsplit)
+                       grad_offset, grad_mask, grad_bias, g, nsplit, inv)
         if (ns == 16) DCD_LAUNCH_BD(16);
         else if (ns == 32) DCD_LAUNCH_BD(32);
         else if (ns == 64) DCD_LAUNCH_BD(64);
@@ -550,7 +832,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const int mb = nb >= 8 ? 8 : nb >= 4 ? 4 : nb >= 2 ? 2 : 1;
         const int gx = (RB + 3) / 4, gz = (nb + mb - 1) / mb;
         const int total = B * tiles;
-        int S = 1024 / (gx * gz);
+        int S = 512 / (gx * gz);
         if (S < 1) S = 1;
         if (S > total) S = total;
         dim3 grid(gx, S, gz), block(256);

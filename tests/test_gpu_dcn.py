@@ -125,6 +125,40 @@ def test_boundary_samples(cuda, oracle_dcn):
         close(g_, r_, 5e-5, "boundary " + name)
 
 
+def test_convergent_offsets_overflow_and_far_fallback(cuda, oracle_dcn):
+    """grad_input comes from inverse sample lists (capacity 10 per cell and tap, radius <= 3 px) with an atomic fallback.
+    Offsets that make every pixel of a 4x4 block sample the SAME location overflow the lists; offsets of 4..7 px are
+    'far'.  Both fallbacks and their mix with the list path must reproduce the oracle."""
+    from dcd_amd import _ext
+    B, C, Co, H, W = 2, 8, 8, 16, 20
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=11)
+    ys = torch.arange(H).view(1, 1, H, 1).float()
+    xs = torch.arange(W).view(1, 1, 1, W).float()
+    for k in range(9):
+        i, j = k // 3, k % 3
+        # un-deformed tap position is (y-1+i, x-1+j); send it to the centre of the pixel's 4x4 block (+ a fraction)
+        off[:, 2 * k] = ((ys // 4) * 4 + 1.3) - (ys - 1 + i)
+        off[:, 2 * k + 1] = ((xs // 4) * 4 + 1.6) - (xs - 1 + j)
+    off[1, :, 8:] += 4.0                                   # second image: half the rows become far samples
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    got = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda), *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, 5e-5, "convergent " + name)
+
+
+def test_backward_is_deterministic_without_fallback(cuda):
+    """With offsets inside the search radius nothing is scattered atomically: grad_input is bit-reproducible
+    (the reference's col2im is not)."""
+    from dcd_amd import _ext
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 64, 64, 24, 40, off_scale=0.25, seed=5))
+    off.clamp_(-0.9, 0.9)      # |offset| < 1 px: a cell collects at most 9 samples of one tap <= list capacity 10
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    g1 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)[0]
+    g2 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)[0]
+    assert torch.equal(g1, g2)
+
+
 def test_full_size_layer_properties(cuda, oracle_dcn):
     """BASELINE size (64->64 @ 96x320, bs 8): size-independent properties instead of a full oracle run.
     (1) linearity in the weights, (2) image 0 of the batch equals a batch-1 run compared with the oracle,

@@ -8,12 +8,12 @@ LAYERS = [(512, 256, 12, 40, 1), (256, 256, 24, 80, 1), (256, 128, 24, 80, 2), (
           (128, 64, 48, 160, 4), (64, 64, 96, 320, 5), (256, 64, 24, 80, 1)]
 
 
-def main(B=8, prec="f32", iters=5):
+def main(B=8, prec="f32", iters=5, off_scale=2.0):
     dev = torch.device("cuda:0")
     tot_f = tot_b = 0.0
     for (C, Co, H, W, mult) in LAYERS:
         x = torch.randn(B, C, H, W, device=dev)
-        off = torch.randn(B, 18, H, W, device=dev) * 2
+        off = torch.randn(B, 18, H, W, device=dev) * off_scale
         m = torch.sigmoid(torch.randn(B, 9, H, W, device=dev))
         w = torch.randn(Co, C, 3, 3, device=dev) / (C * 9) ** 0.5
         b = torch.zeros(Co, device=dev)
@@ -38,8 +38,10 @@ def main(B=8, prec="f32", iters=5):
             C, Co, H, W, mult, tf, fl / tf / 1e9, tb, 2 * fl / tb / 1e9))
         tot_f += tf * mult
         tot_b += tb * mult
+    print("off_scale=%g " % off_scale, end="")
     print("B=%d prec=%s TOTAL fwd %.3f ms  bwd %.3f ms  fwd+bwd %.3f ms" % (B, prec, tot_f, tot_b, tot_f + tot_b))
 
 
 if __name__ == "__main__":
-    main(B=int(sys.argv[1]) if len(sys.argv) > 1 else 8, prec=sys.argv[2] if len(sys.argv) > 2 else "f32")
+    main(B=int(sys.argv[1]) if len(sys.argv) > 1 else 8, prec=sys.argv[2] if len(sys.argv) > 2 else "f32",
+         off_scale=float(sys.argv[3]) if len(sys.argv) > 3 else 2.0)
