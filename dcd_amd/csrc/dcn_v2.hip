@@ -445,8 +445,27 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
     }
 }
 
+// grad_bias[o] = sum_{b,p} dY[b,o,p].  grid = (Cout, splits); one float atomic per block (same-address atomics from
+// every wave of the data kernel serialised in L2 and cost more than the whole MFMA work).
+__global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo)
+{
+    const int o = blockIdx.x;
+    const int64_t n = (int64_t)B * HoWo;
+    float acc = 0.f;
+    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) {
+        const int64_t b = i / HoWo, pp = i - b * HoWo;
+        acc += gy[((size_t)b * Co + o) * HoWo + pp];
+    }
+#pragma unroll
+    for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
+    __syncthreads();
+    if (threadIdx.x == 0) atomicAdd(gbias + o, part[0] + part[1] + part[2] + part[3]);
+}
+
 // ---------------------------------------------------------------------------------------------
-// Backward w.r.t. input, offset, mask (+ bias).
+// Backward w.r.t. input, offset, mask (grad_bias: dcn_bias_grad).
 // grid = (ceil(tiles/4), B, nsplit); each z handles a contiguous range of 32-channel blocks.
 // NS = Cop/2 register-cached dY values per lane (0: stream dY from memory, any Cout).
 // ---------------------------------------------------------------------------------------------
@@ -480,33 +499,6 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
         for (int s = 0; s < NS; ++s) {
             const int o = 2 * s + h;
             dy[s] = (pv && o < g.Co) ? gy_b[(size_t)o * g.HoWo + P] : 0.f;
-        }
-    }
-
-    // grad_bias: sum of dY over the 32 pixels of this tile, one atomic per (tile, o)
-    if (z == 0) {
-        if (NS > 0) {
-#pragma unroll
-            for (int s = 0; s < NS; ++s) {
-                float v = dy[s];
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
-                if (p == 0 && 2 * s + h < g.Co) atomicAdd(gbias + 2 * s + h, v);
-            }
-        } else {
-            for (int s = 0; s < nsteps; ++s) {
-                const int o = 2 * s + h;
-                float v = (pv && o < g.Co) ? gy_b[(size_t)o * g.HoWo + P] : 0.f;
-                v += __shfl_xor(v, 16);
-                v += __shfl_xor(v, 8);
-                v += __shfl_xor(v, 4);
-                v += __shfl_xor(v, 2);
-                v += __shfl_xor(v, 1);
-                if (p == 0 && o < g.Co) atomicAdd(gbias + o, v);
-            }
         }
     }
 
@@ -572,13 +564,20 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                             // d/dh and d/dw of the bilinear sample (cuda/dcn_v2_im2col_cuda.cu:82-123)
                             s_h += dm * (s.hw * (v3 - v1) + s.lw * (v4 - v2));
                             s_w += dm * (s.hh * (v2 - v1) + s.lh * (v4 - v3));
-                            if (a1 | a2 | a3 | a4) {
-                                float *gp = gin_g + (size_t)cc * HW;
-                                if (a1) atomicAdd(gp + s.i1, dm * s.w1);
-                                if (a2) atomicAdd(gp + s.i2, dm * s.w2);
-                                if (a3) atomicAdd(gp + s.i3, dm * s.w3);
-                                if (a4) atomicAdd(gp + s.i4, dm * s.w4);
-                            }
+                        }
+                    }
+                }
+                if (__any(a1 | a2 | a3 | a4)) {     // rare: far samples / overflowed cells of this tap (wave-uniform test)
+#pragma unroll
+                    for (int r = 0; r < 16; ++r) {
+                        const int cc = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                        if (cc < g.cpg) {
+                            const float dm = acc[r] * s.m;
+                            float *gp = gin_g + (size_t)cc * HW;
+                            if (a1) atomicAdd(gp + s.i1, dm * s.w1);
+                            if (a2) atomicAdd(gp + s.i2, dm * s.w2);
+                            if (a3) atomicAdd(gp + s.i3, dm * s.w3);
+                            if (a4) atomicAdd(gp + s.i4, dm * s.w4);
                         }
                     }
                 }
@@ -812,7 +811,12 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
         else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
     }
-    // (4) grad_offset / grad_mask / grad_bias (+ atomic fallback for what the lists do not cover)
+    {
+        int splits = (int)(((int64_t)B * g.HoWo + 16383) / 16384);
+        if (splits > 64) splits = 64;
+        hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
+    }
+    // (4) grad_offset / grad_mask (+ atomic fallback for what the lists do not cover)
     {
         dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
         const int ns = g.Cop / 2;
