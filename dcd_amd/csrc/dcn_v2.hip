@@ -89,17 +89,31 @@ struct Tap {
     float lh, lw, hh, hw;    // fractional parts (for the coordinate gradient)
     float m;                 // modulation mask (0 when the sample is invalid or the pixel is padding)
     float oh, ow;            // raw offsets of this tap
+    // pair form: the two corners of a row are adjacent floats -> ONE dwordx2 load per row.  pt / pb are element offsets of
+    // the (x, x+1) pairs of the top / bottom row, clamped into the plane; a0,a1,b0,b1 are the bilinear weights re-mapped
+    // onto the loaded pair (at the left / right image edge the valid corner moves to the other element).
+    int pt, pb;
+    float a0, a1, b0, b1;
     bool c1, c2, c3, c4;     // corner validity
 };
 
-__device__ __forceinline__ Tap make_tap(const float *__restrict__ off_b, const float *__restrict__ msk_b, const Geom &g,
-                                        int seg, int t, int ho, int wo, int Pc, bool pv)
+struct TapRaw { float oh, ow, m; };
+
+__device__ __forceinline__ TapRaw load_tap_raw(const float *__restrict__ off_b, const float *__restrict__ msk_b, const Geom &g,
+                                               int seg, int Pc)
+{
+    TapRaw r;
+    r.oh = off_b[(size_t)(2 * seg) * g.HoWo + Pc];
+    r.ow = off_b[(size_t)(2 * seg + 1) * g.HoWo + Pc];
+    r.m = msk_b[(size_t)seg * g.HoWo + Pc];
+    return r;
+}
+
+__device__ __forceinline__ Tap finish_tap(const TapRaw &raw, const Geom &g, int t, int ho, int wo, bool pv)
 {
     Tap s;
     const int i = t / g.kw, j = t - i * g.kw;
-    const float oh = off_b[(size_t)(2 * seg) * g.HoWo + Pc];
-    const float ow = off_b[(size_t)(2 * seg + 1) * g.HoWo + Pc];
-    const float m = msk_b[(size_t)seg * g.HoWo + Pc];
+    const float oh = raw.oh, ow = raw.ow, m = raw.m;
     const float hf = (float)(ho * g.sh - g.ph + i * g.dh) + oh;
     const float wf = (float)(wo * g.sw - g.pw + j * g.dw) + ow;
     const bool sv = pv && hf > -1.f && wf > -1.f && hf < (float)g.H && wf < (float)g.W;
@@ -124,7 +138,25 @@ __device__ __forceinline__ Tap make_tap(const float *__restrict__ off_b, const f
     s.m = sv ? m : 0.f;
     s.oh = oh;
     s.ow = ow;
+    {
+        const int xb = g.W >= 2 ? min(max(wl, 0), g.W - 2) : 0;
+        const int ya = min(max(hl, 0), g.H - 1), yb = min(max(hh_i, 0), g.H - 1);
+        const int shift = xb - wl;          // 0 inside, +1 at the left edge (wl == -1), -1 at the right edge (wl == W-1)
+        s.pt = ya * g.W + xb;
+        s.pb = yb * g.W + xb;
+        s.a0 = shift == 0 ? s.w1 : (shift == 1 ? s.w2 : 0.f);
+        s.a1 = shift == 0 ? s.w2 : (shift == -1 ? s.w1 : 0.f);
+        s.b0 = shift == 0 ? s.w3 : (shift == 1 ? s.w4 : 0.f);
+        s.b1 = shift == 0 ? s.w4 : (shift == -1 ? s.w3 : 0.f);
+        if (!sv) { s.pt = 0; s.pb = 0; }
+    }
     return s;
+}
+
+__device__ __forceinline__ Tap make_tap(const float *__restrict__ off_b, const float *__restrict__ msk_b, const Geom &g,
+                                        int seg, int t, int ho, int wo, int Pc, bool pv)
+{
+    return finish_tap(load_tap_raw(off_b, msk_b, g, seg, Pc), g, t, ho, wo, pv);
 }
 
 // Workgroups are dealt to the 8 XCDs round-robin by linear id (observed, speed only).  Re-map (blockIdx.x, blockIdx.y)
@@ -145,6 +177,14 @@ __device__ __forceinline__ void xcd_remap(int &bx, int &by)
 __device__ __forceinline__ float ldg(const float *base, unsigned byte_off)
 {
     return *(const float *)((const char *)base + byte_off);
+}
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+// 8-byte load at a 4-byte aligned address (two horizontally adjacent corners)
+__device__ __forceinline__ f32x2 ldg2(const float *base, unsigned byte_off)
+{
+    typedef f32x2 __attribute__((aligned(4))) f32x2_u;
+    return *(const f32x2_u *)((const char *)base + byte_off);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -188,24 +228,44 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
         const float *wp = wf + (size_t)seg * g.cpgp * g.Cop;              // uniform, advanced 2 rows per step
         const unsigned o1 = (unsigned)s.i1 * 4u + h * HW4, o2 = (unsigned)s.i2 * 4u + h * HW4;
         const unsigned o3 = (unsigned)s.i3 * 4u + h * HW4, o4 = (unsigned)s.i4 * 4u + h * HW4;
+        const unsigned opt = (unsigned)s.pt * 4u + h * HW4, opb = (unsigned)s.pb * 4u + h * HW4;
+        const bool pairs = g.W >= 2;         // uniform
+        const float q1 = pairs ? s.a0 : s.w1, q2 = pairs ? s.a1 : s.w2, q3 = pairs ? s.b0 : s.w3, q4 = pairs ? s.b1 : s.w4;
         // Two register stages of UN channel pairs each: the loads of stage B are in flight while stage A feeds the
         // matrix pipe (the gather addresses depend only on the tap, never on loaded data, so they prefetch freely).
-        constexpr int UN = (MB >= 4) ? 2 : 4;
+#ifndef DCN_FWD_UN
+#define DCN_FWD_UN ((MB >= 4) ? 2 : 4)
+#endif
+        constexpr int UN = DCN_FWD_UN;
         float va[UN][4], vb[UN][4], wa[UN][MB], wb_[UN][MB];
         auto issue = [&](float (&v)[UN][4], float (&a)[UN][MB], int it0) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
                 const float *ipc = (const float *)((const char *)ip + (size_t)(it0 + u) * 2 * HW4);
                 const float *wpc = (const float *)((const char *)wp + (size_t)(it0 + u) * 2 * Cop4);
-                v[u][0] = ldg(ipc, o1); v[u][1] = ldg(ipc, o2); v[u][2] = ldg(ipc, o3); v[u][3] = ldg(ipc, o4);
+#ifdef DCN_ABL_NOGATHER
+                v[u][0] = s.w1 + (float)u; v[u][1] = s.w2; v[u][2] = s.w3; v[u][3] = s.w4; (void)ipc;
+#else
+                if (pairs) {
+                    const f32x2 tp = ldg2(ipc, opt), bt = ldg2(ipc, opb);
+                    v[u][0] = tp.x; v[u][1] = tp.y; v[u][2] = bt.x; v[u][3] = bt.y;
+                } else {
+                    v[u][0] = ldg(ipc, o1); v[u][1] = ldg(ipc, o2); v[u][2] = ldg(ipc, o3); v[u][3] = ldg(ipc, o4);
+                }
+#endif
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb) a[u][mb] = ldg(wpc, wlane + mb * 128u);
+                for (int mb = 0; mb < MB; ++mb)
+#ifdef DCN_ABL_NOWEIGHT
+                    a[u][mb] = s.w1 + (float)(mb + u); (void)wpc;
+#else
+                    a[u][mb] = ldg(wpc, wlane + mb * 128u);
+#endif
             }
         };
         auto compute = [&](float (&v)[UN][4], float (&a)[UN][MB]) {
 #pragma unroll
             for (int u = 0; u < UN; ++u) {
-                const float val = (s.w1 * v[u][0] + s.w2 * v[u][1] + s.w3 * v[u][2] + s.w4 * v[u][3]) * s.m;
+                const float val = (q1 * v[u][0] + q2 * v[u][1] + q3 * v[u][2] + q4 * v[u][3]) * s.m;
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], val, acc[mb], 0, 0, 0);
             }
@@ -239,6 +299,111 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb)
                 acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldg(wp, wlane + mb * 128u), val, acc[mb], 0, 0, 0);
+        }
+    }
+
+    float *out_b = out + (size_t)b * g.Co * g.HoWo;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int obase = (ob0 + mb) * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = obase + (r & 3) + 8 * (r >> 2);
+            if (pv && o < g.Co) out_b[(size_t)o * g.HoWo + P] = acc[mb][r] + bias[o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Forward, 3x3 fast path: CHANNEL-outer / TAP-inner.
+// The generic kernel above walks every channel plane once per tap, so a wave's reuse distance is Cin planes and
+// its gathers miss L1 (measured: pipeline depth made no difference, 42 TF).  Here the sampling state of all nine taps
+// (4 byte offsets + 4 mask-scaled weights each = 72 VGPRs) stays in registers and the loop runs over channel pairs:
+// the 36 gathers of a pair touch the same ~3 rows of one plane, i.e. a handful of L1 lines.  K order is then the
+// weight's native k = c*9 + tap, so Wf9[k][Cout_pad] is a plain transpose.
+// ---------------------------------------------------------------------------------------------
+__global__ void dcn_prep_weights9(const float *__restrict__ w, float *__restrict__ wf9, Geom g)
+{
+    const int K = g.C * 9, n = K * g.Cop;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int k = idx / g.Cop, o = idx - k * g.Cop;
+        wf9[idx] = (o < g.Co) ? w[(size_t)o * K + k] : 0.f;
+    }
+}
+
+template <int MB>
+__global__ __launch_bounds__(256) void dcn_fwd9_f32(const float *__restrict__ in, const float *__restrict__ off,
+                                                    const float *__restrict__ msk, const float *__restrict__ wf9,
+                                                    const float *__restrict__ bias, float *__restrict__ out, Geom g)
+{
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int tile = bx * 4 + wave;
+    if (tile * 32 >= g.HoWo) return;
+    const int ob0 = blockIdx.z * MB;
+    const int P = tile * 32 + p;
+    const bool pv = P < g.HoWo;
+    const int Pc = pv ? P : g.HoWo - 1;
+    const int ho = Pc / g.Wo, wo = Pc - ho * g.Wo;
+    const unsigned HW4 = (unsigned)(g.H * g.W) * 4u;
+    const unsigned Cop4 = (unsigned)g.Cop * 4u;
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    const float *in_b = in + (size_t)b * g.C * g.H * g.W;
+    const float *off_b = off + (size_t)b * g.dg * 18 * g.HoWo;
+    const float *msk_b = msk + (size_t)b * g.dg * 9 * g.HoWo;
+    const unsigned wlane = (unsigned)(ob0 * 32 + p) * 4u;
+    const int npair = g.cpg >> 1;
+
+    for (int grp = 0; grp < g.dg; ++grp) {
+        unsigned to[9][2];      // byte offsets of the top / bottom (x, x+1) pairs
+        float tw[9][4];         // pair-mapped bilinear weights x mask
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+            const Tap s = make_tap(off_b, msk_b, g, grp * 9 + t, t, ho, wo, Pc, pv);
+            to[t][0] = (unsigned)s.pt * 4u; to[t][1] = (unsigned)s.pb * 4u;
+            tw[t][0] = s.a0 * s.m; tw[t][1] = s.a1 * s.m; tw[t][2] = s.b0 * s.m; tw[t][3] = s.b1 * s.m;
+        }
+        // lane half h handles channel 2*it + h of the group
+        const float *ip = in_b + ((size_t)grp * g.cpg + h) * g.H * g.W;
+        const float *wp = wf9 + ((size_t)grp * g.cpg + h) * 9 * g.Cop;
+        auto pair_step = [&](const float *ipc, const float *wpc, bool live) {
+#pragma unroll
+            for (int t0 = 0; t0 < 9; t0 += 3) {      // three taps per stage: 6 pair loads + 3*MB weight loads in flight
+                f32x2 vt[3], vb[3];
+                float a[3][MB];
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    vt[u] = ldg2(ipc, to[t0 + u][0]);
+                    vb[u] = ldg2(ipc, to[t0 + u][1]);
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb) a[u][mb] = ldg(wpc, wlane + (unsigned)(t0 + u) * Cop4 + mb * 128u);
+                }
+#pragma unroll
+                for (int u = 0; u < 3; ++u) {
+                    float val = tw[t0 + u][0] * vt[u].x + tw[t0 + u][1] * vt[u].y + tw[t0 + u][2] * vb[u].x + tw[t0 + u][3] * vb[u].y;
+                    val = live ? val : 0.f;
+#pragma unroll
+                    for (int mb = 0; mb < MB; ++mb)
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(a[u][mb], val, acc[mb], 0, 0, 0);
+                }
+            }
+        };
+        for (int it = 0; it < npair; ++it)
+            pair_step((const float *)((const char *)ip + (size_t)it * 2 * HW4),
+                      (const float *)((const char *)wp + (size_t)it * 18 * Cop4), true);
+        if (g.cpg & 1) {      // odd channel count: only the h == 0 half has a channel left
+            const size_t back = h ? (size_t)g.H * g.W : 0;          // keep the h == 1 addresses inside the tensor
+            const size_t wback = h ? (size_t)9 * g.Cop : 0;
+            pair_step((const float *)((const char *)ip + (size_t)npair * 2 * HW4) - back,
+                      (const float *)((const char *)wp + (size_t)npair * 18 * Cop4) - wback, h == 0);
         }
     }
 
@@ -638,38 +803,74 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     const int t0 = (int)((int64_t)blockIdx.y * total / nsplit), t1 = (int)((int64_t)(blockIdx.y + 1) * total / nsplit);
     float *myT = colT + wave * 32 * 33;
 
-    for (int ti = t0; ti < t1; ++ti) {
-        const int b = ti / tiles_per_img, tile = ti - b * tiles_per_img;
-        const int P = tile * 32 + p;
-        const bool pv = P < g.HoWo;
-        const int Pc = pv ? P : g.HoWo - 1;
-        const int ho = Pc / g.Wo, wo = Pc - ho * g.Wo;
+    // Three-deep software pipeline over the (image, tile) sequence of this block:
+    //   stage R: raw offset/mask loads of tile ti+2      (feeds address generation)
+    //   stage G: 64 bilinear-corner gathers + dY rows of tile ti+1 into registers
+    //   stage M: tile ti -- registers -> LDS (transposed), barrier, 16 x MB MFMAs from LDS
+    // so the two dependent global-memory latencies are covered by the matrix work of earlier tiles.
+    auto tile_coords = [&](int ti, int &b, int &P, bool &pv, int &Pc, int &ho, int &wo) {
+        b = ti / tiles_per_img;
+        const int tile = ti - b * tiles_per_img;
+        P = tile * 32 + p;
+        pv = P < g.HoWo;
+        Pc = pv ? P : g.HoWo - 1;
+        ho = Pc / g.Wo;
+        wo = Pc - ho * g.Wo;
+    };
+    auto stage_raw = [&](int ti) {
+        int b, P, Pc, ho, wo; bool pv;
+        tile_coords(ti, b, P, pv, Pc, ho, wo);
+        return load_tap_raw(off + (size_t)b * g.dg * 2 * g.KK * g.HoWo, msk + (size_t)b * g.dg * g.KK * g.HoWo, g, seg, Pc);
+    };
+    float v[16][4], dyr[MB * 4];
+    Tap s;
+    auto stage_gather = [&](int ti, const TapRaw &raw) {
+        int b, P, Pc, ho, wo; bool pv;
+        tile_coords(ti, b, P, pv, Pc, ho, wo);
+        s = finish_tap(raw, g, t, ho, wo, pv && rbv);
         const float *in_g = in + ((size_t)b * g.C + (size_t)grp * g.cpg) * HW;
-        const float *off_b = off + (size_t)b * g.dg * 2 * g.KK * g.HoWo;
-        const float *msk_b = msk + (size_t)b * g.dg * g.KK * g.HoWo;
         const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
-
-        // (1) sampled columns for this wave's 32 channels -> colT[row][pixel]
-        const Tap s = make_tap(off_b, msk_b, g, seg, t, ho, wo, Pc, pv && rbv);
-#pragma unroll 4
+#pragma unroll
         for (int q = 0; q < 16; ++q) {
-            const int row = 2 * q + h;
-            const int cc = blk * 32 + row;
-            const bool cv = cc < g.cpg;
-            const float *ip = in_g + (size_t)(cv ? cc : 0) * HW;
-            const float v1 = ip[s.i1], v2 = ip[s.i2], v3 = ip[s.i3], v4 = ip[s.i4];
-            const float val = (s.w1 * v1 + s.w2 * v2 + s.w3 * v3 + s.w4 * v4) * s.m;
-            myT[row * 33 + p] = cv ? val : 0.f;
+            const int cc = blk * 32 + 2 * q + h;
+            const float *ip = in_g + (size_t)(cc < g.cpg ? cc : 0) * HW;
+            if (g.W >= 2) {
+                const f32x2 tp = ldg2(ip, (unsigned)s.pt * 4u), bt = ldg2(ip, (unsigned)s.pb * 4u);
+                v[q][0] = tp.x; v[q][1] = tp.y; v[q][2] = bt.x; v[q][3] = bt.y;
+            } else {
+                v[q][0] = ip[s.i1]; v[q][1] = ip[s.i2]; v[q][2] = ip[s.i3]; v[q][3] = ip[s.i4];
+            }
         }
-        // (2) dY tile -> dyT[o][pixel]; the four waves split the rows
 #pragma unroll
         for (int q = 0; q < MB * 4; ++q) {
-            const int ol = q * 8 + wave * 2 + h;  // 0 .. MB*32-1
-            const int o = ob0 * 32 + ol;
-            dyT[ol * 33 + p] = (pv && o < g.Co) ? gy_b[(size_t)o * g.HoWo + P] : 0.f;
+            const int o = ob0 * 32 + q * 8 + wave * 2 + h;
+            dyr[q] = (pv && o < g.Co) ? gy_b[(size_t)o * g.HoWo + P] : 0.f;
         }
+    };
+    TapRaw raw_next = {0.f, 0.f, 0.f};
+    if (t0 < t1) {
+        stage_gather(t0, stage_raw(t0));
+        if (t0 + 1 < t1) raw_next = stage_raw(t0 + 1);
+    }
+    for (int ti = t0; ti < t1; ++ti) {
+        // registers of tile ti -> LDS: sampled columns colT[row][pixel], dY tile dyT[o][pixel]
+#pragma unroll
+        for (int q = 0; q < 16; ++q) {
+            const int row = 2 * q + h;
+            const bool pr = g.W >= 2;
+            const float val = ((pr ? s.a0 : s.w1) * v[q][0] + (pr ? s.a1 : s.w2) * v[q][1] + (pr ? s.b0 : s.w3) * v[q][2] +
+                               (pr ? s.b1 : s.w4) * v[q][3]) * s.m;
+            myT[row * 33 + p] = (blk * 32 + row < g.cpg) ? val : 0.f;
+        }
+#pragma unroll
+        for (int q = 0; q < MB * 4; ++q) dyT[(q * 8 + wave * 2 + h) * 33 + p] = dyr[q];
         __syncthreads();
-        // (3) contraction over the 32 pixels
+        if (ti + 1 < t1) {
+            const TapRaw raw = raw_next;
+            if (ti + 2 < t1) raw_next = stage_raw(ti + 2);
+            stage_gather(ti + 1, raw);
+        }
+        // contraction over the 32 pixels of tile ti
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const float a = myT[p * 33 + 2 * k + h];
@@ -740,6 +941,21 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     const int nb = g.Cop / 32;
     const int mb = pick_mb(nb, tiles * B);
     dim3 grid((tiles + 3) / 4, B, (nb + mb - 1) / mb), block(256);
+#ifndef DCN_NO_FWD9
+    if (g.KK == 9 && W >= 2 && (size_t)Cin * 9 * g.Cop <= nw) {      // 3x3 fast path (the only shape DGDE uses); reuses the Wf area
+        const size_t n9 = (size_t)Cin * 9 * g.Cop;
+        hipLaunchKernelGGL(dcn_prep_weights9, dim3((unsigned)((n9 + 255) / 256 < 2048 ? (n9 + 255) / 256 : 2048)), dim3(256), 0,
+                           stream, weight, wf, g);
+        const int mb9 = mb > 4 ? 4 : mb;                   // 72 VGPRs of tap state: keep <= 64 accumulator registers
+        dim3 grid9((tiles + 3) / 4, B, (nb + mb9 - 1) / mb9);
+        switch (mb9) {
+            case 4: hipLaunchKernelGGL(dcn_fwd9_f32<4>, grid9, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
+            case 2: hipLaunchKernelGGL(dcn_fwd9_f32<2>, grid9, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
+            default: hipLaunchKernelGGL(dcn_fwd9_f32<1>, grid9, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
+        }
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
+#endif
     switch (mb) {
         case 8: hipLaunchKernelGGL(dcn_fwd_f32<8>, grid, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
         case 4: hipLaunchKernelGGL(dcn_fwd_f32<4>, grid, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
