@@ -111,7 +111,9 @@ def run_gpu(args):
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
-    torch.backends.cudnn.benchmark = False     # MIOpen exhaustive find on a fresh box costs minutes; use its heuristics
+    # MIOpen: its exhaustive find costs minutes on a fresh box, so by default its heuristics (immediate mode) pick the
+    # conv kernels.  DCD_MIOPEN_FIND=1 turns the search on (used once to fill dcd_amd/miopen_db/, see README).
+    torch.backends.cudnn.benchmark = os.environ.get("DCD_MIOPEN_FIND", "0") == "1"
 
     cfg, model, optimizer, images, targets, per_rank = build_everything(args, device, world, local_rank)
     timer = DcnTimer(torch, _ext)

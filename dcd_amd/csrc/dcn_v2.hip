@@ -718,7 +718,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
             const float *gp = gy_b + (size_t)(o < g.Co ? o : last_o) * g.HoWo;
 #pragma unroll
             for (int e = 0; e < INV_CAP; ++e)
+#ifdef K3_ABL_NOGATHER
+                if (e < maxc) gv[e] = ew[e] + (float)st;
+#else
                 if (e < maxc) gv[e] = ldg(gp, eoff[e]);
+#endif
             const float *wp = (const float *)((const char *)wb + (size_t)st * Kp8);
 #pragma unroll
             for (int mb = 0; mb < MB; ++mb) {
@@ -941,7 +945,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     const int rb = blockIdx.x * 4 + wave;
     const bool rbv = rb < RB;
     const int rbc = rbv ? rb : RB - 1;
-    const int seg = rbc / nblk, blk = rbc - seg * nblk;
+    // row-blocks are numbered channel-block major: the 4 waves of a workgroup take 4 consecutive TAPS of the same 32
+    // channels, so their gathers (same planes, neighbouring positions) share L1 lines while the barriers keep them in step
+    const int S_ = g.dg * g.KK;
+    const int blk = rbc / S_, seg = rbc - blk * S_;
     const int grp = seg / g.KK, t = seg - grp * g.KK;
     const int ob0 = blockIdx.z * MB;
 
@@ -986,6 +993,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
         for (int q = 0; q < 16; ++q) {
             const int cc = blk * 32 + 2 * q + h;
             const float *ip = in_g + (size_t)(cc < g.cpg ? cc : 0) * HW;
+#ifdef DW_ABL_NOGATHER
+            if (true) { v[q][0] = s.a0; v[q][1] = s.a1 + (float)q; v[q][2] = s.b0; v[q][3] = s.b1; (void)ip; } else
+#endif
             if (g.W >= 2) {
                 const f32x2 tp = ldg2(ip, (unsigned)s.pt * 4u), bt = ldg2(ip, (unsigned)s.pb * 4u);
                 v[q][0] = tp.x; v[q][1] = tp.y; v[q][2] = bt.x; v[q][3] = bt.y;
@@ -1023,6 +1033,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
             stage_gather(ti + 1, raw);
         }
         // contraction over the 32 pixels of tile ti
+#ifdef DW_ABL_NOMFMA
+        if (ti < 0)
+#endif
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const float a = myT[p * 33 + 2 * k + h];
