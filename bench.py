@@ -81,7 +81,8 @@ def build_everything(args, device, world, local_rank):
     from dcd_amd.model.detector import KeypointDetector
 
     _ext.set_precision(args.precision)
-    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1])
+    force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1 or force_ddp])
     torch.manual_seed(0)
     model = KeypointDetector(cfg)
     init_like_trained(model, std=0.01, seed=0)
@@ -108,7 +109,7 @@ def run_gpu(args):
             args.gpus, world, args.gpus))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1:
+    if world > 1 or "RANK" in os.environ:                               # launched by torch.distributed.run
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
     # MIOpen: its exhaustive find costs minutes on a fresh box, so by default its heuristics (immediate mode) pick the
@@ -165,7 +166,7 @@ def run_gpu(args):
                               "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[args.precision] if dcn_ms > 0 else None,
                               "flops": fl},
         }
-    if world > 1:
+    if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
     return out

@@ -61,8 +61,9 @@ def build_scheduler(optimizer, cfg):
 def wrap_distributed(model, cfg, local_rank):
     """SyncBN (when MODEL.USE_SYNC_BN) + DistributedDataParallel over RCCL.  Unlike the reference no unused-parameter
     search is needed (the ImageNet `fc` is never attached), and gradients live in the all-reduce buckets."""
-    if comm.get_world_size() == 1:
-        return model
+    import os
+    if comm.get_world_size() == 1 and os.environ.get("DCD_FORCE_DDP", "0") != "1":
+        return model      # DCD_FORCE_DDP=1: wrap anyway (exercises SyncBN + DDP + RCCL on a single GPU)
     # parameters that structurally never get a gradient (the reason the reference needs find_unused_parameters=True,
     # besides the ImageNet `fc`): freeze them so DDP does not wait for their all-reduce.  Equivalent to the reference,
     # whose optimizer skips parameters whose grad is None.
