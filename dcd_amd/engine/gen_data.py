@@ -1,0 +1,42 @@
+"""DGDE -> GMW wire format.
+
+  gen_data_train.json : Loss_Computation.gen_data dumped as is  (DGDE/engine/trainer.py:207-215):
+      {'kpts_2d': [it][n][73][2] (K-normalised), 'kpts_3d': [it][n][73][3], 'pred_rot': [it][n], 'gt_location': [it][n][3],
+       'pred_location': [it][n][3], 'weight_img': [], 'img_idx': [it][n] str}
+  gen_data_infer.json : {img_id: [{'kpts_2d','kpts_3d','pred_rot','box','dim','pred_location','score','cat'}]}
+      built from the PostProcessor rows [cls, alpha, x1,y1,x2,y2, h,w,l, x,y,z, roty, score] (DGDE/engine/inference.py:59-84).
+Same keys, nesting and `json.dump(indent=4)` as the reference, so GMW's reader (GMW/utilities/dataset_utilities.py:11-56)
+takes the files unchanged.
+"""
+import json
+import os
+
+
+def dump_gen_data_train(loss_evaluator, out_dir="gen_data"):
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "gen_data_train.json")
+    with open(path, "w") as f:
+        json.dump(loss_evaluator.gen_data, f, indent=4)
+    return path
+
+
+def infer_records(output, visualize_preds, cat="Car"):
+    """One image's detections (N,14) + the PostProcessor's `gen_*` tensors -> list of GMW records."""
+    out = output.detach().cpu()
+    k2 = visualize_preds['gen_pred_extra_kpts_2d'].detach().cpu()
+    k3 = visualize_preds['gen_pred_extra_kpts_3d'].detach().cpu()
+    recs = []
+    for i in range(out.shape[0]):
+        recs.append({'kpts_2d': k2[i].numpy().tolist(), 'kpts_3d': k3[i].numpy().tolist(),
+                     'pred_rot': out[i][12:13].numpy().tolist(), 'box': out[i][2:6].numpy().tolist(),
+                     'dim': out[i][6:9].numpy().tolist(), 'pred_location': out[i][9:12].numpy().tolist(),
+                     'score': out[i][13:14].numpy().tolist(), 'cat': cat})
+    return recs
+
+
+def dump_gen_data_infer(infer_data, out_dir="gen_data"):
+    os.makedirs(out_dir, exist_ok=True)
+    path = os.path.join(out_dir, "gen_data_infer.json")
+    with open(path, "w") as f:
+        json.dump(infer_data, f, indent=4)
+    return path

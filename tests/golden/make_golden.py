@@ -224,6 +224,21 @@ def golden_loss_computation():
     save("loss_computation", **out)
 
 
+def golden_gen_data():
+    """TEST.GENERATE_GMW: the per-object records Loss_Computation collects for GMW (detector_loss.py:148-173)."""
+    from model.head.detector_loss import Loss_Computation
+    cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96, "TEST.GENERATE_GMW", True])
+    preds, targets = gi.loss_inputs()
+    lc = Loss_Computation(cfg)
+    with torch.no_grad():
+        lc({"cls": torch.from_numpy(preds["cls"]), "reg": torch.from_numpy(preds["reg"])}, to_ref_targets(targets))
+    gd = lc.gen_data
+    save("gen_data", kpts_2d=np.array(gd["kpts_2d"][0], np.float32), kpts_3d=np.array(gd["kpts_3d"][0], np.float32),
+         pred_rot=np.array(gd["pred_rot"][0], np.float32), gt_location=np.array(gd["gt_location"][0], np.float32),
+         pred_location=np.array(gd["pred_location"][0], np.float32), img_idx=np.array(gd["img_idx"][0]),
+         keys=np.array(list(gd.keys())))
+
+
 def golden_model():
     from model.detector import KeypointDetector
     cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
@@ -263,6 +278,17 @@ def golden_model():
         torch.cuda.FloatTensor = orig
     out["eval_result"] = T(result)
     out["eval_vis_scores"] = T(eval_utils["vis_scores"])
+    # the same eval pass with TEST.GENERATE_GMW: K-normalised keypoints for GMW inference (detector_infer.py:227-243)
+    model.heads.post_processor.generate_data = True
+    torch.cuda.FloatTensor = torch.FloatTensor
+    try:
+        with torch.no_grad():
+            result_g, _, vis_g = model(images[:1], ref_targets[:1])
+    finally:
+        torch.cuda.FloatTensor = orig
+    out["gen_result"] = T(result_g)
+    out["gen_kpts_2d"] = T(vis_g["gen_pred_extra_kpts_2d"])
+    out["gen_kpts_3d"] = T(vis_g["gen_pred_extra_kpts_3d"])
     save("model_96x320", **out)
 
 
@@ -276,6 +302,7 @@ def main():
     golden_anno_encoder()
     golden_decode()
     golden_loss_computation()
+    golden_gen_data()
     golden_model()
 
 

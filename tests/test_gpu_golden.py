@@ -93,6 +93,10 @@ def test_loss_computation_matches_reference(cuda):
     H.check_loss_computation(cuda, 1e-4)
 
 
+def test_gen_data_for_gmw_matches_reference(cuda):
+    H.check_gen_data(cuda, 2e-3)      # the normalised keypoints pass through the solver's mean depth: 2e-3 of the value range
+
+
 def test_whole_model_matches_reference(cuda):
     """KeypointDetector on the GPU (MIOpen convs + HIP DCNv2 + HIP losses) vs the reference on CPU:
     features, predictions, all 13 losses, per-parameter gradient norms, BN statistics and the eval decode.

@@ -126,6 +126,50 @@ def check_model(device, tol, gtol):
         if d[j] <= 0.5 and (np.abs(row - ref[j]) / scale).max() <= 20 * tol:
             matched += 1
     assert matched >= 0.9 * len(ref), "only %d of %d decoded rows match the reference" % (matched, len(ref))
+    # TEST.GENERATE_GMW eval pass -> gen_data_infer.json records (DGDE/engine/inference.py:59-84)
+    from dcd_amd.engine.gen_data import infer_records
+    model.heads.post_processor.generate_data = True
+    with torch.no_grad():
+        result_g, _, vis_g = model(images[:1], targets[:1])
+    recs = infer_records(result_g, vis_g)
+    assert len(recs) == g["gen_result"].shape[0]
+    assert set(recs[0]) == {'kpts_2d', 'kpts_3d', 'pred_rot', 'box', 'dim', 'pred_location', 'score', 'cat'}
+    ref_box, matched = g["gen_result"][:, 2:6], 0
+    for r in recs:
+        d = np.abs(ref_box - np.array(r['box'])[None]).max(1)
+        j = int(d.argmin())
+        k2, k3 = g["gen_kpts_2d"][j], g["gen_kpts_3d"][j]
+        if (d[j] <= 0.5 and np.abs(np.array(r['kpts_2d']) - k2).max() <= 20 * tol * (np.abs(k2).max() + 1e-6)
+                and np.abs(np.array(r['kpts_3d']) - k3).max() <= 20 * tol * (np.abs(k3).max() + 1e-6)):
+            matched += 1
+    assert matched >= 0.9 * len(recs), "only %d of %d GMW inference records match the reference" % (matched, len(recs))
+
+
+def check_gen_data(device, tol):
+    import json
+    from dcd_amd.config import get_cfg
+    from dcd_amd.engine.gen_data import dump_gen_data_train
+    from dcd_amd.model.head.detector_loss import Loss_Computation
+    g = load("gen_data")
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96,
+                        "TEST.GENERATE_GMW", True])
+    preds, targets = gi.loss_inputs()
+    lc = Loss_Computation(cfg)
+    with torch.no_grad():
+        lc({"cls": torch.from_numpy(preds["cls"]).to(device), "reg": torch.from_numpy(preds["reg"]).to(device)},
+           [t.to(device) for t in targets])
+    gd = lc.gen_data
+    assert list(gd.keys()) == list(g["keys"])
+    for k in ("kpts_2d", "kpts_3d", "pred_rot", "gt_location", "pred_location"):
+        got, ref = np.array(gd[k][0], np.float32), g[k]
+        assert got.shape == ref.shape, k
+        assert np.abs(got - ref).max() <= tol * max(np.abs(ref).max(), 1.0), k
+    assert list(gd["img_idx"][0]) == list(g["img_idx"])
+    import tempfile
+    with tempfile.TemporaryDirectory() as d:
+        path = dump_gen_data_train(lc, d)
+        back = json.load(open(path))
+        assert set(back.keys()) == set(gd.keys()) and len(back["kpts_2d"][0][0]) == 73
 
 
 def test_cfg_and_registry():
@@ -146,6 +190,10 @@ def test_anno_encoder_matches_reference(cpu_backend):
 
 def test_loss_computation_matches_reference(cpu_backend):
     check_loss_computation(torch.device("cpu"), 2e-5)
+
+
+def test_gen_data_for_gmw_matches_reference(cpu_backend):
+    check_gen_data(torch.device("cpu"), 2e-5)
 
 
 def test_whole_model_matches_reference(cpu_backend):
