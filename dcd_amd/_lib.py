@@ -10,8 +10,8 @@ _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libdcd_hip.so")
 _LIB = None
 
-c_void_p, c_int, c_float, c_size_t, c_int64 = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
-                                               ctypes.c_size_t, ctypes.c_int64)
+c_void_p, c_int, c_float, c_size_t, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
+                                                         ctypes.c_size_t, ctypes.c_int64, ctypes.c_double)
 
 # name -> (restype, argtypes); mirrors include/dcd_hip.h one to one
 SIGNATURES = {
@@ -31,6 +31,13 @@ SIGNATURES = {
     "dcd_poi_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "dcd_poi_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "dcd_iou3d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dcd_bn_workspace_bytes": (c_size_t, [c_int]),
+    "dcd_bn_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),
+    "dcd_bn_train_apply": (c_int, [c_void_p] * 6 + [c_double] + [c_void_p] * 3 + [c_float, c_float, c_int] + [c_void_p] * 3
+                           + [c_int, c_int, c_int64]),
+    "dcd_bn_eval_apply": (c_int, [c_void_p] * 7 + [c_float, c_int, c_void_p, c_int, c_int, c_int64]),
+    "dcd_bn_backward_stats": (c_int, [c_void_p] * 5 + [c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),
+    "dcd_bn_backward_apply": (c_int, [c_void_p] * 8 + [c_double] + [c_void_p] * 4 + [c_int, c_int, c_int64]),
 }
 
 STATUS = {1: "bad argument", 2: "workspace too small", 3: "kernel launch failed"}

@@ -1,0 +1,349 @@
+// Batch normalisation (training + eval) fused with the residual add and the ReLU that follow it everywhere in DLA-34
+// and the CenterNet heads (DGDE/model/backbone/dla_dcn.py:71-101 BasicBlock, :187-207 Root, :267-295 conv levels,
+// :398-410 DeformConv; DGDE/model/head/detector_predictor.py:52-60,112-120).  gfx950 only.
+//
+// Why it exists: MIOpen's spatial BN runs ONE workgroup per channel and ATen's native kernels one block-row per
+// channel; with 16 / 32 channels at 384x1280 (251 MB tensors) that is 2-3 ms per call on a 256-CU part.  Here the
+// reduction is split over (slice, channel) so every layer launches >= 1024 workgroups, sums are carried in fp64 (exact
+// to ~1e-16, so var = E[x^2] - mean^2 has no cancellation problem), and normalise + residual + ReLU is one pass.
+//
+// HBM passes (fp32 tensors of N = B*C*HW elements):
+//   forward : stats 1R;  apply 1R (+1R residual) 1W                       (stock: BN 2R 1W, add 2R 1W, relu 1R 1W)
+//   backward: sums  3R (dy, y, x);  apply 3R 1W (+1W grad_residual)        (stock: relu 2R 1W, BN 4R 1W, add 1R ..)
+// All kernels are HBM-bound; layout NCHW, one (b, c) plane chunk per workgroup so scale/shift are scalars.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dcd_hip.h"
+
+namespace {
+
+constexpr int BT = 256;            // threads per workgroup
+constexpr int CH = 4096;           // elements of one (b, c) plane handled per workgroup pass (4 float4 per thread)
+constexpr int SMAX = 256;          // max slices per channel in the two-stage reductions
+
+__device__ inline double wave_sum(double v)
+{
+#pragma unroll
+    for (int o = 32; o; o >>= 1) v += __shfl_down(v, o);
+    return v;
+}
+
+// Block-wide sum of two doubles; result valid in thread 0.
+__device__ inline void block_sum2(double &a, double &b)
+{
+    __shared__ double sh[2][BT / 64];
+    a = wave_sum(a);
+    b = wave_sum(b);
+    const int w = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { sh[0][w] = a; sh[1][w] = b; }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        a = sh[0][0]; b = sh[1][0];
+#pragma unroll
+        for (int i = 1; i < BT / 64; ++i) { a += sh[0][i]; b += sh[1][i]; }
+    }
+}
+
+struct Plane {
+    int B, C, cpp;      // cpp = chunks per plane
+    long HW;
+};
+
+// ---- forward statistics: partial[c][s] = (sum x, sum x^2) over the chunks s, s+S, ... of channel c ------------------
+__global__ __launch_bounds__(BT) void bn_partial(const float *__restrict__ x, Plane g, int S, double *__restrict__ partial)
+{
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int P = g.B * g.cpp;
+    const bool vec = (g.HW & 3) == 0;
+    double ds = 0.0, dq = 0.0;
+    for (int j = s; j < P; j += S) {
+        const int b = j / g.cpp, k = j - b * g.cpp;
+        const float *p = x + ((long)b * g.C + c) * g.HW;
+        const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
+        float fs = 0.f, fq = 0.f;
+        if (vec) {
+            for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + i);
+                fs += (v.x + v.y) + (v.z + v.w);
+                fq = fmaf(v.x, v.x, fmaf(v.y, v.y, fmaf(v.z, v.z, fmaf(v.w, v.w, fq))));
+            }
+        } else {
+            for (long i = lo + threadIdx.x; i < hi; i += BT) {
+                const float v = p[i];
+                fs += v;
+                fq = fmaf(v, v, fq);
+            }
+        }
+        ds += (double)fs;          // <= 16 fp32 terms per thread per chunk, then fp64
+        dq += (double)fq;
+    }
+    block_sum2(ds, dq);
+    if (threadIdx.x == 0) {
+        partial[((long)c * S + s) * 2 + 0] = ds;
+        partial[((long)c * S + s) * 2 + 1] = dq;
+    }
+}
+
+// ---- combine S partials per channel (fixed order -> deterministic) ---------------------------------------------------
+__global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ partial, int S, double *__restrict__ out)
+{
+    const int c = blockIdx.x;
+    double a = 0.0, b = 0.0;
+    for (int s = threadIdx.x; s < S; s += 64) {
+        a += partial[((long)c * S + s) * 2 + 0];
+        b += partial[((long)c * S + s) * 2 + 1];
+    }
+    a = wave_sum(a);
+    b = wave_sum(b);
+    if (threadIdx.x == 0) { out[2 * c] = a; out[2 * c + 1] = b; }
+}
+
+// ---- forward apply: y = act((x - mean) * invstd * w + b [+ residual]) ------------------------------------------------
+// stats != nullptr: training, batch statistics from (sum, sumsq, count); else eval with (mean_in, var_in).
+__global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, const float *__restrict__ residual,
+                                               const float *__restrict__ weight, const float *__restrict__ bias,
+                                               const double *__restrict__ stats, double count,
+                                               float *__restrict__ running_mean, float *__restrict__ running_var,
+                                               long long *__restrict__ num_batches_tracked, float momentum, float eps,
+                                               int relu, float *__restrict__ y, float *__restrict__ save_mean,
+                                               float *__restrict__ save_invstd, Plane g)
+{
+    const int c = blockIdx.y;
+    const int b = blockIdx.x / g.cpp, k = blockIdx.x - b * g.cpp;
+    float mean, invstd;
+    if (stats) {
+        const double m = stats[2 * c] / count;
+        double var = stats[2 * c + 1] / count - m * m;
+        var = var < 0.0 ? 0.0 : var;
+        mean = (float)m;
+        invstd = (float)(1.0 / sqrt(var + (double)eps));
+        if (blockIdx.x == 0 && threadIdx.x == 0) {
+            save_mean[c] = mean;
+            save_invstd[c] = invstd;
+            if (running_mean) {
+                const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+                running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+                running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+            }
+            if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+        }
+    } else {
+        mean = running_mean[c];
+        invstd = 1.f / sqrtf(running_var[c] + eps);
+    }
+    const float scale = invstd * (weight ? weight[c] : 1.f);
+    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+    const long base = ((long)b * g.C + c) * g.HW;
+    const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
+    if ((g.HW & 3) == 0) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
+            float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+            v.x = fmaf(v.x, scale, shift); v.y = fmaf(v.y, scale, shift);
+            v.z = fmaf(v.z, scale, shift); v.w = fmaf(v.w, scale, shift);
+            if (residual) {
+                const float4 r = *reinterpret_cast<const float4 *>(residual + base + i);
+                v.x += r.x; v.y += r.y; v.z += r.z; v.w += r.w;
+            }
+            if (relu) {      // NaN-propagating, like clamp_min
+                v.x = v.x < 0.f ? 0.f : v.x; v.y = v.y < 0.f ? 0.f : v.y; v.z = v.z < 0.f ? 0.f : v.z; v.w = v.w < 0.f ? 0.f : v.w;
+            }
+            *reinterpret_cast<float4 *>(y + base + i) = v;
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += BT) {
+            float v = fmaf(x[base + i], scale, shift);
+            if (residual) v += residual[base + i];
+            y[base + i] = (relu && v < 0.f) ? 0.f : v;
+        }
+    }
+}
+
+// ---- backward sums: partial[c][s] = (sum dz, sum dz * (x - mean)), dz = dy * [y > 0] when ReLU is fused ---------------
+__global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
+                                                     const float *__restrict__ x, const float *__restrict__ save_mean,
+                                                     Plane g, int S, double *__restrict__ partial)
+{
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int P = g.B * g.cpp;
+    const bool vec = (g.HW & 3) == 0;
+    const float mean = save_mean[c];
+    double d0 = 0.0, d1 = 0.0;
+    for (int j = s; j < P; j += S) {
+        const int b = j / g.cpp, k = j - b * g.cpp;
+        const long base = ((long)b * g.C + c) * g.HW;
+        const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
+        float f0 = 0.f, f1 = 0.f;
+        if (vec) {
+            for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
+                float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
+                const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+                if (y) {
+                    const float4 o = *reinterpret_cast<const float4 *>(y + base + i);
+                    d.x = o.x <= 0.f ? 0.f : d.x; d.y = o.y <= 0.f ? 0.f : d.y;
+                    d.z = o.z <= 0.f ? 0.f : d.z; d.w = o.w <= 0.f ? 0.f : d.w;
+                }
+                f0 += (d.x + d.y) + (d.z + d.w);
+                f1 = fmaf(d.x, v.x - mean, fmaf(d.y, v.y - mean, fmaf(d.z, v.z - mean, fmaf(d.w, v.w - mean, f1))));
+            }
+        } else {
+            for (long i = lo + threadIdx.x; i < hi; i += BT) {
+                float d = dy[base + i];
+                if (y) d = y[base + i] <= 0.f ? 0.f : d;
+                f0 += d;
+                f1 = fmaf(d, x[base + i] - mean, f1);
+            }
+        }
+        d0 += (double)f0;
+        d1 += (double)f1;
+    }
+    block_sum2(d0, d1);
+    if (threadIdx.x == 0) {
+        partial[((long)c * S + s) * 2 + 0] = d0;
+        partial[((long)c * S + s) * 2 + 1] = d1;
+    }
+}
+
+// ---- backward apply: dx = (dz - mean(dz) - xhat * mean(dz * xhat)) * invstd * w;  grad_residual = dz ------------------
+__global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
+                                                   const float *__restrict__ x, const float *__restrict__ weight,
+                                                   const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                   const double *__restrict__ sums, double count, float *__restrict__ dx,
+                                                   float *__restrict__ dres, float *__restrict__ dweight,
+                                                   float *__restrict__ dbias, Plane g)
+{
+    const int c = blockIdx.y;
+    const int b = blockIdx.x / g.cpp, k = blockIdx.x - b * g.cpp;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    const double s0 = sums[2 * c], s1 = sums[2 * c + 1];
+    if (blockIdx.x == 0 && threadIdx.x == 0) {
+        if (dweight) dweight[c] = (float)(s1 * (double)invstd);
+        if (dbias) dbias[c] = (float)s0;
+    }
+    const float k1 = invstd * (weight ? weight[c] : 1.f);
+    const float a = (float)(s0 / count);
+    const float bq = (float)(s1 / count * (double)invstd * (double)invstd);
+    const long base = ((long)b * g.C + c) * g.HW;
+    const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
+    if ((g.HW & 3) == 0) {
+        for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
+            float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
+            const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
+            if (y) {
+                const float4 o = *reinterpret_cast<const float4 *>(y + base + i);
+                d.x = o.x <= 0.f ? 0.f : d.x; d.y = o.y <= 0.f ? 0.f : d.y;
+                d.z = o.z <= 0.f ? 0.f : d.z; d.w = o.w <= 0.f ? 0.f : d.w;
+            }
+            if (dres) *reinterpret_cast<float4 *>(dres + base + i) = d;
+            float4 r;
+            r.x = (d.x - a - (v.x - mean) * bq) * k1; r.y = (d.y - a - (v.y - mean) * bq) * k1;
+            r.z = (d.z - a - (v.z - mean) * bq) * k1; r.w = (d.w - a - (v.w - mean) * bq) * k1;
+            *reinterpret_cast<float4 *>(dx + base + i) = r;
+        }
+    } else {
+        for (long i = lo + threadIdx.x; i < hi; i += BT) {
+            float d = dy[base + i];
+            if (y) d = y[base + i] <= 0.f ? 0.f : d;
+            if (dres) dres[base + i] = d;
+            dx[base + i] = (d - a - (x[base + i] - mean) * bq) * k1;
+        }
+    }
+}
+
+inline Plane make_plane(int B, int C, long HW)
+{
+    Plane g;
+    g.B = B; g.C = C; g.HW = HW;
+    g.cpp = (int)((HW + CH - 1) / CH);
+    return g;
+}
+
+// slices per channel: enough workgroups to fill 256 CUs several times over, never more than there are chunks
+inline int slices(const Plane &g)
+{
+    const long P = (long)g.B * g.cpp;
+    long want = (4096 + g.C - 1) / g.C;
+    if (want > SMAX) want = SMAX;
+    if (want > P) want = P;
+    return (int)(want < 1 ? 1 : want);
+}
+
+inline bool bad_shape(int B, int C, long HW) { return B <= 0 || C <= 0 || HW <= 0 || C > 65535 || (double)B * ((HW + CH - 1) / CH) > 2.0e9; }
+
+}  // namespace
+
+extern "C" {
+
+size_t dcd_bn_workspace_bytes(int C) { return C > 0 ? (size_t)C * SMAX * 2 * sizeof(double) : 0; }
+
+int dcd_bn_stats(void *stream_, const float *x, int B, int C, int64_t HW, double *stats, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !stats || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
+    hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, stats);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_bn_train_apply(void *stream_, const float *x, const float *residual, const float *weight, const float *bias,
+                       const double *stats, double count, float *running_mean, float *running_var,
+                       int64_t *num_batches_tracked, float momentum, float eps, int relu, float *y, float *save_mean,
+                       float *save_invstd, int B, int C, int64_t HW)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !y || !stats || !save_mean || !save_invstd || bad_shape(B, C, HW) || !(count >= 1.0)) return DCD_ERR_BAD_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return DCD_ERR_BAD_ARG;
+    const Plane g = make_plane(B, C, HW);
+    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, stats, count, running_mean,
+                       running_var, (long long *)num_batches_tracked, momentum, eps, relu, y, save_mean, save_invstd, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_bn_eval_apply(void *stream_, const float *x, const float *residual, const float *weight, const float *bias,
+                      const float *running_mean, const float *running_var, float eps, int relu, float *y, int B, int C,
+                      int64_t HW)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !y || !running_mean || !running_var || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    const Plane g = make_plane(B, C, HW);
+    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, (const double *)nullptr, 1.0,
+                       const_cast<float *>(running_mean), const_cast<float *>(running_var), (long long *)nullptr, 0.f, eps,
+                       relu, y, (float *)nullptr, (float *)nullptr, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_bn_backward_stats(void *stream_, const float *grad_y, const float *y, const float *x, const float *save_mean, int B,
+                          int C, int64_t HW, double *sums, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !sums || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws);
+    hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, sums);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_bn_backward_apply(void *stream_, const float *grad_y, const float *y, const float *x, const float *weight,
+                          const float *save_mean, const float *save_invstd, const double *sums, double count,
+                          float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C, int64_t HW)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !save_invstd || !sums || !grad_x || bad_shape(B, C, HW) || !(count >= 1.0))
+        return DCD_ERR_BAD_ARG;
+    const Plane g = make_plane(B, C, HW);
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd, sums,
+                       count, grad_x, grad_residual, grad_weight, grad_bias, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -58,6 +58,24 @@ def build_scheduler(optimizer, cfg):
     return sched, warm
 
 
+def enable_sync_bn(model, group=None):
+    """MODEL.USE_SYNC_BN (DGDE/tools/plain_train_net.py:56-57).  The fused BatchNorm2d modules all-reduce their fp64
+    per-channel sums themselves (one small RCCL call per BN per pass, no module swap, the ReLU / residual fusion stays);
+    the two BatchNorm1d of the edge-fusion branch become torch SyncBatchNorm (GPU only -- torch has no CPU SyncBN)."""
+    import torch.distributed as dist
+    from dcd_amd.model.layers.norm import BatchNorm2d
+    group = dist.group.WORLD if group is None else group
+    for name, m in list(model.named_modules()):
+        if isinstance(m, BatchNorm2d):
+            m.sync_group = group
+    if next(model.parameters()).is_cuda:
+        for parent in list(model.modules()):
+            for cname, child in list(parent.named_children()):
+                if isinstance(child, nn.BatchNorm1d):
+                    setattr(parent, cname, nn.SyncBatchNorm.convert_sync_batchnorm(child, group))
+    return model
+
+
 def wrap_distributed(model, cfg, local_rank):
     """SyncBN (when MODEL.USE_SYNC_BN) + DistributedDataParallel over RCCL.  Unlike the reference no unused-parameter
     search is needed (the ImageNet `fc` is never attached), and gradients live in the all-reduce buckets."""
@@ -72,7 +90,7 @@ def wrap_distributed(model, cfg, local_rank):
             for p in m.project.parameters():
                 p.requires_grad_(False)
     if cfg.MODEL.USE_SYNC_BN:
-        model = nn.SyncBatchNorm.convert_sync_batchnorm(model)
+        enable_sync_bn(model)
     kw = dict(broadcast_buffers=False, find_unused_parameters=False, gradient_as_bucket_view=True, bucket_cap_mb=32)
     if next(model.parameters()).is_cuda:
         kw.update(device_ids=[local_rank], output_device=local_rank)

@@ -3,7 +3,8 @@
 Module tree and parameter names equal the reference's so its checkpoints load:
 `base.{base_layer,level0..5}`, `dla_up.ida_{0,1,2}.{proj,up,node}_k`, `ida_up.{proj,up,node}_k`, with
 `DeformConv = {conv: DCN, actf: [BN, ReLU]}`.  Ordinary convolutions / BN / transposed convolutions run on
-stock PyTorch-ROCm (MIOpen); every DeformConv runs the HIP DCNv2 kernels.
+stock PyTorch-ROCm (MIOpen); every DeformConv runs the HIP DCNv2 kernels and every BN (+residual) (+ReLU) chain
+runs the fused HIP normalisation kernels (csrc/norm.hip).
 """
 import math
 
@@ -12,26 +13,21 @@ import torch
 from torch import nn
 
 from .DCNv2.dcn_v2 import DCN
+from dcd_amd.model.layers.norm import BatchNorm2d
 
 BN_MOMENTUM = 0.1
 
 
-class BatchNorm2d(nn.BatchNorm2d):
-    """nn.BatchNorm2d (same parameters / buffers / state-dict keys) that can route around MIOpen's spatial batch-norm:
-    that kernel runs ONE workgroup per channel, so the 16- and 32-channel layers at full resolution (251 MB tensors) take
-    2.4 ms forward + 1.7 ms backward each on a 256-CU chip.  ATen's native kernels split the reduction over the batch
-    and spatial axes.  `native_below` = channel count under which the native path is used (0 = always MIOpen)."""
-    native_below = int(__import__("os").environ.get("DCD_BN_NATIVE_BELOW", "64"))
-
-    def forward(self, x):
-        if x.is_cuda and self.num_features < self.native_below:
-            with torch.backends.cudnn.flags(enabled=False):
-                return super().forward(x)
-        return super().forward(x)
+def _bn(c, relu=False):
+    """The reference's `nn.BatchNorm2d(c, momentum=BN_MOMENTUM)`; `relu=True` folds the ReLU (and, at call time, the
+    residual add) that follows it into the same HIP kernel (dcd_amd/model/layers/norm.py)."""
+    return BatchNorm2d(c, momentum=BN_MOMENTUM, fuse_relu=relu)
 
 
-def _bn(c):
-    return BatchNorm2d(c, momentum=BN_MOMENTUM)
+def _relu_slot():
+    """Placeholder where the reference has `nn.ReLU(inplace=True)` after a BN inside an nn.Sequential: the ReLU runs inside
+    the preceding BN kernel; the slot keeps the Sequential indices (state-dict keys) of the reference."""
+    return nn.Identity()
 
 
 class BasicBlock(nn.Module):
@@ -40,19 +36,17 @@ class BasicBlock(nn.Module):
     def __init__(self, inplanes, planes, stride=1, dilation=1):
         super().__init__()
         self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, bias=False, dilation=dilation)
-        self.bn1 = _bn(planes)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn1 = _bn(planes, relu=True)
+        self.relu = nn.ReLU(inplace=True)       # kept for structural parity; executed inside bn1 / bn2
         self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=dilation, bias=False, dilation=dilation)
-        self.bn2 = _bn(planes)
+        self.bn2 = _bn(planes, relu=True)
         self.stride = stride
 
     def forward(self, x, residual=None):
         if residual is None:
             residual = x
-        out = self.relu(self.bn1(self.conv1(x)))
-        out = self.bn2(self.conv2(out))
-        out += residual
-        return self.relu(out)
+        out = self.bn1(self.conv1(x))                      # bn + relu
+        return self.bn2(self.conv2(out), residual)         # bn + residual + relu
 
 
 class Root(nn.Module):
@@ -61,15 +55,12 @@ class Root(nn.Module):
     def __init__(self, in_channels, out_channels, kernel_size, residual):
         super().__init__()
         self.conv = nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False, padding=(kernel_size - 1) // 2)
-        self.bn = _bn(out_channels)
-        self.relu = nn.ReLU(inplace=True)
+        self.bn = _bn(out_channels, relu=True)
+        self.relu = nn.ReLU(inplace=True)       # executed inside self.bn
         self.residual = residual
 
     def forward(self, *x):
-        out = self.bn(self.conv(torch.cat(x, 1)))
-        if self.residual:
-            out += x[0]
-        return self.relu(out)
+        return self.bn(self.conv(torch.cat(x, 1)), x[0] if self.residual else None)
 
 
 class Tree(nn.Module):
@@ -124,7 +115,7 @@ class DLA(nn.Module):
         self.channels = channels
         self.num_classes = num_classes
         self.base_layer = nn.Sequential(nn.Conv2d(3, channels[0], 7, stride=1, padding=3, bias=False),
-                                        _bn(channels[0]), nn.ReLU(inplace=True))
+                                        _bn(channels[0], relu=True), _relu_slot())
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
         self.level2 = Tree(levels[2], block, channels[1], channels[2], 2, level_root=False, root_residual=residual_root)
@@ -137,7 +128,7 @@ class DLA(nn.Module):
         mods = []
         for i in range(convs):
             mods += [nn.Conv2d(inplanes, planes, 3, stride=stride if i == 0 else 1, padding=dilation, bias=False,
-                               dilation=dilation), _bn(planes), nn.ReLU(inplace=True)]
+                               dilation=dilation), _bn(planes, relu=True), _relu_slot()]
             inplanes = planes
         return nn.Sequential(*mods)
 
@@ -189,7 +180,7 @@ def fill_up_weights(up):
 class DeformConv(nn.Module):
     def __init__(self, chi, cho):
         super().__init__()
-        self.actf = nn.Sequential(_bn(cho), nn.ReLU(inplace=True))
+        self.actf = nn.Sequential(_bn(cho, relu=True), _relu_slot())
         self.conv = DCN(chi, cho, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1)
 
     def forward(self, x):

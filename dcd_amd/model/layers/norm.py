@@ -1,0 +1,87 @@
+"""BatchNorm2d with the residual add and ReLU that follow it fused in (csrc/norm.hip).
+
+Same parameters, buffers and state-dict keys as `torch.nn.BatchNorm2d` (the reference's `BatchNorm`,
+DGDE/model/backbone/dla_dcn.py:17-18), so checkpoints are interchangeable.  `forward(x, residual=None)` computes
+`act(bn(x) + residual)` with `act` = ReLU when `fuse_relu` is set.  Where the reference has `[BN, ReLU]` inside an
+`nn.Sequential`, the ReLU slot is kept as `nn.Identity()` so module indices (and therefore keys) do not move.
+
+Device tensors always take the HIP kernels (and raise if libdcd_hip.so is missing).  CPU tensors -- the CPU test
+suite and the gloo DDP tests -- run the stock torch ops the reference itself uses.
+`sync_group`: set by `engine.trainer.wrap_distributed` when MODEL.USE_SYNC_BN; statistics are then all-reduced.
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from dcd_amd import ops
+
+
+class _SyncStatsCPU(torch.autograd.Function):
+    """SyncBN on CPU tensors over gloo (torch's SyncBatchNorm is GPU-only): the same two-phase scheme as the HIP path,
+    written with torch ops.  Test infrastructure for the world-size-2 CPU tests."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, eps, group):
+        import torch.distributed as dist
+        dims = [0] + list(range(2, x.dim()))
+        xd = x.double()
+        stats = torch.stack((xd.sum(dims), (xd * xd).sum(dims)), 1)
+        dist.all_reduce(stats, group=group)
+        count = x.numel() // x.shape[1] * dist.get_world_size(group)
+        mean = stats[:, 0] / count
+        var = (stats[:, 1] / count - mean * mean).clamp_min(0)
+        invstd = (var + eps).rsqrt()
+        shape = [1, -1] + [1] * (x.dim() - 2)
+        xhat = ((xd - mean.view(shape)) * invstd.view(shape)).float()
+        ctx.save_for_backward(xhat, weight, invstd.float())
+        ctx.group, ctx.count = group, count
+        ctx.mark_non_differentiable(mean, var)
+        return xhat * weight.view(shape) + bias.view(shape), mean, var
+
+    @staticmethod
+    def backward(ctx, gy, _gm, _gv):
+        import torch.distributed as dist
+        xhat, weight, invstd = ctx.saved_tensors
+        dims = [0] + list(range(2, gy.dim()))
+        shape = [1, -1] + [1] * (gy.dim() - 2)
+        sums = torch.stack((gy.double().sum(dims), (gy.double() * xhat.double()).sum(dims)), 1)
+        gw, gb = sums[:, 1].float(), sums[:, 0].float()
+        dist.all_reduce(sums, group=ctx.group)
+        m = (sums / ctx.count).float()
+        gx = (gy - m[:, 0].view(shape) - xhat * m[:, 1].view(shape)) * (invstd * weight).view(shape)
+        return gx, gw, gb, None, None
+
+
+class BatchNorm2d(nn.BatchNorm2d):
+    def __init__(self, num_features, eps=1e-5, momentum=0.1, fuse_relu=False):
+        super().__init__(num_features, eps=eps, momentum=momentum)
+        self.fuse_relu = fuse_relu
+        self.sync_group = None
+
+    def extra_repr(self):
+        return super().extra_repr() + ", fuse_relu={}".format(self.fuse_relu)
+
+    def _stock(self, x, residual):
+        if self.training and self.sync_group is not None:
+            y, mean, var = _SyncStatsCPU.apply(x, self.weight, self.bias, self.eps, self.sync_group)
+            with torch.no_grad():
+                n = x.numel() // x.shape[1] * torch.distributed.get_world_size(self.sync_group)
+                self.running_mean.mul_(1 - self.momentum).add_(mean.float(), alpha=self.momentum)
+                self.running_var.mul_(1 - self.momentum).add_((var * n / max(n - 1, 1)).float(), alpha=self.momentum)
+                self.num_batches_tracked.add_(1)
+        else:
+            y = super().forward(x)
+        if residual is not None:
+            y = y + residual
+        return F.relu(y) if self.fuse_relu else y
+
+    def forward(self, x, residual=None):
+        if not x.is_cuda or x.dtype != torch.float32:
+            return self._stock(x, residual)
+        if self.training:
+            return ops.batch_norm_act(x, residual, self.weight, self.bias, self.running_mean, self.running_var,
+                                      self.num_batches_tracked, self.momentum, self.eps, self.fuse_relu, self.sync_group)
+        if torch.is_grad_enabled() and (x.requires_grad or (residual is not None and residual.requires_grad)):
+            return self._stock(x, residual)      # gradients through frozen statistics: stock autograd
+        return ops.batch_norm_act_eval(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
+                                       self.fuse_relu)

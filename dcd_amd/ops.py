@@ -240,3 +240,104 @@ def iou_3d(pred_corners, target_corners):
     st = _lib.lib().dcd_iou3d(_lib.stream_of(a), a.data_ptr(), b.data_ptr(), N, out.data_ptr())
     _lib.check(st, "dcd_iou3d")
     return out
+
+
+# ----------------------------------------------------------------------------------------------
+# Batch norm (+ residual) (+ ReLU), training mode, optionally synchronised over a process group
+# ----------------------------------------------------------------------------------------------
+def _bn_ws(C, dev):
+    return torch.empty(_lib.lib().dcd_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
+
+
+class _BatchNormAct(torch.autograd.Function):
+    """y = act(batch_norm(x) [+ residual]) on the HIP kernels of csrc/norm.hip (two launches forward, two backward;
+    the stock chain is BN + add + ReLU = 3 kernels and 3 extra tensor round trips).  With `group` the per-channel fp64
+    sums are all-reduced over RCCL between the two launches (SyncBatchNorm semantics; every rank must hold the same
+    number of elements, which the reference's equal per-rank batches guarantee, DGDE/data/build.py:63-67)."""
+
+    @staticmethod
+    def forward(ctx, x, residual, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu, group):
+        _lib.require_cuda(x, residual, weight, bias)
+        L = _lib.lib()
+        x = _f32c(x)
+        residual = None if residual is None else _f32c(residual)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dev, st = x.device, _lib.stream_of(x)
+        stats = torch.empty((C, 2), dtype=torch.float64, device=dev)
+        ws = _bn_ws(C, dev)
+        _lib.check(L.dcd_bn_stats(st, x.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
+        count = float(B * HW)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(stats, group=group)
+            count *= dist.get_world_size(group)
+        y = torch.empty_like(x)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        _lib.check(L.dcd_bn_train_apply(st, x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias), stats.data_ptr(),
+                                        count, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                        float(momentum), float(eps), int(bool(relu)), y.data_ptr(), save_mean.data_ptr(),
+                                        save_invstd.data_ptr(), B, C, HW), "dcd_bn_train_apply")
+        ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+        ctx.count, ctx.group, ctx.has_res = count, group, residual is not None
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, y, weight, save_mean, save_invstd = ctx.saved_tensors
+        L = _lib.lib()
+        gy = _f32c(gy)
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        dev, st = x.device, _lib.stream_of(x)
+        sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+        ws = _bn_ws(C, dev)
+        _lib.check(L.dcd_bn_backward_stats(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), save_mean.data_ptr(), B, C, HW,
+                                           sums.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_backward_stats")
+        gw = gb = None
+        if ctx.group is not None:
+            # weight / bias gradients stay local (DDP averages them); the input gradient needs the global sums
+            import torch.distributed as dist
+            gw = (sums[:, 1] * save_invstd.double()).float()
+            gb = sums[:, 0].float()
+            dist.all_reduce(sums, group=ctx.group)
+        else:
+            gw = torch.empty(C, dtype=torch.float32, device=dev)
+            gb = torch.empty(C, dtype=torch.float32, device=dev)
+        gx = torch.empty_like(x)
+        want_res = ctx.has_res and ctx.needs_input_grad[1]
+        gres = None
+        if want_res:
+            gres = torch.empty_like(x) if y is not None else gy      # no ReLU: d(residual) is grad_y itself
+        local = ctx.group is None
+        _lib.check(L.dcd_bn_backward_apply(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
+                                           save_invstd.data_ptr(), sums.data_ptr(), ctx.count, gx.data_ptr(),
+                                           gres.data_ptr() if (want_res and y is not None) else None,
+                                           gw.data_ptr() if local else None, gb.data_ptr() if local else None, B, C, HW),
+                   "dcd_bn_backward_apply")
+        return (gx, gres, gw if weight is not None else None, gb if weight is not None else None,
+                None, None, None, None, None, None, None)
+
+
+def batch_norm_act(x, residual, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu,
+                   group=None):
+    """Training-mode BN (+residual) (+ReLU); updates the running buffers in place like F.batch_norm(training=True)."""
+    return _BatchNormAct.apply(x, residual, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps,
+                               relu, group)
+
+
+def batch_norm_act_eval(x, residual, weight, bias, running_mean, running_var, eps, relu):
+    """Inference-mode BN (+residual) (+ReLU) with the running statistics; no gradient."""
+    _lib.require_cuda(x, residual)
+    x = _f32c(x.detach())
+    residual = None if residual is None else _f32c(residual.detach())
+    B, C = x.shape[0], x.shape[1]
+    HW = x.numel() // (B * C)
+    y = torch.empty_like(x)
+    st = _lib.lib().dcd_bn_eval_apply(_lib.stream_of(x), x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias),
+                                      running_mean.data_ptr(), running_var.data_ptr(), float(eps), int(bool(relu)),
+                                      y.data_ptr(), B, C, HW)
+    _lib.check(st, "dcd_bn_eval_apply")
+    return y

@@ -150,6 +150,47 @@ int dcd_poi_scatter_add(void *stream, const float *grad_out, const int64_t *inde
  * ---------------------------------------------------------------------------------------------- */
 int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corners, int N, float *iou);
 
+/* ------------------------------------------------------------------------------------------------
+ * Batch normalisation fused with the residual add and ReLU that follow it.  Replaces the stock-op chains
+ *   bn -> relu            DGDE/model/backbone/dla_dcn.py:91-93 (BasicBlock), :272-283 (conv levels), :403-410
+ *                         (DeformConv.actf); DGDE/model/head/detector_predictor.py:52-60,112-120 (head trunks)
+ *   bn -> (+residual) -> relu   dla_dcn.py:95-99 (BasicBlock), :199-205 (Root)
+ *   bn                    dla_dcn.py:237-240 (Tree.project)
+ * i.e. torch.nn.functional.batch_norm + add + relu and their autograd.  x, residual, y: (B,C,HW) fp32 contiguous
+ * (NCHW with HW = H*W).  Statistics are exchanged as fp64 per-channel sums so that a multi-GPU job all-reduces
+ * `stats` / `sums` (C x 2 doubles) between the two calls -- the SyncBatchNorm of MODEL.USE_SYNC_BN
+ * (DGDE/tools/plain_train_net.py:56-57) -- and passes the global element count.
+ *
+ * dcd_bn_stats:           stats[c] = (sum x, sum x^2) over this rank's B*HW elements.
+ * dcd_bn_train_apply:     mean = S0/count, var = S1/count - mean^2 (biased); y = act((x-mean)*rsqrt(var+eps)*w + b
+ *                         [+ residual]); writes save_mean / save_invstd (C); when running_mean/var are given,
+ *                         running = (1-momentum)*running + momentum*(mean | var*count/(count-1)) and
+ *                         *num_batches_tracked += 1 (all nullable).  weight / bias nullable (1 / 0).
+ * dcd_bn_eval_apply:      same formula with the running statistics.
+ * dcd_bn_backward_stats:  sums[c] = (sum dz, sum dz*(x-mean)), dz = grad_y * [y > 0] when `y` (the forward output,
+ *                         ReLU fused) is given, dz = grad_y when y is NULL.
+ * dcd_bn_backward_apply:  grad_x = (dz - S0/count - (x-mean)*invstd^2*S1/count) * invstd * w;
+ *                         grad_residual = dz (nullable); grad_weight = S1*invstd, grad_bias = S0 of THIS call's sums
+ *                         (nullable; under SyncBN pass the local sums' result, see dcd_amd/norm.py).
+ * workspace: dcd_bn_workspace_bytes(C) bytes of device scratch for the two-stage reductions.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dcd_bn_workspace_bytes(int C);
+int dcd_bn_stats(void *stream, const float *x, int B, int C, int64_t HW, double *stats, void *workspace,
+                 size_t workspace_bytes);
+int dcd_bn_train_apply(void *stream, const float *x, const float *residual, const float *weight, const float *bias,
+                       const double *stats, double count, float *running_mean, float *running_var,
+                       int64_t *num_batches_tracked, float momentum, float eps, int relu, float *y, float *save_mean,
+                       float *save_invstd, int B, int C, int64_t HW);
+int dcd_bn_eval_apply(void *stream, const float *x, const float *residual, const float *weight, const float *bias,
+                      const float *running_mean, const float *running_var, float eps, int relu, float *y, int B, int C,
+                      int64_t HW);
+int dcd_bn_backward_stats(void *stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
+                          int B, int C, int64_t HW, double *sums, void *workspace, size_t workspace_bytes);
+int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, const float *x, const float *weight,
+                          const float *save_mean, const float *save_invstd, const double *sums, double count,
+                          float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,
+                          int64_t HW);
+
 #ifdef __cplusplus
 }
 #endif

@@ -37,7 +37,7 @@ def _worker(rank, world, port, out_dir):
     from dcd_amd.model.detector import KeypointDetector
 
     dist.init_process_group("gloo", rank=rank, world_size=world)
-    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False,
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False,   # plain DP gradients
                         "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
     torch.manual_seed(0)
     model = KeypointDetector(cfg).train()
@@ -82,3 +82,48 @@ def test_ddp_world_size_2_gloo(tmp_path, oracle_dcn):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["err"] < 1e-5, "DDP gradient != mean of local gradients (%g)" % res["err"]
         assert res["same"], "parameters diverged across ranks after one step"
+
+
+def _syncbn_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from dcd_amd.model.layers.norm import BatchNorm2d
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    g = torch.Generator().manual_seed(5)
+    x = torch.randn(4, 6, 5, 7, generator=g) * 2 + 1
+    res = torch.randn(4, 6, 5, 7, generator=g)
+    w = torch.randn(4, 6, 5, 7, generator=g)
+    # single-process answer on the full batch
+    ref = BatchNorm2d(6, fuse_relu=True).train()
+    with torch.no_grad():
+        ref.weight.copy_(torch.linspace(0.5, 1.5, 6))
+        ref.bias.copy_(torch.linspace(-0.2, 0.3, 6))
+    xr, rr = x.clone().requires_grad_(), res.clone().requires_grad_()
+    (ref(xr, rr) * w).sum().backward()
+    # two ranks, half the batch each, statistics exchanged over gloo
+    bn = BatchNorm2d(6, fuse_relu=True).train()
+    bn.load_state_dict(ref.state_dict())
+    bn.reset_running_stats()
+    bn.sync_group = dist.group.WORLD
+    sl = slice(2 * rank, 2 * rank + 2)
+    xs, rs = x[sl].clone().requires_grad_(), res[sl].clone().requires_grad_()
+    (bn(xs, rs) * w[sl]).sum().backward()
+    gw = bn.weight.grad.clone()
+    dist.all_reduce(gw)          # DDP would average; the full-batch gradient is the SUM of the local ones
+    ok = (torch.allclose(xs.grad, xr.grad[sl], atol=1e-5) and torch.allclose(rs.grad, rr.grad[sl], atol=1e-6)
+          and torch.allclose(gw, ref.weight.grad, atol=1e-4) and torch.allclose(bn.running_mean, ref.running_mean, atol=1e-6)
+          and torch.allclose(bn.running_var, ref.running_var, atol=1e-5) and int(bn.num_batches_tracked) == 1)
+    torch.save({"ok": bool(ok)}, os.path.join(out_dir, "s%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(300)
+def test_sync_bn_two_ranks_equal_full_batch(tmp_path):
+    """The fused BatchNorm2d's synchronised mode (statistics all-reduced as fp64 sums): two ranks with half the batch
+    each reproduce the single-process full-batch output gradients and running statistics."""
+    port = _free_port()
+    mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        assert torch.load(os.path.join(str(tmp_path), "s%d.pt" % r))["ok"]
