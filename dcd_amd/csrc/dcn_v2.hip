@@ -26,6 +26,7 @@
 
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
 
@@ -572,6 +573,224 @@ __global__ __launch_bounds__(256) void dcn_fwd_lds_f32(const float *__restrict__
 }
 
 // ---------------------------------------------------------------------------------------------
+// Forward, 3x3 / stride 1 / pad 1 / dilation 1 / one deformable group: workgroup-tiled, LDS-resident gathers.
+//
+// Measured on MI355X (tools/micro/gather_rate.hip): a vector-memory instruction whose 64 lane addresses are strictly
+// consecutive issues in ~4.5 clk per CU; the same instruction with bilinear-corner addresses (consecutive +/- a per-lane
+// jitter) takes the 4-lanes-per-clock path: 16.3 clk, dword or dwordx2 alike, and ~36 clk inside the register-gather
+// kernels once L1 misses are added.  64->64 @ 96x320 x 8 issues 4.4 M such gathers per forward: that, not MFMA, is the
+// 0.26 ms.  LDS has no such path (128 B/clk per CU for any conflict-free pattern), so here:
+//   * a workgroup of 8 waves owns an 8 x 32 pixel tile (one row segment per wave);
+//   * per chunk of 8 input channels the 16 x 40 window [r0-4, r0+12) x [c0-4, c0+36) is copied to LDS with aligned
+//     dwordx4 loads (fast path; cells outside the image become zeros = the reference's zero padding), together with the
+//     chunk's weight slab, laid out so that a lane's four A operands of a tap are ONE ds_read_b128;
+//   * chunks are double-buffered through registers: loads of chunk k+1 are issued before the MFMA work of chunk k and
+//     written to the other LDS buffer after it -- one barrier per chunk;
+//   * each bilinear corner pair is one ds_read2_b32.  Samples displaced by 3 px or more fall outside the window and are
+//     gathered from global memory by their lane after the chunk loop (correct for any offset, fast for realistic ones).
+// ---------------------------------------------------------------------------------------------
+constexpr int TL_WW = 40;                   // window cols  c0-4 .. c0+35 (16-byte aligned rows)
+constexpr int TL_CH = 8;                    // channels per chunk
+constexpr int TL_OB = 64;                   // output channels per workgroup (two 32-wide MFMA blocks)
+constexpr int TL_W_FLOATS = 9 * TL_OB * TL_CH;            // 4608: [tap][o][h][4 steps]
+constexpr int TL_NW = TL_W_FLOATS / 4;                    // 1152 dwordx4 per chunk (weights)
+// TR = waves per workgroup = tile rows (8: 16-row window, 1 workgroup / CU; 4: 12-row window, 2 workgroups / CU)
+template <int TR> struct TileCfg {
+    static constexpr int WH = TR + 8;                             // window rows r0-4 .. r0+TR+3
+    static constexpr int PLANE = (WH * TL_WW) % 64 == 32 ? WH * TL_WW : WH * TL_WW + 32;   // odd/even planes 32 banks apart
+    static constexpr int IN_FLOATS = TL_CH * PLANE;
+    static constexpr int BUF = IN_FLOATS + TL_W_FLOATS;           // floats per buffer
+    static constexpr int NIN = TL_CH * WH * (TL_WW / 4);          // dwordx4 per chunk (window)
+    static constexpr int NT = TR * 64;                            // threads
+    static constexpr int KIN = (NIN + NT - 1) / NT, KW = (TL_NW + NT - 1) / NT;
+};
+
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+
+// Wl[z][chunk][tap][o(64)][h(2)][s(4)] = W[z*64+o][chunk*8 + 2s + h][tap]   (zero padded)
+__global__ void dcn_prep_weights_tile(const float *__restrict__ w, float *__restrict__ wl, Geom g, int nchunk, int nz)
+{
+    const int n = nz * nchunk * TL_W_FLOATS;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int s = r & 3; r >>= 2;
+        const int h = r & 1; r >>= 1;
+        const int o = r % TL_OB; r /= TL_OB;
+        const int t = r % 9; r /= 9;
+        const int ck = r % nchunk, z = r / nchunk;
+        const int oo = z * TL_OB + o, c = ck * TL_CH + 2 * s + h;
+        wl[idx] = (oo < g.Co && c < g.C) ? w[((size_t)oo * g.C + c) * 9 + t] : 0.f;
+    }
+}
+
+template <int TR>
+__global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
+                                                        const float *__restrict__ msk, const float *__restrict__ wl,
+                                                        const float *__restrict__ bias, float *__restrict__ out, Geom g,
+                                                        int tiles_x, int nchunk)
+{
+    typedef TileCfg<TR> T;
+    constexpr int TL_ROWS = TR, TL_WH = T::WH, TL_PLANE = T::PLANE, TL_IN_FLOATS = T::IN_FLOATS, TL_BUF = T::BUF,
+                  TL_NIN = T::NIN, NT = T::NT, KIN = T::KIN, KW = T::KW;
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x TL_BUF
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int r0 = ty * TL_ROWS, c0 = tx * 32;
+    const int ho = r0 + wave, wo = c0 + p;
+    const bool pv = ho < g.Ho && wo < g.Wo;
+    const int Pc = pv ? ho * g.Wo + wo : 0;
+    const int z = blockIdx.z;
+    const int HW = g.H * g.W;
+    const int Y0 = r0 - 4, X0 = c0 - 4;
+
+    const float *in_b = in + (size_t)b * g.C * HW;
+    const float *off_b = off + (size_t)b * 18 * g.HoWo;
+    const float *msk_b = msk + (size_t)b * 9 * g.HoWo;
+    const float *wl_z = wl + (size_t)z * nchunk * TL_W_FLOATS;
+
+    // ---- staging map (chunk invariant): three window dwordx4 + three weight dwordx4 per thread
+    int sg[KIN], sl[KIN];            // global float offset inside the chunk's 8 planes (-1: zeros), LDS float offset
+    bool sv_[KIN];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+        const int e = tid + NT * k;
+        const int ch = e / (TL_WH * 10), rem = e - ch * (TL_WH * 10);
+        const int row = rem / 10, q = rem - row * 10;
+        const int y = Y0 + row, x = X0 + 4 * q;
+        sv_[k] = e < TL_NIN;
+        sg[k] = (sv_[k] && y >= 0 && y < g.H && x >= 0 && x < g.W) ? ch * HW + y * g.W + x : -1;
+        sl[k] = ch * TL_PLANE + row * TL_WW + 4 * q;
+    }
+    f32x4 rin[KIN], rw[KW];
+    auto issue = [&](int ck) {
+        const float *src = in_b + (size_t)ck * TL_CH * HW;
+        const int cleft = g.C - ck * TL_CH;                      // channels left (may be < 8 in the last chunk)
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            rin[k] = zero4;
+            if (sv_[k] && sg[k] >= 0 && (tid + NT * k) / (TL_WH * 10) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
+        }
+        const float *wsrc = wl_z + (size_t)ck * TL_W_FLOATS;
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (tid + NT * k < TL_NW) rw[k] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * (tid + NT * k));
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k)
+            if (sv_[k]) *reinterpret_cast<f32x4 *>(buf + sl[k]) = rin[k];
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (tid + NT * k < TL_NW) *reinterpret_cast<f32x4 *>(buf + TL_IN_FLOATS + 4 * (tid + NT * k)) = rw[k];
+    };
+
+    issue(0);
+
+    // ---- sampling state of the nine taps of this lane's pixel (while the first chunk is in flight)
+    int lo[9];
+    float wq[9][4];
+    unsigned farbits = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) {
+        const TapRaw raw = load_tap_raw(off_b, msk_b, g, t, Pc);
+        const float hf = (float)(ho - 1 + t / 3) + raw.oh, wf_ = (float)(wo - 1 + t % 3) + raw.ow;
+        const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W;
+        const float hlf = floorf(hf), wlf = floorf(wf_);
+        const int ly = sv ? (int)hlf - Y0 : 0, lx = sv ? (int)wlf - X0 : 0;
+        const bool inside = ly >= 0 && lx >= 0 && ly <= TL_WH - 2 && lx <= TL_WW - 2;
+        farbits |= (sv && !inside) ? (1u << t) : 0u;
+        lo[t] = (inside ? ly * TL_WW + lx : 0) + h * TL_PLANE;
+        const float lh = hf - hlf, lw = wf_ - wlf;
+        const float m = (sv && inside) ? raw.m : 0.f;
+        wq[t][0] = (1.f - lh) * (1.f - lw) * m; wq[t][1] = (1.f - lh) * lw * m;
+        wq[t][2] = lh * (1.f - lw) * m;         wq[t][3] = lh * lw * m;
+    }
+
+    f32x16 acc[2];
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    commit(lds);
+    __syncthreads();
+
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *buf = lds + (ck & 1) * TL_BUF;
+#ifndef TL_ABL_NOSTAGE
+        if (ck + 1 < nchunk) issue(ck + 1);
+#endif
+        const float *wb_ = buf + TL_IN_FLOATS + (p * 2 + h) * 4;
+#pragma unroll
+        for (int t = 0; t < 9; ++t) {
+#ifdef TL_ABL_NOW
+            const f32x4 a0 = {wq[t][0], wq[t][1], wq[t][2], wq[t][3]}, a1 = {wq[t][1], wq[t][0], wq[t][3], wq[t][2]};
+            (void)wb_;
+#else
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(wb_ + (t * TL_OB) * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(wb_ + (t * TL_OB + 32) * 8);
+#endif
+            const float *cp = buf + lo[t];
+            const float q0 = wq[t][0], q1 = wq[t][1], q2 = wq[t][2], q3 = wq[t][3];
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float *c2 = cp + 2 * s * TL_PLANE;
+#ifdef TL_ABL_NOLDS
+                const float val = q0 * (float)s + q1 + q2 * (float)ck + q3;
+                (void)c2;
+#else
+                const float val = q0 * c2[0] + q1 * c2[1] + q2 * c2[TL_WW] + q3 * c2[TL_WW + 1];
+#endif
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], val, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], val, acc[1], 0, 0, 0);
+            }
+        }
+#ifndef TL_ABL_NOSTAGE
+        if (ck + 1 < nchunk) commit(lds + ((ck + 1) & 1) * TL_BUF);
+#endif
+#ifndef TL_ABL_NOBAR
+        __syncthreads();
+#endif
+    }
+
+    if (__any(farbits != 0u)) {
+        // samples whose 2x2 footprint left the staged window: gathered from global memory by their lane
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            if (!__any((farbits >> t) & 1u)) continue;
+            const bool mine = (farbits >> t) & 1u;
+            const Tap s = make_tap(off_b, msk_b, g, t, t, ho, wo, Pc, pv);
+            for (int c = h; c < ((g.C + 1) & ~1); c += 2) {
+                const bool live = mine && c < g.C;
+                const float *gp = in_b + (size_t)(live ? c : 0) * HW;
+                const f32x2 gt = ldg2(gp, (unsigned)s.pt * 4u), gb = ldg2(gp, (unsigned)s.pb * 4u);
+                const float val = live ? (s.a0 * gt.x + s.a1 * gt.y + s.b0 * gb.x + s.b1 * gb.y) * s.m : 0.f;
+                const int ck = c >> 3, st = (c & 7) >> 1;
+                const float *wr = wl_z + (size_t)ck * TL_W_FLOATS + ((size_t)(t * TL_OB + p) * 2 + h) * 4 + st;
+                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[0], val, acc[0], 0, 0, 0);
+                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * 8], val, acc[1], 0, 0, 0);
+            }
+        }
+    }
+
+    float *out_b = out + (size_t)b * g.Co * g.HoWo;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        const int obase = z * TL_OB + mb * 32 + 4 * h;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int o = obase + (r & 3) + 8 * (r >> 2);
+            if (pv && o < g.Co) out_b[(size_t)o * g.HoWo + ho * g.Wo + wo] = acc[mb][r] + bias[o];
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
 // Atomic-free grad_input.
 //
 // Measured on MI355X (tools/micro/atomics.hip): global fp32 atomics retire ~21 G cache-line requests/s
@@ -585,6 +804,7 @@ __global__ __launch_bounds__(256) void dcn_fwd_lds_f32(const float *__restrict__
 // Samples whose offset exceeds the search radius, and cells that collect more than INV_CAP samples of one
 // tap, fall back to atomics inside dcn_bwd_data_f32 -- correct for any input, fast for realistic offsets.
 // ---------------------------------------------------------------------------------------------
+constexpr float TL_NEAR = 3.f;   // tiled kernels: |offset| below this stays inside every staged window
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
 constexpr int INV_RCAP = 3;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
 constexpr int INV_OVERFLOW = 255;
@@ -931,8 +1151,12 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
 template <int MB>
 __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                           const float *__restrict__ msk, const float *__restrict__ gy,
-                                                          float *__restrict__ gw, Geom g, int tiles_per_img, int nsplit)
+                                                          float *__restrict__ gw, Geom g, int tiles_per_img, int nsplit,
+                                                          const unsigned *__restrict__ far_only_absmax)
 {
+    // far-only mode (far_only_absmax != nullptr): the tiled kernel took every sample with |offset| < TL_NEAR; this kernel
+    // adds the rest, and has nothing to do when the call's max |offset| is below the threshold (uniform early exit).
+    if (far_only_absmax && __uint_as_float(*far_only_absmax) < TL_NEAR) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *colT = smem;                       // [4][32][33]
     float *dyT = smem + 4 * 32 * 33;          // [MB*32][33]
@@ -987,6 +1211,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
         int b, P, Pc, ho, wo; bool pv;
         tile_coords(ti, b, P, pv, Pc, ho, wo);
         s = finish_tap(raw, g, t, ho, wo, pv && rbv);
+        if (far_only_absmax && fabsf(raw.oh) < TL_NEAR && fabsf(raw.ow) < TL_NEAR) s.m = 0.f;     // near sample: already counted
         const float *in_g = in + ((size_t)b * g.C + (size_t)grp * g.cpg) * HW;
         const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
 #pragma unroll
@@ -1060,6 +1285,192 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Backward w.r.t. weight, workgroup-tiled (3x3 / stride 1 / pad 1 / dil 1 / one group): no transposes, no global gathers.
+//
+// dW[o][c][t] = sum_p dY[o][p] col[c,t][p] contracts over PIXELS, so the MFMA wants A[i = c][k = pixel]: lane = channel.
+// From global memory that layout is uncoalesced; from an LDS window it is just another conflict-free pattern (plane stride
+// 2*odd -> 32 channels hit 32 distinct even banks, the x+1 corner the odd ones).  So per 2 x 32-pixel tile the workgroup
+// stages the 10 x 40 window of a 32-channel block and the dY tile (stride 65: lane = o conflict-free), and each of its six
+// waves = (tile row, kernel row ky) runs 16 steps x 3 taps of: sampling state of pixel 2s+h broadcast from the lane that
+// owns it (ds_bpermute), two ds_read2_b32 corner pairs for ITS channel, bilinear, MFMA against the dY operand.
+// Accumulators (3 taps x 64 outputs) persist over the workgroup's share of tiles; one atomic flush at the end.
+// Samples displaced by >= 3 px (outside any window) are zero-weighted here and taken by dcn_bwd_weight_f32 in its
+// far-only mode, which exits immediately when max|offset| < 3 (device scalar from dcn_offset_absmax).
+// ---------------------------------------------------------------------------------------------
+constexpr int DW_TR = 2;
+constexpr int DW_WH = DW_TR + 8;                      // 10 window rows
+constexpr int DW_PLANE = DW_WH * TL_WW + 2;           // 402 = 2 * 201
+constexpr int DW_CB = 32;                             // channels per block
+constexpr int DW_IN_FLOATS = DW_CB * DW_PLANE;        // 12 864
+constexpr int DW_DYS = DW_TR * 32 + 1;                // dY row stride 65
+constexpr int DW_DY_FLOATS = TL_OB * DW_DYS;          // 4 160
+constexpr int DW_NT = DW_TR * 3 * 64;                 // 384 threads
+
+__global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
+                                                                const float *__restrict__ msk, const float *__restrict__ gy,
+                                                                float *__restrict__ gw, Geom g, int tiles_x, int tiles_y,
+                                                                int nsplit)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [DW_IN_FLOATS | DW_DY_FLOATS]
+    float *win = lds, *dyt = lds + DW_IN_FLOATS;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const int row = wave & 1, ky = wave >> 1;
+    const int cb = blockIdx.x, zo = blockIdx.z;
+    const int HW = g.H * g.W;
+    const int total = g.B * tiles_x * tiles_y;
+    const int t0 = (int)((int64_t)blockIdx.y * total / nsplit), t1 = (int)((int64_t)(blockIdx.y + 1) * total / nsplit);
+
+    f32x16 acc[3][2];
+#pragma unroll
+    for (int a = 0; a < 3; ++a)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[a][mb][r] = 0.f;
+
+    constexpr int KIN = (DW_CB * DW_WH * 10 + DW_NT - 1) / DW_NT;      // 9 window dwordx4 per thread
+    constexpr int KDY = (TL_OB * DW_TR * 8 + DW_NT - 1) / DW_NT;       // 3 dY dwordx4 per thread
+
+    for (int ti = t0; ti < t1; ++ti) {
+        const int b = ti / (tiles_x * tiles_y);
+        const int rem = ti - b * (tiles_x * tiles_y);
+        const int ty = rem / tiles_x, tx = rem - ty * tiles_x;
+        const int r0 = ty * DW_TR, c0 = tx * 32;
+        const int Y0 = r0 - 4, X0 = c0 - 4;
+        const float *in_b = in + ((size_t)b * g.C + (size_t)cb * DW_CB) * HW;
+        const float *gy_b = gy + ((size_t)b * g.Co + (size_t)zo * TL_OB) * g.HoWo;
+        const int cleft = g.C - cb * DW_CB, oleft = g.Co - zo * TL_OB;
+
+        // ---- sampling state of this wave's (row, ky), lane = pixel
+        const int ho = r0 + row, wo = c0 + i;
+        const bool pv = ho < g.Ho && wo < g.Wo;
+        const int Pc = pv ? ho * g.Wo + wo : 0;
+        const float *off_b = off + (size_t)b * 18 * g.HoWo;
+        const float *msk_b = msk + (size_t)b * 9 * g.HoWo;
+        int posv[3];
+        float wv[3][4];
+#pragma unroll
+        for (int kx = 0; kx < 3; ++kx) {
+            const int t = ky * 3 + kx;
+            const TapRaw raw = load_tap_raw(off_b, msk_b, g, t, Pc);
+            const float hf = (float)(ho - 1 + ky) + raw.oh, wf_ = (float)(wo - 1 + kx) + raw.ow;
+            const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W &&
+                            fabsf(raw.oh) < TL_NEAR && fabsf(raw.ow) < TL_NEAR;
+            const float hlf = floorf(hf), wlf = floorf(wf_);
+            const int ly = sv ? (int)hlf - Y0 : 0, lx = sv ? (int)wlf - X0 : 0;
+            posv[kx] = ly * TL_WW + lx;
+            const float lh = hf - hlf, lw = wf_ - wlf;
+            const float m = sv ? raw.m : 0.f;
+            wv[kx][0] = (1.f - lh) * (1.f - lw) * m; wv[kx][1] = (1.f - lh) * lw * m;
+            wv[kx][2] = lh * (1.f - lw) * m;         wv[kx][3] = lh * lw * m;
+        }
+
+        __syncthreads();                                   // previous tile fully consumed
+        // ---- stage the window (three batches of three dwordx4 per thread: bounded register use) and the dY tile
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+        typedef float f32x2_ __attribute__((ext_vector_type(2)));
+#pragma unroll 1
+        for (int k0 = 0; k0 < KIN; k0 += 3) {
+            f32x4 rin[3];
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = tid + DW_NT * (k0 + k);
+                const int ch = e / (DW_WH * 10), rm = e - ch * (DW_WH * 10);
+                const int wr = rm / 10, q = rm - wr * 10;
+                const int y = Y0 + wr, x = X0 + 4 * q;
+                rin[k] = zero4;
+                if (e < DW_CB * DW_WH * 10 && ch < cleft && y >= 0 && y < g.H && x >= 0 && x < g.W)
+                    rin[k] = *reinterpret_cast<const f32x4 *>(in_b + (size_t)ch * HW + y * g.W + x);
+            }
+#pragma unroll
+            for (int k = 0; k < 3; ++k) {
+                const int e = tid + DW_NT * (k0 + k);
+                const int ch = e / (DW_WH * 10), rm = e - ch * (DW_WH * 10);
+                if (e < DW_CB * DW_WH * 10) {
+                    float *d = win + ch * DW_PLANE + rm * 4;
+                    *reinterpret_cast<f32x2_ *>(d) = f32x2_{rin[k].x, rin[k].y};
+                    *reinterpret_cast<f32x2_ *>(d + 2) = f32x2_{rin[k].z, rin[k].w};
+                }
+            }
+        }
+        {
+            f32x4 rdy[KDY];
+#pragma unroll
+            for (int k = 0; k < KDY; ++k) {
+                const int e = tid + DW_NT * k;
+                const int o = e / (DW_TR * 8), rm = e - o * (DW_TR * 8);
+                const int wr = rm / 8, q = rm - wr * 8;
+                const int y = r0 + wr, x = c0 + 4 * q;
+                rdy[k] = zero4;
+                if (e < TL_OB * DW_TR * 8 && o < oleft && y < g.Ho && x < g.Wo)
+                    rdy[k] = *reinterpret_cast<const f32x4 *>(gy_b + (size_t)o * g.HoWo + y * g.Wo + x);
+            }
+#pragma unroll
+            for (int k = 0; k < KDY; ++k) {
+                const int e = tid + DW_NT * k;
+                const int o = e / (DW_TR * 8), rm = e - o * (DW_TR * 8);
+                if (e < TL_OB * DW_TR * 8) {
+                    float *d = dyt + o * DW_DYS + rm * 4;
+                    d[0] = rdy[k].x; d[1] = rdy[k].y; d[2] = rdy[k].z; d[3] = rdy[k].w;
+                }
+            }
+        }
+        __syncthreads();
+
+        const float *wl_ = win + i * DW_PLANE;                 // this lane's channel plane
+        const float *dl0 = dyt + i * DW_DYS + row * 32 + h, *dl1 = dl0 + 32 * DW_DYS;
+#pragma unroll 2
+        for (int s = 0; s < 16; ++s) {
+            const int src = 2 * s + h;                          // lane that owns pixel 2s+h of this row
+            const float d0 = dl0[2 * s], d1 = dl1[2 * s];
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx) {
+                const int pos = __shfl(posv[kx], src);
+                const float q0 = __shfl(wv[kx][0], src), q1 = __shfl(wv[kx][1], src);
+                const float q2 = __shfl(wv[kx][2], src), q3 = __shfl(wv[kx][3], src);
+                const float *cp = wl_ + pos;
+                const float val = q0 * cp[0] + q1 * cp[1] + q2 * cp[TL_WW] + q3 * cp[TL_WW + 1];
+                acc[kx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(val, d0, acc[kx][0], 0, 0, 0);
+                acc[kx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(val, d1, acc[kx][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // lane holds D[c = (r&3)+8*(r>>2)+4h][o = mb*32 + i] for its three taps.  Flush: the two tile rows are summed in LDS,
+    // laid out like the weight tensor ([o][c][t]: 288 contiguous floats per output channel), and added to global memory
+    // with COALESCED atomics -- strided per-lane atomics cost one cache-line request each (~21 G/s, tools/micro/atomics.hip).
+    constexpr int STG = DW_CB * 9 + 1;                     // 289: lanes (o) hit distinct banks
+    float *stage = lds;                                    // 32 x 289 floats (reuses the window area)
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        __syncthreads();
+        if (row == 0) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[i * STG + ((r & 3) + 8 * (r >> 2) + 4 * h) * 9 + ky * 3 + kx] = acc[kx][mb][r];
+        }
+        __syncthreads();
+        if (row == 1) {
+#pragma unroll
+            for (int kx = 0; kx < 3; ++kx)
+#pragma unroll
+                for (int r = 0; r < 16; ++r)
+                    stage[i * STG + ((r & 3) + 8 * (r >> 2) + 4 * h) * 9 + ky * 3 + kx] += acc[kx][mb][r];
+        }
+        __syncthreads();
+        for (int e = tid; e < 32 * DW_CB * 9; e += DW_NT) {
+            const int ol = e / (DW_CB * 9), j = e - ol * (DW_CB * 9);
+            const int o = zo * TL_OB + mb * 32 + ol, c = cb * DW_CB + j / 9;
+            if (o < g.Co && c < g.C) atomicAdd(gw + ((size_t)o * g.C + (size_t)cb * DW_CB) * 9 + j, stage[ol * STG + j]);
+        }
+    }
+}
+
 inline int pick_mb(int nb, int tiles_total)
 {
     // largest MB in {8,4,2,1} (32-wide Cout blocks per wave) that still leaves >= 1024 waves
@@ -1119,6 +1530,38 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             default: hipLaunchKernelGGL(dcn_fwd_lds_f32<1>, gridl, block, ldsb, stream, input, offset, mask, wf, bias, output, g, tiles_x, tiles_y); break;
         }
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
+#endif
+#ifndef DCN_NO_FWD_TILE
+    // workgroup-tiled LDS kernel: the DLA-34 shape (3x3, stride 1, pad 1, dil 1, dg 1); maps of at least 16 rows
+    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
+        H >= 16 && W >= 32) {
+        const int nchunk = (Cin + TL_CH - 1) / TL_CH, nz = (Cout + TL_OB - 1) / TL_OB;
+        const size_t nwl = (size_t)nz * nchunk * TL_W_FLOATS;
+        if (nwl <= 2 * nw) {                                          // Wl lives in the [Wf | Wb] area
+            static bool attr_set = false;
+            static int tile_rows = 0;
+            if (!attr_set) {
+                const char *e = getenv("DCD_TILE_ROWS");
+                tile_rows = (e && atoi(e) == 4) ? 4 : 8;
+                if (hipFuncSetAttribute((const void *)dcn_fwd_tile_f32<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * TileCfg<8>::BUF * sizeof(float))) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)dcn_fwd_tile_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                        (int)(2 * TileCfg<4>::BUF * sizeof(float))) != hipSuccess)
+                    return DCD_ERR_LAUNCH;
+                attr_set = true;
+            }
+            hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
+                               dim3(256), 0, stream, weight, wf, g, nchunk, nz);
+            const int tiles_x = (g.Wo + 31) / 32;
+            if (tile_rows == 8)
+                hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(tiles_x * ((g.Ho + 7) / 8), B, nz), dim3(512),
+                                   2 * TileCfg<8>::BUF * sizeof(float), stream, input, offset, mask, wf, bias, output, g, tiles_x, nchunk);
+            else
+                hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(tiles_x * ((g.Ho + 3) / 4), B, nz), dim3(256),
+                                   2 * TileCfg<4>::BUF * sizeof(float), stream, input, offset, mask, wf, bias, output, g, tiles_x, nchunk);
+            return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+        }
     }
 #endif
 #ifndef DCN_NO_FWD9
@@ -1226,6 +1669,29 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         else DCD_LAUNCH_BD(0);
 #undef DCD_LAUNCH_BD
     }
+    bool dw_tiled = false;
+#ifndef DCN_NO_BWD_TILE
+    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
+        H >= 16 && W >= 32) {
+        static bool attr_set = false;
+        const size_t ldsb = (size_t)(DW_IN_FLOATS + DW_DY_FLOATS) * sizeof(float);
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)dcn_bwd_weight_tile_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) !=
+                hipSuccess)
+                return DCD_ERR_LAUNCH;
+            attr_set = true;
+        }
+        const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + DW_TR - 1) / DW_TR;
+        const int ncb = (Cin + DW_CB - 1) / DW_CB, nzo = (Cout + TL_OB - 1) / TL_OB;
+        const int total = B * tiles_x * tiles_y;
+        int S = 512 / (ncb * nzo);
+        if (S < 1) S = 1;
+        if (S > total) S = total;
+        hipLaunchKernelGGL(dcn_bwd_weight_tile_f32, dim3(ncb, S, nzo), dim3(DW_NT), ldsb, stream, input, offset, mask, grad_output,
+                           grad_weight, g, tiles_x, tiles_y, S);
+        dw_tiled = true;
+    }
+#endif
     {
         const int RB = dg * g.KK * nblk;
         const int nb = g.Cop / 32;
@@ -1239,7 +1705,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const size_t lds = (size_t)(4 * 32 * 33 + mb * 32 * 33) * sizeof(float);
 #define DCD_LAUNCH_BW(MBV)                                                                                        \
     hipLaunchKernelGGL(dcn_bwd_weight_f32<MBV>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, \
-                       tiles, S)
+                       tiles, S, dw_tiled ? (const unsigned *)absmax : (const unsigned *)nullptr)
         if (mb == 8) DCD_LAUNCH_BW(8);
         else if (mb == 4) DCD_LAUNCH_BW(4);
         else if (mb == 2) DCD_LAUNCH_BW(2);

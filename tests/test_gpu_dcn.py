@@ -39,6 +39,10 @@ CASES = [
     (2, 64, 32, 9, 11, 2, 2.0),      # deformable_groups = 2 (DCN/testcpu.py:172-173)
     (1, 6, 3, 5, 6, 3, 6.0),         # odd channels per group, samples far outside the image
     (1, 96, 320, 8, 8, 1, 1.0),      # Cout > 256: streamed dY path
+    # shapes that take the workgroup-tiled LDS kernels (3x3 s1 p1, dg 1, W % 4 == 0, H >= 16, W >= 32)
+    (2, 64, 64, 24, 64, 1, 0.5),     # sub-pixel offsets: everything from the staged window
+    (1, 12, 70, 17, 36, 1, 1.5),     # ragged: C % 8 != 0, Cout > 64 with a partial slice, partial tiles, some far samples
+    (1, 32, 64, 16, 32, 1, 4.0),     # many samples beyond the 3-px window -> per-lane global fallback
 ]
 
 

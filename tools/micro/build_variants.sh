@@ -1,0 +1,11 @@
+#!/bin/bash
+# usage: tools/micro/build_variants.sh name1:"-DFLAG ..." name2:"..."   -> tools/micro/libdcd_<name>.so (timed by time_variants.py)
+set -e
+R=$(cd "$(dirname "$0")/../.." && pwd)
+rm -f $R/tools/micro/libdcd_*.so
+for spec in "$@"; do
+  name=${spec%%:*}; flags=${spec#*:}
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -O3 -std=c++17 -fPIC -munsafe-fp-atomics $flags -c $R/dcd_amd/csrc/dcn_v2.hip -o /tmp/v_$name.o 2>/dev/null
+  /opt/rocm/bin/hipcc --offload-arch=gfx950 -shared -fPIC -o $R/tools/micro/libdcd_$name.so /tmp/v_$name.o $R/dcd_amd/csrc/heads.o $R/dcd_amd/csrc/norm.o
+  echo built $name
+done
