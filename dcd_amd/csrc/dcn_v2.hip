@@ -31,6 +31,7 @@
 #include "../../include/dcd_hip.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 namespace {
 
@@ -823,14 +824,29 @@ __device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
     return r > INV_RCAP ? INV_RCAP : r;
 }
 
-__global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsigned *__restrict__ out_bits)
+// Also lists the 32-pixel tiles (image-major tile ids, the generic kernels' tiling) that hold at least one sample displaced
+// by TL_NEAR px or more: the workgroup-tiled kernels leave exactly those samples to the generic kernels' far-only mode,
+// which then visits the listed tiles only (usually none).  scal[0] = max bits, scal[1] = number of listed tiles.
+__global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsigned *__restrict__ scal, int HoWo,
+                                  int ch_per_img, int tiles_per_img, unsigned char *__restrict__ far_flag,
+                                  int *__restrict__ far_list)
 {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
-        m = fmaxf(m, fabsf(off[i]));
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const float v = fabsf(off[i]);
+        m = fmaxf(m, v);
+        if (!(v < TL_NEAR)) {                                      // rare
+            const int64_t plane = i / HoWo;
+            const int P = (int)(i - plane * HoWo), b = (int)(plane / ch_per_img);
+            const int tid_ = b * tiles_per_img + (P >> 5);
+            unsigned *word = (unsigned *)(far_flag + (tid_ & ~3));
+            const unsigned bit = 1u << (8 * (tid_ & 3));
+            if ((atomicOr(word, bit) & bit) == 0u) far_list[atomicAdd(scal + 1, 1u)] = tid_;
+        }
+    }
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(out_bits, __float_as_uint(m));   // non-negative floats order like their bits
+    if ((threadIdx.x & 63) == 0) atomicMax(scal, __float_as_uint(m));   // non-negative floats order like their bits
 }
 
 // one thread per (input cell q, tap segment, image)
@@ -1152,11 +1168,12 @@ template <int MB>
 __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                           const float *__restrict__ msk, const float *__restrict__ gy,
                                                           float *__restrict__ gw, Geom g, int tiles_per_img, int nsplit,
-                                                          const unsigned *__restrict__ far_only_absmax)
+                                                          const unsigned *__restrict__ far_scal, const int *__restrict__ far_list)
 {
-    // far-only mode (far_only_absmax != nullptr): the tiled kernel took every sample with |offset| < TL_NEAR; this kernel
-    // adds the rest, and has nothing to do when the call's max |offset| is below the threshold (uniform early exit).
-    if (far_only_absmax && __uint_as_float(*far_only_absmax) < TL_NEAR) return;
+    // far-only mode (far_scal != nullptr): the tiled kernel took every sample with |offset| < TL_NEAR; this kernel adds the
+    // rest, walking only the tiles dcn_offset_absmax listed (far_scal[1] of them; usually zero -> uniform early exit).
+    const bool far_only_absmax = far_scal != nullptr;
+    if (far_only_absmax && far_scal[1] == 0u) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *colT = smem;                       // [4][32][33]
     float *dyT = smem + 4 * 32 * 33;          // [MB*32][33]
@@ -1182,7 +1199,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-    const int total = g.B * tiles_per_img;
+    const int total = far_only_absmax ? (int)far_scal[1] : g.B * tiles_per_img;
     const int t0 = (int)((int64_t)blockIdx.y * total / nsplit), t1 = (int)((int64_t)(blockIdx.y + 1) * total / nsplit);
     float *myT = colT + wave * 32 * 33;
 
@@ -1192,6 +1209,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     //   stage M: tile ti -- registers -> LDS (transposed), barrier, 16 x MB MFMAs from LDS
     // so the two dependent global-memory latencies are covered by the matrix work of earlier tiles.
     auto tile_coords = [&](int ti, int &b, int &P, bool &pv, int &Pc, int &ho, int &wo) {
+        if (far_only_absmax) ti = far_list[ti];
         b = ti / tiles_per_img;
         const int tile = ti - b * tiles_per_img;
         P = tile * 32 + p;
@@ -1314,7 +1332,7 @@ constexpr int DW_NT = DW_TR * 3 * 64;                 // 384 threads
 
 __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                                 const float *__restrict__ msk, const float *__restrict__ gy,
-                                                                float *__restrict__ gw, Geom g, int tiles_x, int tiles_y,
+                                                                float *__restrict__ part, Geom g, int tiles_x, int tiles_y,
                                                                 int nsplit)
 {
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [DW_IN_FLOATS | DW_DY_FLOATS]
@@ -1360,7 +1378,12 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
 #pragma unroll
         for (int kx = 0; kx < 3; ++kx) {
             const int t = ky * 3 + kx;
+#ifdef DWT_ABL_NOTAP
+            const TapRaw raw = {0.1f * (float)t, 0.2f, 0.5f};
+            (void)off_b; (void)msk_b;
+#else
             const TapRaw raw = load_tap_raw(off_b, msk_b, g, t, Pc);
+#endif
             const float hf = (float)(ho - 1 + ky) + raw.oh, wf_ = (float)(wo - 1 + kx) + raw.ow;
             const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W &&
                             fabsf(raw.oh) < TL_NEAR && fabsf(raw.ow) < TL_NEAR;
@@ -1373,7 +1396,13 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
             wv[kx][2] = lh * (1.f - lw) * m;         wv[kx][3] = lh * lw * m;
         }
 
+#ifndef DWT_ABL_NOBAR
         __syncthreads();                                   // previous tile fully consumed
+#endif
+#ifdef DWT_ABL_NOSTAGE
+        if (ti == t0)
+#endif
+        {
         // ---- stage the window (three batches of three dwordx4 per thread: bounded register use) and the dY tile
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
         typedef float f32x2_ __attribute__((ext_vector_type(2)));
@@ -1423,7 +1452,10 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
                 }
             }
         }
+        }
+#ifndef DWT_ABL_NOBAR
         __syncthreads();
+#endif
 
         const float *wl_ = win + i * DW_PLANE;                 // this lane's channel plane
         const float *dl0 = dyt + i * DW_DYS + row * 32 + h, *dl1 = dl0 + 32 * DW_DYS;
@@ -1433,22 +1465,39 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
             const float d0 = dl0[2 * s], d1 = dl1[2 * s];
 #pragma unroll
             for (int kx = 0; kx < 3; ++kx) {
+#ifdef DWT_ABL_NOSHFL
+                const int pos = posv[kx] + (src & 1);
+                const float q0 = wv[kx][0], q1 = wv[kx][1], q2 = wv[kx][2], q3 = wv[kx][3];
+#else
                 const int pos = __shfl(posv[kx], src);
                 const float q0 = __shfl(wv[kx][0], src), q1 = __shfl(wv[kx][1], src);
                 const float q2 = __shfl(wv[kx][2], src), q3 = __shfl(wv[kx][3], src);
+#endif
                 const float *cp = wl_ + pos;
+#ifdef DWT_ABL_NOGATHER
+                const float val = q0 + q1 * (float)pos + q2 + q3 * (float)s;
+                (void)cp;
+#else
                 const float val = q0 * cp[0] + q1 * cp[1] + q2 * cp[TL_WW] + q3 * cp[TL_WW + 1];
+#endif
+#ifdef DWT_ABL_NOMFMA
+                acc[kx][0][s] += val * d0;
+                acc[kx][1][s] += val * d1;
+#else
                 acc[kx][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(val, d0, acc[kx][0], 0, 0, 0);
                 acc[kx][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(val, d1, acc[kx][1], 0, 0, 0);
+#endif
             }
         }
     }
 
-    // lane holds D[c = (r&3)+8*(r>>2)+4h][o = mb*32 + i] for its three taps.  Flush: the two tile rows are summed in LDS,
-    // laid out like the weight tensor ([o][c][t]: 288 contiguous floats per output channel), and added to global memory
-    // with COALESCED atomics -- strided per-lane atomics cost one cache-line request each (~21 G/s, tools/micro/atomics.hip).
+    // lane holds, per tap, D[c = (r&3)+8*(r>>2)+4h][o = 32 mb + i] in acc[kx][mb][r].  The two tile rows are summed in LDS,
+    // laid out like the weight tensor ([o][c][t]: 288 contiguous floats per output channel), and written as this workgroup's
+    // partial result with plain coalesced stores; dcn_dw_reduce sums the partials.  (Atomics straight into grad_weight cost
+    // 0.11 ms on 64->64: 256 splits contend for the same 36 864 addresses; strided ones one cache-line request per lane.)
     constexpr int STG = DW_CB * 9 + 1;                     // 289: lanes (o) hit distinct banks
     float *stage = lds;                                    // 32 x 289 floats (reuses the window area)
+    float *mine = part + ((size_t)(cb * gridDim.z + zo) * nsplit + blockIdx.y) * (2 * 32 * DW_CB * 9);
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         __syncthreads();
@@ -1470,9 +1519,30 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
         __syncthreads();
         for (int e = tid; e < 32 * DW_CB * 9; e += DW_NT) {
             const int ol = e / (DW_CB * 9), j = e - ol * (DW_CB * 9);
-            const int o = zo * TL_OB + mb * 32 + ol, c = cb * DW_CB + j / 9;
-            if (o < g.Co && c < g.C) atomicAdd(gw + ((size_t)o * g.C + (size_t)cb * DW_CB) * 9 + j, stage[ol * STG + j]);
+            mine[mb * (32 * DW_CB * 9) + e] = stage[ol * STG + j];
         }
+    }
+}
+
+// grad_weight[o][c][t] += sum over the pixel splits of the tiled kernel's partials.  grid.y split-groups each sum a slice
+// of the splits (coalesced over the 288-float rows) and add it to the zero-filled gradient: <= 16 atomics per address.
+__global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict__ gw, Geom g, int ncb, int nzo, int nsplit)
+{
+    constexpr int PER = 2 * 32 * DW_CB * 9;                // floats per partial
+    const int n = ncb * nzo * PER;
+    const int s0 = (int)((int64_t)blockIdx.y * nsplit / gridDim.y), s1 = (int)((int64_t)(blockIdx.y + 1) * nsplit / gridDim.y);
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        const int blk = idx / PER, e = idx - blk * PER;
+        const int cb = blk / nzo, zo = blk - cb * nzo;
+        const int mb = e / (32 * DW_CB * 9), e2 = e - mb * (32 * DW_CB * 9);
+        const int ol = e2 / (DW_CB * 9), j = e2 - ol * (DW_CB * 9);
+        const int o = zo * TL_OB + mb * 32 + ol, c = cb * DW_CB + j / 9;
+        if (o >= g.Co || c >= g.C) continue;
+        const float *src = part + (size_t)blk * nsplit * PER + e;
+        float sum = 0.f;
+#pragma unroll 8
+        for (int sp = s0; sp < s1; ++sp) sum += src[(size_t)sp * PER];
+        atomicAdd(gw + ((size_t)o * g.C + (size_t)cb * DW_CB) * 9 + j, sum);
     }
 }
 
@@ -1490,14 +1560,23 @@ inline int pick_mb(int nb, int tiles_total)
 
 extern "C" {
 
+// partial grad_weight blocks of the tiled kernel: (channel blocks x output slices x pixel splits) x [64 o][32 c][9]
+static size_t dw_partial_floats(int Cin, int Cout)
+{
+    const size_t nb = (size_t)((Cin + DW_CB - 1) / DW_CB) * ((Cout + TL_OB - 1) / TL_OB);
+    return (nb > 512 ? nb : 512) * (size_t)(2 * 32 * DW_CB * 9);
+}
+
 size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
                                   int pw, int dh, int dw, int dg)
 {
     Geom g;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return 0;
-    // [Wf | Wb | absmax word (256 B) | inverse lists: cnt, idx, w]
+    // [Wf | Wb | scalars (256 B) | inverse lists: cnt, idx, w | far-tile flags | far-tile list]
     const size_t cells = (size_t)B * dg * g.KK * H * W;
-    return (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256;
+    const size_t ntile = (size_t)B * ((g.HoWo + 31) / 32);
+    return (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256 +
+           ((ntile + 255) / 256 * 256) + (ntile + 63) / 64 * 64 * sizeof(int) + dw_partial_floats(Cin, Cout) * sizeof(float);
 }
 
 int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, const float *bias,
@@ -1620,6 +1699,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     inv.cnt = (unsigned char *)absmax + 256;
     inv.idx = (int *)(inv.cnt + (cells + 255) / 256 * 256);
     inv.w = (float *)(inv.idx + cells * INV_CAP);
+    const size_t ntile = (size_t)B * ((g.HoWo + 31) / 32);
+    unsigned char *far_flag = (unsigned char *)(((uintptr_t)(inv.w + cells * INV_CAP) + 255) / 256 * 256);
+    int *far_list = (int *)(far_flag + (ntile + 255) / 256 * 256);
+    float *dw_part = (float *)(far_list + (ntile + 63) / 64 * 64);
 
     hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
                        0, stream, weight, wf, wb, g);
@@ -1630,7 +1713,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     int nsplit = 1;
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
 
-    hipMemsetAsync(absmax, 0, sizeof(unsigned), stream);
+    hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), stream);
+    hipMemsetAsync(far_flag, 0, (ntile + 3) / 4 * 4, stream);
     hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)Cout * Cin * g.KK, stream);
     hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)Cout, stream);
     if (nsplit > 1) {
@@ -1643,7 +1727,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const int64_t noff = (int64_t)B * dg * 2 * g.KK * g.HoWo;
         int gsz = (int)((noff + 1023) / 1024);
         if (gsz > 1024) gsz = 1024;
-        hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax);
+        hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
+                           (g.HoWo + 31) / 32, far_flag, far_list);
         const int HWin = H * W;
         hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         const int in_tiles = (HWin + 31) / 32;
@@ -1694,7 +1779,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (S < 1) S = 1;
         if (S > total) S = total;
         hipLaunchKernelGGL(dcn_bwd_weight_tile_f32, dim3(ncb, S, nzo), dim3(DW_NT), ldsb, stream, input, offset, mask, grad_output,
-                           grad_weight, g, tiles_x, tiles_y, S);
+                           dw_part, g, tiles_x, tiles_y, S);
+        const int nred = ncb * nzo * 2 * 32 * DW_CB * 9;
+        const int rgroups = S >= 16 ? 16 : S;
+        hipLaunchKernelGGL(dcn_dw_reduce, dim3((nred + 255) / 256, rgroups), dim3(256), 0, stream, dw_part, grad_weight, g, ncb, nzo, S);
         dw_tiled = true;
     }
 #endif
@@ -1711,7 +1799,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const size_t lds = (size_t)(4 * 32 * 33 + mb * 32 * 33) * sizeof(float);
 #define DCD_LAUNCH_BW(MBV)                                                                                        \
     hipLaunchKernelGGL(dcn_bwd_weight_f32<MBV>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, \
-                       tiles, S, dw_tiled ? (const unsigned *)absmax : (const unsigned *)nullptr)
+                       tiles, S, dw_tiled ? (const unsigned *)absmax : (const unsigned *)nullptr, (const int *)far_list)
         if (mb == 8) DCD_LAUNCH_BW(8);
         else if (mb == 4) DCD_LAUNCH_BW(4);
         else if (mb == 2) DCD_LAUNCH_BW(2);
