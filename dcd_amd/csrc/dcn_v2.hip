@@ -1031,13 +1031,25 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                                                         const float *__restrict__ msk, const float *__restrict__ wb,
                                                         const float *__restrict__ gy, float *__restrict__ gin,
                                                         float *__restrict__ goff, float *__restrict__ gmsk,
-                                                        float *__restrict__ gbias, Geom g, int nsplit, InvLists inv)
+                                                        float *__restrict__ gbias, Geom g, int nsplit, InvLists inv,
+                                                        const unsigned *__restrict__ far_scal, const int *__restrict__ far_list)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     int bx = blockIdx.x, b = blockIdx.y;
     xcd_remap(bx, b);
-    const int tile = bx * 4 + wave;
+    int tile = bx * 4 + wave;
+    // far-only mode (far_scal != nullptr): the tiled kernel produced grad_offset / grad_mask of every sample displaced by
+    // less than TL_NEAR; this launch visits the listed tiles and OVERWRITES the entries of the remaining samples only.
+    const bool far_mode = far_scal != nullptr;
+    if (far_mode) {
+        const int tiles_per_img = (g.HoWo + 31) / 32;
+        const int L = (b * (int)gridDim.x + bx) * 4 + wave;
+        if (L >= (int)far_scal[1]) return;
+        const int tid_ = far_list[L];
+        b = tid_ / tiles_per_img;
+        tile = tid_ - b * tiles_per_img;
+    }
     if (tile * 32 >= g.HoWo) return;
     const int z = blockIdx.z;
     const float rlim = (float)inv_radius(inv.absmax_bits);
@@ -1079,9 +1091,11 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
             // grad_input normally comes from dcn_bwd_input_f32; this kernel scatters only what the inverse lists do
             // not cover: samples farther than the search radius, and corners that fell into an overflowed cell.
             const bool far = !(fabsf(s.oh) <= rlim && fabsf(s.ow) <= rlim);
+            const bool mine = !far_mode || !(fabsf(s.oh) < TL_NEAR && fabsf(s.ow) < TL_NEAR);   // sample owned by this launch
+            if (far_mode && !__any(mine)) continue;
             const unsigned char *cnt_p = inv.cnt + ((size_t)b * S_all + seg) * HW;
-            const bool a1 = s.c1 && (far || cnt_p[s.i1] == INV_OVERFLOW), a2 = s.c2 && (far || cnt_p[s.i2] == INV_OVERFLOW);
-            const bool a3 = s.c3 && (far || cnt_p[s.i3] == INV_OVERFLOW), a4 = s.c4 && (far || cnt_p[s.i4] == INV_OVERFLOW);
+            const bool a1 = mine && s.c1 && (far || cnt_p[s.i1] == INV_OVERFLOW), a2 = mine && s.c2 && (far || cnt_p[s.i2] == INV_OVERFLOW);
+            const bool a3 = mine && s.c3 && (far || cnt_p[s.i3] == INV_OVERFLOW), a4 = mine && s.c4 && (far || cnt_p[s.i4] == INV_OVERFLOW);
             for (int blk = blk0; blk < blk1; ++blk) {
                 f32x16 acc;
 #pragma unroll
@@ -1142,7 +1156,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
             s_m += __shfl_xor(s_m, 32);
             s_h += __shfl_xor(s_h, 32);
             s_w += __shfl_xor(s_w, 32);
-            if (h == 0 && pv) {
+            if (h == 0 && pv && mine) {
                 if (nsplit == 1) {
                     goff_b[(size_t)(2 * seg) * g.HoWo + P] = s_h;
                     goff_b[(size_t)(2 * seg + 1) * g.HoWo + P] = s_w;
@@ -1151,6 +1165,207 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                     atomicAdd(goff_b + (size_t)(2 * seg) * g.HoWo + P, s_h);
                     atomicAdd(goff_b + (size_t)(2 * seg + 1) * g.HoWo + P, s_w);
                     atomicAdd(gmsk_b + (size_t)seg * g.HoWo + P, s_m);
+                }
+            }
+        }
+    }
+}
+
+// ---------------------------------------------------------------------------------------------
+// Backward w.r.t. offset / mask, workgroup-tiled (3x3 / stride 1 / pad 1 / dil 1 / one group).
+// Same contraction as dcn_bwd_data_f32 (dcol = W^T dY on the matrix pipe, dY held in registers), but the 4 x 16 bilinear
+// corner values each lane needs per (tap, 32-channel block) come from the LDS window of its workgroup's 4 x 32-pixel tile
+// (two ds_read2_b32 per channel) instead of 64 jittered global gathers.  Near samples only (|offset| < TL_NEAR): the generic
+// kernel's far-only mode overwrites grad_offset / grad_mask of the far ones in the listed tiles.  The rare grad_input
+// atomics for cells whose inverse list overflowed are issued from here exactly as in the generic kernel.
+// grid = (tiles, B, nsplit); block = 256 (wave = tile row).
+// ---------------------------------------------------------------------------------------------
+constexpr int BD_TR = 4;
+constexpr int BD_WH = BD_TR + 8;                      // 12 window rows
+constexpr int BD_PLANE = BD_WH * TL_WW + 8;           // 488: 4 planes apart (the two lane halves) = 32 banks apart
+constexpr int BD_CB = 32;
+
+template <int NS>
+__global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
+                                                                   const float *__restrict__ msk, const float *__restrict__ wb,
+                                                                   const float *__restrict__ gy, float *__restrict__ gin,
+                                                                   float *__restrict__ goff, float *__restrict__ gmsk, Geom g,
+                                                                   int tiles_x, int nsplit, InvLists inv)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [32][BD_PLANE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int r0 = ty * BD_TR, c0 = tx * 32;
+    const int ho = r0 + wave, wo = c0 + p;
+    const bool pv = ho < g.Ho && wo < g.Wo;
+    const int P = pv ? ho * g.Wo + wo : 0;
+    const int Y0 = r0 - 4, X0 = c0 - 4;
+    const int HW = g.H * g.W;
+    const int z = blockIdx.z;
+
+    const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
+    float dy[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        const int o = 2 * s + h;
+        dy[s] = (pv && o < g.Co) ? gy_b[(size_t)o * g.HoWo + P] : 0.f;
+    }
+    const float *in_b = in + (size_t)b * g.C * HW;
+    float *gin_b = gin + (size_t)b * g.C * HW;
+    const float *off_b = off + (size_t)b * 18 * g.HoWo;
+    const float *msk_b = msk + (size_t)b * 9 * g.HoWo;
+    float *goff_b = goff + (size_t)b * 18 * g.HoWo;
+    float *gmsk_b = gmsk + (size_t)b * 9 * g.HoWo;
+
+    // one 32-channel block per workgroup (grid.z = blocks): the tap loop stays rolled (bounded registers) and each tap's
+    // sums leave through atomics on the zero-filled gradients when there is more than one block
+    const int blk0 = z, blk1 = z + 1;
+
+    constexpr int NIN = BD_CB * BD_WH * 10;                   // window dwordx4 per block (3840)
+    constexpr int KIN = NIN / (BD_TR * 64);                   // 15 per thread
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int blk = blk0; blk < blk1; ++blk) {
+        const float *in_c = in_b + (size_t)blk * BD_CB * HW;
+        const int cleft = g.cpg - blk * BD_CB;
+        __syncthreads();                                       // previous block fully consumed
+#ifdef BDT_ABL_NOSTAGE
+        if (blk < 0)
+#endif
+#pragma unroll 1
+        for (int k0 = 0; k0 < KIN; k0 += 5) {
+            f32x4 rin[5];
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = tid + BD_TR * 64 * (k0 + k);
+                const int ch = e / (BD_WH * 10), rm = e - ch * (BD_WH * 10);
+                const int wr = rm / 10, q = rm - wr * 10;
+                const int y = Y0 + wr, x = X0 + 4 * q;
+                rin[k] = zero4;
+                if (ch < cleft && y >= 0 && y < g.H && x >= 0 && x < g.W)
+                    rin[k] = *reinterpret_cast<const f32x4 *>(in_c + (size_t)ch * HW + y * g.W + x);
+            }
+#pragma unroll
+            for (int k = 0; k < 5; ++k) {
+                const int e = tid + BD_TR * 64 * (k0 + k);
+                const int ch = e / (BD_WH * 10), rm = e - ch * (BD_WH * 10);
+                *reinterpret_cast<f32x4 *>(lds + ch * BD_PLANE + rm * 4) = rin[k];
+            }
+        }
+        __syncthreads();
+
+        float wcur[NS];
+        {
+            const float *wp0 = wb + (size_t)blk * 32 + p + (size_t)h * g.Kp;
+#pragma unroll
+            for (int k = 0; k < NS; ++k) wcur[k] = wp0[(size_t)(2 * k) * g.Kp];
+        }
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            // sampling state of (pixel, tap): recomputed per channel block (3 loads + ~40 VALU against 2*NS MFMAs)
+            const TapRaw raw = load_tap_raw(off_b, msk_b, g, t, P);
+            const int ky = t / 3, kx = t - ky * 3;
+            const float hf = (float)(ho - 1 + ky) + raw.oh, wf_ = (float)(wo - 1 + kx) + raw.ow;
+            const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W &&
+                            fabsf(raw.oh) < TL_NEAR && fabsf(raw.ow) < TL_NEAR;
+            const float hlf = floorf(hf), wlf = floorf(wf_);
+            const int hl = (int)hlf, wl = (int)wlf;
+            const int pos = sv ? (hl - Y0) * TL_WW + (wl - X0) : 0;
+            const float lh = sv ? hf - hlf : 0.f, lw = sv ? wf_ - wlf : 0.f;
+            const float hh = 1.f - lh, hw = 1.f - lw;
+            const float m = sv ? raw.m : 0.f;
+            const float w1 = sv ? hh * hw : 0.f, w2 = sv ? hh * lw : 0.f, w3 = sv ? lh * hw : 0.f, w4 = sv ? lh * lw : 0.f;
+            // corners whose cell list overflowed get their grad_input by atomics here (the list kernel skips them)
+            const bool c1 = sv && hl >= 0 && wl >= 0, c2 = sv && hl >= 0 && wl + 1 <= g.W - 1;
+            const bool c3 = sv && hl + 1 <= g.H - 1 && wl >= 0, c4 = sv && hl + 1 <= g.H - 1 && wl + 1 <= g.W - 1;
+            const int i1 = c1 ? hl * g.W + wl : 0, i2 = c2 ? hl * g.W + wl + 1 : 0;
+            const int i3 = c3 ? (hl + 1) * g.W + wl : 0, i4 = c4 ? (hl + 1) * g.W + wl + 1 : 0;
+            const unsigned char *cnt_p = inv.cnt + ((size_t)b * 9 + t) * HW;
+#ifdef BDT_ABL_NOCNT
+            const bool a1 = false, a2 = false, a3 = false, a4 = false; (void)cnt_p;
+#else
+            const bool a1 = c1 && cnt_p[i1] == INV_OVERFLOW, a2 = c2 && cnt_p[i2] == INV_OVERFLOW;
+            const bool a3 = c3 && cnt_p[i3] == INV_OVERFLOW, a4 = c4 && cnt_p[i4] == INV_OVERFLOW;
+#endif
+
+            // dcol block on the matrix pipe: the A operands (weights of this tap) were fetched during the previous tap, the
+            // next tap's are requested now; two accumulator chains keep dependent MFMAs from serialising the wave
+            float wnext[NS];
+            if (t + 1 < 9) {
+                const float *wpn = wb + (size_t)(t + 1) * g.cpgp + blk * 32 + p + (size_t)h * g.Kp;
+#pragma unroll
+                for (int k = 0; k < NS; ++k) wnext[k] = wpn[(size_t)(2 * k) * g.Kp];
+            }
+            f32x16 acc, acc2;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
+#ifndef BDT_ABL_NOMFMA
+#pragma unroll
+            for (int k = 0; k < NS; k += 2) {
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[k], dy[k], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[k + 1], dy[k + 1], acc2, 0, 0, 0);
+            }
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
+#else
+            acc[0] = wcur[0] + dy[t]; acc[5] = dy[t + 1];
+#endif
+            if (t + 1 < 9) {
+#pragma unroll
+                for (int k = 0; k < NS; ++k) wcur[k] = wnext[k];
+            }
+
+            const float *cp0 = lds + pos + 4 * h * BD_PLANE;
+            float s_m = 0.f, s_h = 0.f, s_w = 0.f;
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const float *cp = cp0 + ((r & 3) + 8 * (r >> 2)) * BD_PLANE;
+#ifdef BDT_ABL_NOCORNER
+                const float v1 = w1 + (float)r, v2 = w2, v3 = w3, v4 = w4; (void)cp;
+#else
+                const float v1 = cp[0], v2 = cp[1], v3 = cp[TL_WW], v4 = cp[TL_WW + 1];
+#endif
+                const float d = acc[r];
+                s_m += d * (w1 * v1 + w2 * v2 + w3 * v3 + w4 * v4);
+                const float dm = d * m;
+                s_h += dm * (hw * (v3 - v1) + lw * (v4 - v2));
+                s_w += dm * (hh * (v2 - v1) + lh * (v4 - v3));
+            }
+            s_m += __shfl_xor(s_m, 32);
+            s_h += __shfl_xor(s_h, 32);
+            s_w += __shfl_xor(s_w, 32);
+#ifdef BDT_ABL_NOATOM
+            if (h == 0 && pv && s_m == 123.456f) {
+#else
+            if (h == 0 && pv) {
+#endif
+                if (nsplit == 1) {
+                    goff_b[(size_t)(2 * t) * g.HoWo + P] = s_h;
+                    goff_b[(size_t)(2 * t + 1) * g.HoWo + P] = s_w;
+                    gmsk_b[(size_t)t * g.HoWo + P] = s_m;
+                } else {
+                    atomicAdd(goff_b + (size_t)(2 * t) * g.HoWo + P, s_h);
+                    atomicAdd(goff_b + (size_t)(2 * t + 1) * g.HoWo + P, s_w);
+                    atomicAdd(gmsk_b + (size_t)t * g.HoWo + P, s_m);
+                }
+            }
+            if (__any(a1 | a2 | a3 | a4)) {
+                float *gin_g = gin_b + (size_t)blk * BD_CB * HW;
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int cc = (r & 3) + 8 * (r >> 2) + 4 * h;
+                    if (cc < cleft) {
+                        const float dm = acc[r] * m;
+                        float *gp = gin_g + (size_t)cc * HW;
+                        if (a1) atomicAdd(gp + i1, dm * w1);
+                        if (a2) atomicAdd(gp + i2, dm * w2);
+                        if (a3) atomicAdd(gp + i3, dm * w3);
+                        if (a4) atomicAdd(gp + i4, dm * w4);
+                    }
                 }
             }
         }
@@ -1747,12 +1962,41 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
     }
     // (4) grad_offset / grad_mask (+ atomic fallback for what the lists do not cover)
+    bool bd_tiled = false;
+#ifndef DCN_NO_BWD_TILE
+    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
+        H >= 8 && W >= 32 && g.Cop == 64) {      // Cout 128 (64 dY registers per lane) spills at two waves per SIMD: generic kernel
+        static bool attr_set = false;
+        const size_t ldsb = (size_t)BD_CB * BD_PLANE * sizeof(float);
+        if (!attr_set) {
+            if (hipFuncSetAttribute((const void *)dcn_bwd_data_tile_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess ||
+                hipFuncSetAttribute((const void *)dcn_bwd_data_tile_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+                return DCD_ERR_LAUNCH;
+            attr_set = true;
+        }
+        const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + BD_TR - 1) / BD_TR;
+        const int nsp = nblk;                 // one 32-channel block per workgroup
+        if (nsp > 1 && nsplit == 1) {        // the tiled launch accumulates with atomics when there are several blocks
+            hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * 18 * g.HoWo, stream);
+            hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * 9 * g.HoWo, stream);
+        }
+        dim3 gridt(tiles_x * tiles_y, B, nsp), blockt(BD_TR * 64);
+        if (g.Cop == 64)
+            hipLaunchKernelGGL(dcn_bwd_data_tile_f32<32>, gridt, blockt, ldsb, stream, input, offset, mask, wb, grad_output, grad_input,
+                               grad_offset, grad_mask, g, tiles_x, nsp, inv);
+        else
+            hipLaunchKernelGGL(dcn_bwd_data_tile_f32<64>, gridt, blockt, ldsb, stream, input, offset, mask, wb, grad_output, grad_input,
+                               grad_offset, grad_mask, g, tiles_x, nsp, inv);
+        bd_tiled = true;
+    }
+#endif
     {
         dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
         const int ns = g.Cop / 2;
 #define DCD_LAUNCH_BD(NS)                                                                                          \
     hipLaunchKernelGGL(dcn_bwd_data_f32<NS>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, \
-                       grad_offset, grad_mask, grad_bias, g, nsplit, inv)
+                       grad_offset, grad_mask, grad_bias, g, nsplit, inv, bd_tiled ? (const unsigned *)absmax : (const unsigned *)nullptr, \
+                       (const int *)far_list)
         if (ns == 16) DCD_LAUNCH_BD(16);
         else if (ns == 32) DCD_LAUNCH_BD(32);
         else if (ns == 64) DCD_LAUNCH_BD(64);
