@@ -31,6 +31,8 @@ SIGNATURES = {
     "dcd_poi_gather": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "dcd_poi_scatter_add": (c_int, [c_void_p, c_void_p, c_void_p] + [c_int] * 5 + [c_void_p]),
     "dcd_iou3d": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_void_p]),
+    "dcd_conv3x3_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dcd_conv3x3": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t]),
     "dcd_bn_workspace_bytes": (c_size_t, [c_int]),
     "dcd_bn_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),
     "dcd_bn_train_apply": (c_int, [c_void_p] * 6 + [c_double] + [c_void_p] * 3 + [c_float, c_float, c_int] + [c_void_p] * 3

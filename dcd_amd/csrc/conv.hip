@@ -1,0 +1,283 @@
+// conv.hip -- 3x3 / stride 1 / pad 1 convolution (forward and backward-data) for gfx950: Winograd F(2x2, 3x3) on the
+// fp32 matrix pipe.
+//
+// Where it sits: the 3x3 convolutions of DLA-34's BasicBlocks (DGDE/model/backbone/dla_dcn.py:71-101) and of the eleven
+// CenterNet head trunks (DGDE/model/head/detector_predictor.py:52-60,112-120) are 45 % of the train step's FLOPs.  The
+// stock path (MIOpen's fp32 Winograd, miopenSp3AsmConv f2x3) runs them on the vector ALUs at ~97 TFLOP/s effective; the
+// same algorithm on v_mfma_f32_32x32x2_f32 has a 2.25 x 157 TFLOP/s ceiling.
+//
+// Algorithm (Lavin & Gray): Y = A^T [ sum_c (G g G^T) . (B^T d B) ] A per 2x2 output tile, 16 multiplies per 4 outputs.
+//   * One workgroup = 8 waves = 2 tile groups x 4 transform rows (xi); it owns an 8 x 32 pixel region (64 tiles) and 64
+//     output channels.  Lane = (tile l&31, channel parity l>>5): the lane computes the transformed input value
+//     V[xi][nu][c][tile] = +-d[r1][c1] +- d[r1][c2] +- d[r2][c1] +- d[r2][c2] straight from the raw input window in LDS
+//     (two ds_read2_b32, three adds) -- that value IS its MFMA B operand, so V is never materialised.
+//   * Per chunk of 8 input channels the 10 x 40 window and the transformed-weight slab U[16][64][8] are staged in LDS,
+//     double-buffered through registers (one barrier per chunk), exactly like the DCN forward tile kernel.
+//   * A wave accumulates M[xi][nu] for its four nu (4 x 2 x 16 accumulators); the output transform is linear, so the
+//     nu-reduction happens in registers and the xi-reduction through LDS once, after the channel loop.
+// Layout notes: window row stride 48 and plane stride 481 (odd) make the stride-2 tile addressing conflict free: the 16
+// tile columns hit 16 even (or odd) banks, the second tile row lands 32 banks further, the other lane half (next
+// channel) on the opposite parity.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dcd_hip.h"
+
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+namespace {
+
+constexpr int WN_CH = 8;                          // input channels per chunk
+constexpr int WN_ROWS = 10;                       // window rows  r0-1 .. r0+8
+constexpr int WN_RS = 48;                         // window row stride (40 staged columns c0-4 .. c0+35)
+constexpr int WN_PLANE = WN_ROWS * WN_RS + 1;     // 481
+constexpr int WN_IN = WN_CH * WN_PLANE;           // 3848 floats
+constexpr int WN_KS = 64;                         // output channels per workgroup
+constexpr int WN_U = 16 * WN_KS * WN_CH;          // 8192 floats: [pos][k][h][4 steps]
+constexpr int WN_BUF = WN_IN + WN_U;              // 12040 floats per buffer
+constexpr int WN_NT = 512;
+
+// Workgroups are dealt to the 8 XCDs round-robin: walk contiguous runs of regions per XCD (L2 locality of the halos).
+__device__ __forceinline__ void xcd_remap(int &bx, int &by)
+{
+    const int gx = gridDim.x, NT = gx * gridDim.y;
+    const int L = bx + gx * by;
+    const int xc = L & 7, slot = L >> 3;
+    const int q = NT >> 3, r = NT & 7;
+    const int Lp = (xc < r ? xc * (q + 1) : r * (q + 1) + (xc - r) * q) + slot;
+    by = Lp / gx;
+    bx = Lp - by * gx;
+}
+
+// U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
+// ul[z][chunk][pos = 4 xi + nu][kk (64)][h (2)][s (4)] for output channel z*64+kk and contraction channel chunk*8 + 2s + h.
+// mode 0: forward        (contraction over Cin:  g = w[k][c][a][b])
+// mode 1: backward-data  (contraction over Cout: g = w[c][k][2-a][2-b], i.e. output channel = input channel of w)
+__global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz)
+{
+    const int n = nz * nchunk * 16 * WN_KS * WN_CH / 16;          // one thread per (z, chunk, kk, h, s): writes 16 positions
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int s = r & 3; r >>= 2;
+        const int h = r & 1; r >>= 1;
+        const int kk = r % WN_KS; r /= WN_KS;
+        const int ck = r % nchunk, z = r / nchunk;
+        const int k = z * WN_KS + kk, c = ck * WN_CH + 2 * s + h;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+                if (k < Kk && c < Cc)
+                    v = mode == 0 ? w[(((size_t)k * Cc + c) * 3 + a) * 3 + b] : w[(((size_t)c * Kk + k) * 3 + (2 - a)) * 3 + (2 - b)];
+                g[a][b] = v;
+            }
+        float t[4][3];                       // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]),
+                        u3 = t[xi][2];
+            const float u[4] = {u0, u1, u2, u3};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * WN_KS + kk) * 2 + h) * 4 + s] = u[nu];
+        }
+    }
+}
+
+// grid = (regions, B, K/64); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
+__global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restrict__ x, const float *__restrict__ ul,
+                                                          float *__restrict__ y, int Cc, int H, int W, int Kk, int tiles_x,
+                                                          int nchunk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x WN_BUF (epilogue: 8 x 32 x 64 exchange)
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int xi = wave & 3, tg = wave >> 2;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int r0 = ty * 8, c0 = tx * 32;
+    const int z = blockIdx.z;
+    const int HW = H * W;
+    const int tcol = p & 15, trow = p >> 4;
+
+    // B^T row pair and signs of this wave's xi:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
+    const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
+    const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
+    const int lanebase = (4 * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
+    const int base1 = lanebase + ra * WN_RS, base2 = lanebase + rb * WN_RS;
+
+    const float *x_b = x + (size_t)b * Cc * HW;
+    const float *ul_z = ul + (size_t)z * nchunk * WN_U;
+
+    // ---- staging map (chunk invariant): window 8 ch x 10 rows x 10 dwordx4 = 800 items; weight slab 2048 dwordx4
+    constexpr int KIN = (WN_CH * WN_ROWS * 10 + WN_NT - 1) / WN_NT;      // 2
+    constexpr int KW = WN_U / 4 / WN_NT;                                 // 4
+    int sg[KIN], sl[KIN];
+    bool sv_[KIN];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+        const int e = tid + WN_NT * k;
+        const int ch = e / (WN_ROWS * 10), rem = e - ch * (WN_ROWS * 10);
+        const int row = rem / 10, q = rem - row * 10;
+        const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * q;
+        sv_[k] = e < WN_CH * WN_ROWS * 10;
+        sg[k] = (sv_[k] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ch * HW + yy * W + xx : -1;
+        sl[k] = ch * WN_PLANE + row * WN_RS + 4 * q;
+    }
+    f32x4 rin[KIN], rw[KW];
+    auto issue = [&](int ck) {
+        const float *src = x_b + (size_t)ck * WN_CH * HW;
+        const int cleft = Cc - ck * WN_CH;
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            rin[k] = zero4;
+            if (sv_[k] && sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * 10) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
+        }
+        const float *wsrc = ul_z + (size_t)ck * WN_U;
+#pragma unroll
+        for (int k = 0; k < KW; ++k) rw[k] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * (tid + WN_NT * k));
+    };
+    auto commit = [&](float *buf) {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k)
+            if (sv_[k]) {
+                float *d = buf + sl[k];                       // odd plane stride: dword stores
+                d[0] = rin[k].x; d[1] = rin[k].y; d[2] = rin[k].z; d[3] = rin[k].w;
+            }
+#pragma unroll
+        for (int k = 0; k < KW; ++k) *reinterpret_cast<f32x4 *>(buf + WN_IN + 4 * (tid + WN_NT * k)) = rw[k];
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int mb = 0; mb < 2; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.f;
+
+    issue(0);
+    commit(lds);
+    __syncthreads();
+
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *buf = lds + (ck & 1) * WN_BUF;
+        if (ck + 1 < nchunk) issue(ck + 1);
+        const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
+        const float *cp1 = buf + base1, *cp2 = buf + base2;
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            // B column pair and signs:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
+            constexpr int CA[4] = {0, 1, 1, 1}, CB[4] = {2, 2, 2, 3};
+            constexpr float TA[4] = {1.f, 1.f, -1.f, 1.f}, TB[4] = {-1.f, 1.f, 1.f, -1.f};
+            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
+            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) {
+                const float *q1 = cp1 + 2 * s * WN_PLANE, *q2 = cp2 + 2 * s * WN_PLANE;
+                const float u1 = TA[nu] * q1[CA[nu]] + TB[nu] * q1[CB[nu]];
+                const float u2 = TA[nu] * q2[CA[nu]] + TB[nu] * q2[CB[nu]];
+                const float val = sa * u1 + sb * u2;
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], val, acc[nu][0], 0, 0, 0);
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], val, acc[nu][1], 0, 0, 0);
+            }
+        }
+        if (ck + 1 < nchunk) commit(lds + ((ck + 1) & 1) * WN_BUF);
+        __syncthreads();
+    }
+
+    // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]]: over nu in registers, over xi through LDS.
+    // ex[wave][j*16 + r][lane]; per mb round 8 x 32 x 64 floats = 64 KB.
+    float *ex = lds;
+    float *y_b = y + (size_t)b * Kk * HW;
+#pragma unroll
+    for (int mb = 0; mb < 2; ++mb) {
+        float *mine = ex + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine[r * 64] = acc[0][mb][r] + acc[1][mb][r] + acc[2][mb][r];             // j = 0
+            mine[(16 + r) * 64] = acc[1][mb][r] - acc[2][mb][r] - acc[3][mb][r];      // j = 1
+        }
+        __syncthreads();
+        if (xi == 0 || xi == 3) {
+            // xi == 0 produces output row i = 0 (T0 + T1 + T2), xi == 3 row i = 1 (T1 - T2 - T3)
+            const float *t1 = ex + (size_t)(tg * 4 + 1) * 32 * 64 + lane, *t2 = ex + (size_t)(tg * 4 + 2) * 32 * 64 + lane;
+            const float *t0 = ex + (size_t)wave * 32 * 64 + lane;
+            const int i = xi == 0 ? 0 : 1;
+            const int orow = r0 + 4 * tg + 2 * trow + i, ocol = c0 + 2 * tcol;
+            if (orow < H && ocol < W) {
+#pragma unroll
+                for (int r = 0; r < 16; ++r) {
+                    const int k = z * WN_KS + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                    float o0, o1;
+                    if (i == 0) {
+                        o0 = t0[r * 64] + t1[r * 64] + t2[r * 64];
+                        o1 = t0[(16 + r) * 64] + t1[(16 + r) * 64] + t2[(16 + r) * 64];
+                    } else {
+                        o0 = t1[r * 64] - t2[r * 64] - t0[r * 64];
+                        o1 = t1[(16 + r) * 64] - t2[(16 + r) * 64] - t0[(16 + r) * 64];
+                    }
+                    if (k < Kk) *reinterpret_cast<f32x2 *>(y_b + (size_t)k * HW + (size_t)orow * W + ocol) = f32x2{o0, o1};
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+}  // namespace
+
+extern "C" {
+
+size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    const int cmax = Cin > Cout ? Cin : Cout;
+    const size_t nchunk = (size_t)(cmax + WN_CH - 1) / WN_CH, nz = (size_t)(cmax + WN_KS - 1) / WN_KS;
+    return nchunk * nz * WN_U * sizeof(float);
+}
+
+int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
+                int Cout, int backward_data, void *workspace, size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!input || !weight || !output || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    // contraction channels Cc and produced channels Kk of this call
+    const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
+    const int nchunk = (Cc + WN_CH - 1) / WN_CH, nz = (Kk + WN_KS - 1) / WN_KS;
+    if (workspace_bytes < (size_t)nchunk * nz * WN_U * sizeof(float)) return DCD_ERR_WORKSPACE;
+    float *ul = (float *)workspace;
+    static bool attr_set = false;
+    const size_t ldsb = (size_t)2 * WN_BUF * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)wino_conv3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+            return DCD_ERR_LAUNCH;
+        attr_set = true;
+    }
+    const int nprep = nz * nchunk * WN_KS * WN_CH;
+    // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
+    hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
+                       ul, Cc, Kk, backward_data ? 1 : 0, nchunk, nz);
+    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
+    hipLaunchKernelGGL(wino_conv3x3_f32, dim3(tiles_x * tiles_y, B, nz), dim3(WN_NT), ldsb, stream, input, ul, output, Cc, H, W, Kk,
+                       tiles_x, nchunk);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+}  // extern "C"

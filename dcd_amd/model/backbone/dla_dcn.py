@@ -14,6 +14,7 @@ from torch import nn
 
 from .DCNv2.dcn_v2 import DCN
 from dcd_amd.model.layers.norm import BatchNorm2d
+from dcd_amd.model.layers.conv import Conv2d
 
 BN_MOMENTUM = 0.1
 
@@ -35,10 +36,10 @@ class BasicBlock(nn.Module):
 
     def __init__(self, inplanes, planes, stride=1, dilation=1):
         super().__init__()
-        self.conv1 = nn.Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, bias=False, dilation=dilation)
+        self.conv1 = Conv2d(inplanes, planes, 3, stride=stride, padding=dilation, bias=False, dilation=dilation)
         self.bn1 = _bn(planes, relu=True)
         self.relu = nn.ReLU(inplace=True)       # kept for structural parity; executed inside bn1 / bn2
-        self.conv2 = nn.Conv2d(planes, planes, 3, stride=1, padding=dilation, bias=False, dilation=dilation)
+        self.conv2 = Conv2d(planes, planes, 3, stride=1, padding=dilation, bias=False, dilation=dilation)
         self.bn2 = _bn(planes, relu=True)
         self.stride = stride
 

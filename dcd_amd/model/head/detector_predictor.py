@@ -16,6 +16,7 @@ from dcd_amd.model.layers.utils import sigmoid_hm
 from dcd_amd.model.make_layers import group_norm, _fill_fc_weights
 from dcd_amd.model.backbone.DCNv2.dcn_v2 import DCN
 from dcd_amd.model.layers.norm import BatchNorm2d
+from dcd_amd.model.layers.conv import Conv2d
 
 
 @registry.PREDICTOR.register("Base_Predictor")
@@ -55,7 +56,7 @@ class _predictor(nn.Module):
         if self.deeper_head:
             self.cls_head_pre = self._deep_stem()
         self.class_head = nn.Sequential(
-            nn.Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
+            Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
             self.norm_func(self.head_conv), self._get_active_func(),
             nn.Conv2d(self.head_conv, classes, kernel_size=1, padding=0, bias=True))
         self.class_head[-1].bias.data.fill_(- np.log(1 / cfg.MODEL.HEAD.INIT_P - 1))
@@ -67,7 +68,7 @@ class _predictor(nn.Module):
         self.reg_heads = nn.ModuleList()
         for idx, keys in enumerate(self.regression_head_cfg):
             self.reg_features.append(nn.Sequential(
-                nn.Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
+                Conv2d(trunk_in, self.head_conv, kernel_size=3, padding=1, bias=False),
                 self.norm_func(self.head_conv), self._get_active_func()))
             heads = nn.ModuleList()
             for key_index, key in enumerate(keys):
@@ -110,7 +111,7 @@ class _predictor(nn.Module):
     def _deep_stem(self):
         """Optional conv + DCN stem used when MODEL.HEAD.DEEPER_HEAD is set (detector_predictor.py:134-151)."""
         return nn.Sequential(
-            nn.Conv2d(self.in_channels, self.head_conv, kernel_size=3, padding=1, bias=False),
+            Conv2d(self.in_channels, self.head_conv, kernel_size=3, padding=1, bias=False),
             self.norm_func(self.head_conv), self._get_active_func(),
             DCN(self.head_conv, self.head_conv, kernel_size=(3, 3), stride=1, padding=1, dilation=1, deformable_groups=1),
             self.norm_func(self.head_conv), self._get_active_func())

@@ -341,3 +341,56 @@ def batch_norm_act_eval(x, residual, weight, bias, running_mean, running_var, ep
                                       y.data_ptr(), B, C, HW)
     _lib.check(st, "dcd_bn_eval_apply")
     return y
+
+
+# ----------------------------------------------------------------------------------------------
+# 3x3 stride-1 convolution (Winograd F(2x2,3x3) on the matrix pipe): forward + input gradient
+# ----------------------------------------------------------------------------------------------
+def conv3x3_supported(x, weight):
+    """Shapes the HIP kernel is used for: 3x3 weight, W % 4 == 0, H even, at least 64 input and output channels (narrower
+    layers would idle most of a 64-wide output slice), maps of at least 48x160 (measured cross-over, tools/time_conv.py)."""
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3
+            and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] >= 64 and weight.shape[1] >= 64
+            and x.shape[2] * x.shape[3] >= 48 * 160)      # smaller maps: too few workgroups, the stock solver is as fast
+
+
+def _conv3x3_call(inp, weight, out_channels, backward_data):
+    L = _lib.lib()
+    B, _, H, W = inp.shape
+    Co, Ci = weight.shape[0], weight.shape[1]
+    out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
+    n = L.dcd_conv3x3_workspace_bytes(Ci, Co)
+    ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
+    st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Ci, H, W, Co,
+                       1 if backward_data else 0, ws.data_ptr(), n)
+    _lib.check(st, "dcd_conv3x3")
+    return out
+
+
+class _Conv3x3(torch.autograd.Function):
+    """y = conv2d(x, w, stride 1, padding 1) and dL/dx on csrc/conv.hip; dL/dw on the stock op (MIOpen's MFMA
+    implicit-GEMM weight-gradient kernels already run near the fp32 matrix peak)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        ctx.save_for_backward(x, weight)
+        return _conv3x3_call(x, weight, weight.shape[0], False)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True)
+        if ctx.needs_input_grad[1]:
+            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [False, True, False])[1]
+        return gx, gw
+
+
+def conv3x3(x, weight):
+    return _Conv3x3.apply(x, weight)

@@ -191,6 +191,21 @@ int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, con
                           float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,
                           int64_t HW);
 
+/* ------------------------------------------------------------------------------------------------
+ * 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution without bias: forward and backward-data (Winograd
+ * F(2x2,3x3) on the fp32 matrix pipe).  Replaces the stock `nn.Conv2d(.., 3, padding=1, bias=False)` calls of
+ *   DGDE/model/backbone/dla_dcn.py:76-82 (BasicBlock.conv1/conv2 at stride 1) and
+ *   DGDE/model/head/detector_predictor.py:52-58,112-118 (the 64->256 trunks of the class / regression heads),
+ * i.e. torch's cudnn/MIOpen convolution and its input gradient.  The weight gradient stays on the stock op.
+ * weight (Cout,Cin,3,3).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
+ *                         backward_data = 1: input = grad_output (B,Cout,H,W) -> output = grad_input (B,Cin,H,W).
+ * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(Cin, Cout) bytes
+ * (transformed weights), dead after the call's kernels complete.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout);
+int dcd_conv3x3(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
+                int Cout, int backward_data, void *workspace, size_t workspace_bytes);
+
 #ifdef __cplusplus
 }
 #endif
