@@ -1002,6 +1002,127 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// grad_input from the inverse lists, workgroup-tiled (3x3 / stride 1 / pad 1 / dil 1 / one group).
+// dcn_bwd_input_f32 spends its time on ~5 jittered global gathers of dY per (tap, output-channel pair) -- the 16-clk
+// texture-addresser path again.  Every listed pixel lies within 5 px of its cell (|offset| <= 3 by construction of the
+// lists), so a workgroup that owns a 4 x 32 cell tile stages the 14 x 48 dY window of 16 output channels at a time in LDS
+// and the gathers become ds_read_b32.  Loop order: channel chunk (barrier) -> tap (list entries re-read, coalesced) ->
+// 8 output-channel pairs.  No fallback path is needed: what the lists do not hold is added by the data kernels' atomics.
+// grid = (cell tiles, B, ceil(Cin/32/MB)); block = 256 (wave = tile row).
+// ---------------------------------------------------------------------------------------------
+constexpr int BI_TR = 4;
+constexpr int BI_WH = BI_TR + 10;                     // 14 window rows  r0-5 .. r0+8
+constexpr int BI_WW = 48;                             // window cols  c0-8 .. c0+39
+constexpr int BI_PLANE = BI_WH * BI_WW;               // 672 = 10*64 + 32: the two lane halves (o, o+1) are 32 banks apart
+constexpr int BI_OC = 16;                             // output channels per chunk
+
+template <int MB>
+__global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float *__restrict__ gy, const float *__restrict__ wb,
+                                                                    InvLists inv, float *__restrict__ gin, Geom g, int tiles_x)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [BI_OC][BI_PLANE]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int r0 = ty * BI_TR, c0 = tx * 32;
+    const int qy = r0 + wave, qx = c0 + p;
+    const bool qv = qy < g.H && qx < g.W;
+    const int HW = g.H * g.W;
+    const int Qc = qv ? qy * g.W + qx : 0;
+    const int Y0 = r0 - 5, X0 = c0 - 8;
+    const int gb0 = blockIdx.z * MB;
+    const int nchunk = g.Cop / BI_OC;
+    const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
+
+    f32x16 acc[MB];
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb)
+#pragma unroll
+        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
+
+    constexpr int NIN = BI_OC * BI_WH * (BI_WW / 4);          // 2688 dwordx4 per chunk
+    constexpr int KIN = (NIN + BI_TR * 64 - 1) / (BI_TR * 64);   // 11 (last partial)
+    const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+
+    for (int ck = 0; ck < nchunk; ++ck) {
+        const float *src = gy_b + (size_t)ck * BI_OC * g.HoWo;
+        const int oleft = g.Co - ck * BI_OC;
+        __syncthreads();                                       // previous chunk fully consumed
+#pragma unroll 1
+        for (int k0 = 0; k0 < KIN; k0 += 4) {
+            f32x4 rin[4];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tid + BI_TR * 64 * (k0 + k);
+                const int o = e / (BI_WH * 12), rm = e - o * (BI_WH * 12);
+                const int wr = rm / 12, q = rm - wr * 12;
+                const int y = Y0 + wr, x = X0 + 4 * q;
+                rin[k] = zero4;
+                if (e < NIN && o < oleft && y >= 0 && y < g.Ho && x >= 0 && x < g.Wo)
+                    rin[k] = *reinterpret_cast<const f32x4 *>(src + (size_t)o * g.HoWo + y * g.Wo + x);
+            }
+#pragma unroll
+            for (int k = 0; k < 4; ++k) {
+                const int e = tid + BI_TR * 64 * (k0 + k);
+                if (e < NIN) *reinterpret_cast<f32x4 *>(lds + e * 4) = rin[k];      // [o][row][col] is exactly item order
+            }
+        }
+        __syncthreads();
+
+#pragma unroll 1
+        for (int t = 0; t < 9; ++t) {
+            int cnt = qv ? (int)inv.cnt[((size_t)b * 9 + t) * HW + Qc] : 0;
+            if (cnt == INV_OVERFLOW) cnt = 0;
+            int maxc = cnt;
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
+            if (maxc == 0) continue;
+            int eo[INV_CAP];
+            float ew[INV_CAP];
+            const size_t base = ((size_t)b * 9 + t) * INV_CAP * HW + Qc;
+#pragma unroll
+            for (int e = 0; e < INV_CAP; ++e) {
+                eo[e] = 0;
+                ew[e] = 0.f;
+                if (e < maxc && e < cnt) {
+                    const int P = inv.idx[base + (size_t)e * HW];
+                    const int py = P / g.Wo, px = P - py * g.Wo;
+                    eo[e] = (py - Y0) * BI_WW + (px - X0) + h * BI_PLANE;
+                    ew[e] = inv.w[base + (size_t)e * HW];
+                }
+            }
+            const float *wrow = wb + (size_t)(ck * BI_OC + h) * g.Kp + (size_t)t * g.cpgp + p;
+#pragma unroll
+            for (int s = 0; s < BI_OC / 2; ++s) {
+                const float *pl = lds + 2 * s * BI_PLANE;
+                float val = 0.f;
+#pragma unroll
+                for (int e = 0; e < INV_CAP; ++e)
+                    if (e < maxc) val += ew[e] * pl[eo[e]];
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    if ((gb0 + mb) * 32 < g.cpgp)
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(size_t)(2 * s) * g.Kp + (gb0 + mb) * 32], val, acc[mb], 0, 0, 0);
+            }
+        }
+    }
+
+    float *gin_b = gin + (size_t)b * g.C * HW;
+#pragma unroll
+    for (int mb = 0; mb < MB; ++mb) {
+        const int blk = gb0 + mb;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            const int cc = blk * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+            if (qv && cc < g.C) gin_b[(size_t)cc * HW + Qc] = acc[mb][r];
+        }
+    }
+}
+
 // grad_bias[o] = sum_{b,p} dY[b,o,p].  grid = (Cout, splits); one float atomic per block (same-address atomics from
 // every wave of the data kernel serialised in L2 and cost more than the whole MFMA work).
 __global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo)
@@ -1946,12 +2067,35 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                            (g.HoWo + 31) / 32, far_flag, far_list);
         const int HWin = H * W;
         hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
+        bool bi_tiled = false;
+#ifndef DCN_NO_BWD_TILE
+        if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
+            H >= 8 && W >= 32 && getenv("DCD_BI_TILE") != nullptr) {   // opt-in: measured round 1 at 1.4 ms vs 0.65 ms (64->64), see DESIGN.md
+            static bool attr_set = false;
+            const size_t ldsb = (size_t)BI_OC * BI_PLANE * sizeof(float);
+            if (!attr_set) {
+                if (hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess ||
+                    hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+                    return DCD_ERR_LAUNCH;
+                attr_set = true;
+            }
+            const int tiles_x = (W + 31) / 32, tiles_y = (H + BI_TR - 1) / BI_TR;
+            if (nblk <= 2)
+                hipLaunchKernelGGL(dcn_bwd_input_tile_f32<2>, dim3(tiles_x * tiles_y, B, 1), dim3(BI_TR * 64), ldsb, stream, grad_output, wb,
+                                   inv, grad_input, g, tiles_x);
+            else
+                hipLaunchKernelGGL(dcn_bwd_input_tile_f32<4>, dim3(tiles_x * tiles_y, B, (nblk + 3) / 4), dim3(BI_TR * 64), ldsb, stream,
+                                   grad_output, wb, inv, grad_input, g, tiles_x);
+            bi_tiled = true;
+        }
+#endif
         const int in_tiles = (HWin + 31) / 32;
         const int total_blocks = dg * nblk;
         int mbi = total_blocks >= 8 ? 8 : total_blocks >= 4 ? 4 : total_blocks >= 2 ? 2 : 1;
         while (mbi > 1 && (int64_t)in_tiles * B * ((total_blocks + mbi - 1) / mbi) < 1024) mbi >>= 1;
         dim3 grid((in_tiles + 3) / 4, B, (total_blocks + mbi - 1) / mbi), block(256);
-        if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+        if (bi_tiled) { /* done above */ }
+        else if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
         else if (mbi == 4) hipLaunchKernelGGL(dcn_bwd_input_f32<4>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
         else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
         else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
