@@ -176,7 +176,9 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 
     for (int ck = 0; ck < nchunk; ++ck) {
         const float *buf = lds + (ck & 1) * WN_BUF;
+#ifndef WN_ABL_NOSTAGE
         if (ck + 1 < nchunk) issue(ck + 1);
+#endif
         const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
 #pragma unroll
@@ -189,21 +191,32 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #pragma unroll
             for (int s = 0; s < 4; ++s) {
                 const float *q1 = cp1 + 2 * s * WN_PLANE, *q2 = cp2 + 2 * s * WN_PLANE;
+#ifdef WN_ABL_NOLDS
+                const float u1 = sa * (float)s, u2 = sb + (float)nu; (void)q1; (void)q2;
+#else
                 const float u1 = TA[nu] * q1[CA[nu]] + TB[nu] * q1[CB[nu]];
                 const float u2 = TA[nu] * q2[CA[nu]] + TB[nu] * q2[CB[nu]];
+#endif
                 const float val = sa * u1 + sb * u2;
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], val, acc[nu][0], 0, 0, 0);
                 acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], val, acc[nu][1], 0, 0, 0);
             }
         }
+#ifndef WN_ABL_NOSTAGE
         if (ck + 1 < nchunk) commit(lds + ((ck + 1) & 1) * WN_BUF);
+#endif
         __syncthreads();
     }
+#ifdef WN_ABL_NOEPI
+    if (acc[0][0][0] != 123.456f) return;
+#endif
 
     // ---- output transform.  A^T = [[1,1,1,0],[0,1,-1,-1]]: over nu in registers, over xi through LDS.
-    // ex[wave][j*16 + r][lane]; per mb round 8 x 32 x 64 floats = 64 KB.
+    // ex[wave][j*16 + r][lane]; per mb round 8 x 32 x 64 floats = 64 KB.  Every wave finalises four of the sixteen
+    // accumulator rows (r = 4 xi .. 4 xi + 3) for both output rows, so the exchange reads and the stores are balanced.
     float *ex = lds;
     float *y_b = y + (size_t)b * Kk * HW;
+    const int orow0 = r0 + 4 * tg + 2 * trow, ocol = c0 + 2 * tcol;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         float *mine = ex + (size_t)wave * 32 * 64 + lane;
@@ -213,25 +226,18 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             mine[(16 + r) * 64] = acc[1][mb][r] - acc[2][mb][r] - acc[3][mb][r];      // j = 1
         }
         __syncthreads();
-        if (xi == 0 || xi == 3) {
-            // xi == 0 produces output row i = 0 (T0 + T1 + T2), xi == 3 row i = 1 (T1 - T2 - T3)
-            const float *t1 = ex + (size_t)(tg * 4 + 1) * 32 * 64 + lane, *t2 = ex + (size_t)(tg * 4 + 2) * 32 * 64 + lane;
-            const float *t0 = ex + (size_t)wave * 32 * 64 + lane;
-            const int i = xi == 0 ? 0 : 1;
-            const int orow = r0 + 4 * tg + 2 * trow + i, ocol = c0 + 2 * tcol;
-            if (orow < H && ocol < W) {
+        const float *t0 = ex + (size_t)(tg * 4 + 0) * 32 * 64 + lane, *t1 = t0 + 32 * 64, *t2 = t1 + 32 * 64, *t3 = t2 + 32 * 64;
+        if (ocol < W) {
 #pragma unroll
-                for (int r = 0; r < 16; ++r) {
-                    const int k = z * WN_KS + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
-                    float o0, o1;
-                    if (i == 0) {
-                        o0 = t0[r * 64] + t1[r * 64] + t2[r * 64];
-                        o1 = t0[(16 + r) * 64] + t1[(16 + r) * 64] + t2[(16 + r) * 64];
-                    } else {
-                        o0 = t1[r * 64] - t2[r * 64] - t0[r * 64];
-                        o1 = t1[(16 + r) * 64] - t2[(16 + r) * 64] - t0[(16 + r) * 64];
-                    }
-                    if (k < Kk) *reinterpret_cast<f32x2 *>(y_b + (size_t)k * HW + (size_t)orow * W + ocol) = f32x2{o0, o1};
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * xi + rr;
+                const int k = z * WN_KS + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float a0 = t0[r * 64], a1 = t1[r * 64], a2 = t2[r * 64], a3 = t3[r * 64];
+                const float b0 = t0[(16 + r) * 64], b1 = t1[(16 + r) * 64], b2 = t2[(16 + r) * 64], b3 = t3[(16 + r) * 64];
+                if (k < Kk) {
+                    float *dst = y_b + (size_t)k * HW + (size_t)orow0 * W + ocol;
+                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2, b0 + b1 + b2};
+                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3, b1 - b2 - b3};
                 }
             }
         }
