@@ -422,158 +422,6 @@ __global__ __launch_bounds__(256) void dcn_fwd9_f32(const float *__restrict__ in
 }
 
 // ---------------------------------------------------------------------------------------------
-// Forward, 3x3 / stride 1 / pad 1 / dilation 1 (every DCN of DLA-34): LDS-staged gathers.
-//
-// A workgroup owns LT_ROWS x 32 output pixels (one row segment per wave).  For each chunk of 32 input channels it copies
-// the window [r0-1-HALO, r0+LT_ROWS+HALO] x [c0-1-HALO, c0+32+HALO] of the planes into LDS with coalesced loads (cells
-// outside the image are stored as 0, which IS the reference's zero padding of bilinear corners), and every bilinear
-// corner pair is then ONE ds_read2_b32.  The 36x re-reads of the input therefore hit LDS instead of the L2->L1 path that
-// bounded the register-gather kernels (~25 TB/s of line traffic at 64->64).  A sample whose 2x2 footprint leaves the
-// staged window (|offset| > HALO) is fetched from global memory by that lane instead (wave-uniform test per tap).
-// ---------------------------------------------------------------------------------------------
-constexpr int LT_ROWS = 4;                       // waves per workgroup = output rows per tile
-constexpr int LT_HALO = 2;                       // extra cells around the 3x3 footprint
-constexpr int LT_SH = LT_ROWS + 2 + 2 * LT_HALO; // staged rows   (10)
-constexpr int LT_SW = 32 + 2 + 2 * LT_HALO;      // staged cols   (38)
-constexpr int LT_CH = 32;                        // channels per chunk
-constexpr int LT_PLANE = LT_SH * LT_SW;          // floats per staged channel (380)
-
-template <int MB>
-__global__ __launch_bounds__(256) void dcn_fwd_lds_f32(const float *__restrict__ in, const float *__restrict__ off,
-                                                       const float *__restrict__ msk, const float *__restrict__ wf,
-                                                       const float *__restrict__ bias, float *__restrict__ out, Geom g,
-                                                       int tiles_x, int tiles_y)
-{
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // [LT_CH][LT_SH][LT_SW]
-    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-    const int p = lane & 31, h = lane >> 5;
-    int bx = blockIdx.x, b = blockIdx.y;
-    xcd_remap(bx, b);
-    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
-    const int r0 = ty * LT_ROWS, c0 = tx * 32;
-    const int ho = r0 + wave, wo = c0 + p;
-    const bool pv = ho < g.Ho && wo < g.Wo;
-    const int Pc = pv ? ho * g.Wo + wo : 0;
-    const int ob0 = blockIdx.z * MB;
-    const int HW = g.H * g.W;
-    const unsigned Cop4 = (unsigned)g.Cop * 4u;
-    const int Y0 = r0 - 1 - LT_HALO, X0 = c0 - 1 - LT_HALO;      // image coordinates of staged cell (0,0)
-
-    f32x16 acc[MB];
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb)
-#pragma unroll
-        for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
-
-    const float *in_b = in + (size_t)b * g.C * HW;
-    const float *off_b = off + (size_t)b * g.dg * 18 * g.HoWo;
-    const float *msk_b = msk + (size_t)b * g.dg * 9 * g.HoWo;
-    const unsigned wlane = ((unsigned)h * (unsigned)g.Cop + (unsigned)(ob0 * 32 + p)) * 4u;
-
-    // staging map: element e = lane + 64*k of one staged plane (channel independent -> registers)
-    constexpr int NSTG = (LT_PLANE + 63) / 64;
-    int st_g[NSTG];            // global element offset inside a plane, or -1 (outside the image / past the plane)
-#pragma unroll
-    for (int k = 0; k < NSTG; ++k) {
-        const int e = lane + 64 * k;
-        const int sy = e / LT_SW, sx = e - sy * LT_SW;
-        const int y = Y0 + sy, x = X0 + sx;
-        st_g[k] = (e < LT_PLANE && y >= 0 && y < g.H && x >= 0 && x < g.W) ? y * g.W + x : -1;
-    }
-
-    for (int grp = 0; grp < g.dg; ++grp) {
-        // sampling state of the nine taps of this pixel: LDS offset of the top pair + 4 mask-scaled bilinear weights.
-        // Zero padding needs no corner tests: cells outside the image are staged as zeros.
-        int lo[9];
-        float wq[9][4];
-        unsigned farbits = 0;
-#pragma unroll
-        for (int t = 0; t < 9; ++t) {
-            const TapRaw raw = load_tap_raw(off_b, msk_b, g, grp * 9 + t, Pc);
-            const float hf = (float)(ho - 1 + t / 3) + raw.oh, wf_ = (float)(wo - 1 + t % 3) + raw.ow;
-            const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W;
-            const float hlf = sv ? floorf(hf) : (float)Y0, wlf = sv ? floorf(wf_) : (float)X0;
-            const int ly = (int)hlf - Y0, lx = (int)wlf - X0;
-            const bool far = sv && (ly < 0 || lx < 0 || ly + 1 > LT_SH - 1 || lx + 1 > LT_SW - 1);
-            farbits |= far ? (1u << t) : 0u;
-            lo[t] = min(max(ly, 0), LT_SH - 2) * LT_SW + min(max(lx, 0), LT_SW - 2);
-            const float lh = hf - hlf, lw = wf_ - wlf;
-            const float m = (sv && !far) ? raw.m : 0.f;
-            wq[t][0] = (1.f - lh) * (1.f - lw) * m; wq[t][1] = (1.f - lh) * lw * m;
-            wq[t][2] = lh * (1.f - lw) * m;         wq[t][3] = lh * lw * m;
-        }
-        const bool wave_far = __any(farbits != 0u);
-
-        for (int ch0 = 0; ch0 < g.cpg; ch0 += LT_CH) {
-            const int nch = min(LT_CH, g.cpg - ch0);
-            const float *in_c = in_b + ((size_t)grp * g.cpg + ch0) * HW;
-            __syncthreads();                                  // previous chunk fully consumed
-            for (int c = wave; c < nch; c += 4) {             // each wave stages every 4th plane of the chunk
-                const float *pl = in_c + (size_t)c * HW;
-                float v[NSTG];
-#pragma unroll
-                for (int k = 0; k < NSTG; ++k) v[k] = st_g[k] >= 0 ? pl[st_g[k]] : 0.f;
-#pragma unroll
-                for (int k = 0; k < NSTG; ++k)
-                    if (lane + 64 * k < LT_PLANE) lds[c * LT_PLANE + lane + 64 * k] = v[k];
-            }
-            __syncthreads();
-            // ---- consume: taps outer, channel pairs inner (lane half h takes channel 2*i + h of the chunk)
-            const int npair = (nch + 1) >> 1;
-            const bool odd = nch & 1;
-#pragma unroll
-            for (int t = 0; t < 9; ++t) {
-                const float *wrow = wf + ((size_t)(grp * 9 + t) * g.cpgp + ch0) * g.Cop;
-                const float *lp = lds + h * LT_PLANE + lo[t];
-                const float q0 = wq[t][0], q1 = wq[t][1], q2 = wq[t][2], q3 = wq[t][3];
-#pragma unroll 4
-                for (int i = 0; i < npair; ++i) {
-                    const bool live = !(odd && h && i + 1 == npair);
-                    const float *cp = lp + (live ? 2 * i * LT_PLANE : 0);
-                    float val = q0 * cp[0] + q1 * cp[1] + q2 * cp[LT_SW] + q3 * cp[LT_SW + 1];
-                    val = live ? val : 0.f;
-                    const float *wr = (const float *)((const char *)wrow + (size_t)(2 * i) * Cop4);
-#pragma unroll
-                    for (int mb = 0; mb < MB; ++mb)
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldg(wr, wlane + mb * 128u), val, acc[mb], 0, 0, 0);
-                }
-            }
-            if (wave_far) {
-                // rare: samples whose footprint is outside the staged window are taken from global memory by their lane
-#pragma unroll 1
-                for (int t = 0; t < 9; ++t) {
-                    if (!__any((farbits >> t) & 1u)) continue;
-                    const bool mine = (farbits >> t) & 1u;
-                    const Tap s = make_tap(off_b, msk_b, g, grp * 9 + t, t, ho, wo, Pc, pv);
-                    const float *wrow = wf + ((size_t)(grp * 9 + t) * g.cpgp + ch0) * g.Cop;
-                    for (int i = 0; i < npair; ++i) {
-                        const bool live = mine && !(odd && h && i + 1 == npair);
-                        const float *gp = in_c + (size_t)(live ? 2 * i + h : 0) * HW;
-                        const f32x2 gt = ldg2(gp, (unsigned)s.pt * 4u), gb = ldg2(gp, (unsigned)s.pb * 4u);
-                        const float val = live ? (s.a0 * gt.x + s.a1 * gt.y + s.b0 * gb.x + s.b1 * gb.y) * s.m : 0.f;
-                        const float *wr = (const float *)((const char *)wrow + (size_t)(2 * i) * Cop4);
-#pragma unroll
-                        for (int mb = 0; mb < MB; ++mb)
-                            acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(ldg(wr, wlane + mb * 128u), val, acc[mb], 0, 0, 0);
-                    }
-                }
-            }
-        }
-    }
-
-    float *out_b = out + (size_t)b * g.Co * g.HoWo;
-#pragma unroll
-    for (int mb = 0; mb < MB; ++mb) {
-        const int obase = (ob0 + mb) * 32 + 4 * h;
-#pragma unroll
-        for (int r = 0; r < 16; ++r) {
-            const int o = obase + (r & 3) + 8 * (r >> 2);
-            if (pv && o < g.Co) out_b[(size_t)o * g.HoWo + ho * g.Wo + wo] = acc[mb][r] + bias[o];
-        }
-    }
-}
-
-// ---------------------------------------------------------------------------------------------
 // Forward, 3x3 / stride 1 / pad 1 / dilation 1 / one deformable group: workgroup-tiled, LDS-resident gathers.
 //
 // Measured on MI355X (tools/micro/gather_rate.hip): a vector-memory instruction whose 64 lane addresses are strictly
@@ -1882,6 +1730,21 @@ __global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict_
     }
 }
 
+// One launch instead of up to six hipMemsetAsync calls (each is its own ~5 us kernel on the stream).
+struct ZeroRanges {
+    unsigned *p[6];
+    unsigned n[6];        // dwords
+};
+__global__ void dcn_zero_ranges(ZeroRanges z)
+{
+#pragma unroll
+    for (int r = 0; r < 6; ++r) {
+        unsigned *p = z.p[r];
+        const unsigned n = z.n[r];
+        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+    }
+}
+
 inline int pick_mb(int nb, int tiles_total)
 {
     // largest MB in {8,4,2,1} (32-wide Cout blocks per wave) that still leaves >= 1024 waves
@@ -1930,28 +1793,10 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
     float *wf = (float *)workspace, *wb = wf + nw;
 
-    hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
-                       0, stream, weight, wf, wb, g);
-
     const int tiles = (g.HoWo + 31) / 32;
     const int nb = g.Cop / 32;
     const int mb = pick_mb(nb, tiles * B);
     dim3 grid((tiles + 3) / 4, B, (nb + mb - 1) / mb), block(256);
-#ifdef DCN_USE_FWD_LDS   // measured round 1: 0.436 ms vs 0.344 ms (fwd9) at 64->64 @ 96x320 bs 8 -- not the default yet
-    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && W >= 2) {
-        const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + LT_ROWS - 1) / LT_ROWS;
-        int mbl = nb >= 4 ? 4 : nb >= 2 ? 2 : 1;
-        while (mbl > 1 && (int64_t)tiles_x * tiles_y * B * ((nb + mbl - 1) / mbl) < 512) mbl >>= 1;
-        dim3 gridl(tiles_x * tiles_y, B, (nb + mbl - 1) / mbl);
-        const size_t ldsb = (size_t)LT_CH * LT_PLANE * sizeof(float);
-        switch (mbl) {
-            case 4: hipLaunchKernelGGL(dcn_fwd_lds_f32<4>, gridl, block, ldsb, stream, input, offset, mask, wf, bias, output, g, tiles_x, tiles_y); break;
-            case 2: hipLaunchKernelGGL(dcn_fwd_lds_f32<2>, gridl, block, ldsb, stream, input, offset, mask, wf, bias, output, g, tiles_x, tiles_y); break;
-            default: hipLaunchKernelGGL(dcn_fwd_lds_f32<1>, gridl, block, ldsb, stream, input, offset, mask, wf, bias, output, g, tiles_x, tiles_y); break;
-        }
-        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
-    }
-#endif
 #ifndef DCN_NO_FWD_TILE
     // workgroup-tiled LDS kernel: the DLA-34 shape (3x3, stride 1, pad 1, dil 1, dg 1); maps of at least 16 rows
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
@@ -2000,6 +1845,8 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
 #endif
+    hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
+                       0, stream, weight, wf, wb, g);
     switch (mb) {
         case 8: hipLaunchKernelGGL(dcn_fwd_f32<8>, grid, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
         case 4: hipLaunchKernelGGL(dcn_fwd_f32<4>, grid, block, 0, stream, input, offset, mask, wf, bias, output, g); break;
@@ -2049,13 +1896,22 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     int nsplit = 1;
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
 
-    hipMemsetAsync(absmax, 0, 2 * sizeof(unsigned), stream);
-    hipMemsetAsync(far_flag, 0, (ntile + 3) / 4 * 4, stream);
-    hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)Cout * Cin * g.KK, stream);
-    hipMemsetAsync(grad_bias, 0, sizeof(float) * (size_t)Cout, stream);
-    if (nsplit > 1) {
-        hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * dg * 2 * g.KK * g.HoWo, stream);
-        hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * dg * g.KK * g.HoWo, stream);
+    const bool tile_shape = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 &&
+                            (W & 3) == 0 && H >= 8 && W >= 32;
+    const bool bd_tile_ok = tile_shape && g.Cop == 64;   // Cout 128 (64 dY registers per lane) spills at two waves per SIMD
+    {
+        ZeroRanges z;
+        for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        z.p[0] = absmax; z.n[0] = 2;
+        z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
+        z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
+        z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
+        if (nsplit > 1 || (bd_tile_ok && nblk > 1)) {      // these accumulate with atomics when the channel blocks are split
+            z.p[4] = (unsigned *)grad_offset; z.n[4] = (unsigned)((size_t)B * dg * 2 * g.KK * g.HoWo);
+            z.p[5] = (unsigned *)grad_mask; z.n[5] = (unsigned)((size_t)B * dg * g.KK * g.HoWo);
+        }
+        const size_t most = (size_t)z.n[2] > (size_t)z.n[4] ? z.n[2] : z.n[4];
+        hipLaunchKernelGGL(dcn_zero_ranges, dim3((unsigned)(most / 1024 + 1 < 2048 ? most / 1024 + 1 : 2048)), dim3(256), 0, stream, z);
     }
 
     // (1) search radius from max |offset|, (2) inverse sample lists, (3) grad_input by gather + MFMA (plain stores)
@@ -2108,8 +1964,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     // (4) grad_offset / grad_mask (+ atomic fallback for what the lists do not cover)
     bool bd_tiled = false;
 #ifndef DCN_NO_BWD_TILE
-    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
-        H >= 8 && W >= 32 && g.Cop == 64) {      // Cout 128 (64 dY registers per lane) spills at two waves per SIMD: generic kernel
+    if (bd_tile_ok) {
         static bool attr_set = false;
         const size_t ldsb = (size_t)BD_CB * BD_PLANE * sizeof(float);
         if (!attr_set) {
@@ -2120,10 +1975,6 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         }
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + BD_TR - 1) / BD_TR;
         const int nsp = nblk;                 // one 32-channel block per workgroup
-        if (nsp > 1 && nsplit == 1) {        // the tiled launch accumulates with atomics when there are several blocks
-            hipMemsetAsync(grad_offset, 0, sizeof(float) * (size_t)B * 18 * g.HoWo, stream);
-            hipMemsetAsync(grad_mask, 0, sizeof(float) * (size_t)B * 9 * g.HoWo, stream);
-        }
         dim3 gridt(tiles_x * tiles_y, B, nsp), blockt(BD_TR * 64);
         if (g.Cop == 64)
             hipLaunchKernelGGL(dcn_bwd_data_tile_f32<32>, gridt, blockt, ldsb, stream, input, offset, mask, wb, grad_output, grad_input,
