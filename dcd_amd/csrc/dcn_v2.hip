@@ -663,6 +663,7 @@ struct InvLists {
     unsigned char *cnt;            // [B][S][HW]
     int *idx;                      // [B][S][INV_CAP][HW]
     float *w;                      // [B][S][INV_CAP][HW]
+    int packed;                    // idx holds (py << 16 | px) instead of the flat pixel index (tiled grad_input kernel)
 };
 
 __device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
@@ -732,7 +733,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             const float dw_ = ((float)(px * g.sw - g.pw + j * g.dw) + ow) - (float)qx;
             if (fabsf(dh_) < 1.f && fabsf(dw_) < 1.f) {
                 if (cnt < INV_CAP) {
-                    inv.idx[base + (size_t)cnt * HW] = P;
+                    inv.idx[base + (size_t)cnt * HW] = inv.packed ? ((py << 16) | px) : P;
                     inv.w[base + (size_t)cnt * HW] = (1.f - fabsf(dh_)) * (1.f - fabsf(dw_)) * m_p[P];
                 }
                 ++cnt;
@@ -869,7 +870,8 @@ template <int MB>
 __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float *__restrict__ gy, const float *__restrict__ wb,
                                                                     InvLists inv, float *__restrict__ gin, Geom g, int tiles_x)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // [BI_OC][BI_PLANE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [BI_OC][BI_PLANE] window | [8 pairs][9][MB][2][32] weights
+    float *wsl = lds + BI_OC * BI_PLANE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -896,10 +898,28 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
     constexpr int KIN = (NIN + BI_TR * 64 - 1) / (BI_TR * 64);   // 11 (last partial)
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
+    // list entries (raw, undecoded) of the next tap to run: cnt is capped at 6 loads in flight per array to bound registers
+    int ncnt = 0, neo[INV_CAP];
+    float new_[INV_CAP];
+    auto fetch_list = [&](int t) {
+        int c = qv ? (int)inv.cnt[((size_t)b * 9 + t) * HW + Qc] : 0;
+        ncnt = c == INV_OVERFLOW ? 0 : c;
+        const size_t base = ((size_t)b * 9 + t) * INV_CAP * HW + Qc;
+#pragma unroll
+        for (int e = 0; e < INV_CAP; ++e) {       // unconditional: slots past cnt hold stale data of the workspace, masked on use
+            neo[e] = inv.idx[base + (size_t)e * HW];
+            new_[e] = inv.w[base + (size_t)e * HW];
+        }
+    };
+    fetch_list(0);
+
     for (int ck = 0; ck < nchunk; ++ck) {
         const float *src = gy_b + (size_t)ck * BI_OC * g.HoWo;
         const int oleft = g.Co - ck * BI_OC;
         __syncthreads();                                       // previous chunk fully consumed
+#ifdef BIT_ABL_NOSTAGE
+        if (ck < 0)
+#endif
 #pragma unroll 1
         for (int k0 = 0; k0 < KIN; k0 += 4) {
             f32x4 rin[4];
@@ -919,42 +939,68 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
                 if (e < NIN) *reinterpret_cast<f32x4 *>(lds + e * 4) = rin[k];      // [o][row][col] is exactly item order
             }
         }
+        {
+            // A operands of this chunk: Wb rows of its 16 output channels, the 64 channels of this workgroup, all 9 taps.
+            // Slab index = ((pair*9 + tap)*MB + mb)*2 + h groups of 32 floats: the two lane halves sit 32 banks apart.
+            constexpr int NWQ = (BI_OC / 2) * 9 * MB * 2 * 8;                 // dwordx4 items
+            f32x4 rw[(NWQ + BI_TR * 64 - 1) / (BI_TR * 64)];
+#pragma unroll
+            for (int k = 0; k < (NWQ + BI_TR * 64 - 1) / (BI_TR * 64); ++k) {
+                const int e = tid + BI_TR * 64 * k;
+                const int gq = e >> 3, q = e & 7;
+                const int hh = gq & 1, mbq = (gq >> 1) % MB, st = (gq >> 1) / MB;
+                const int t = st % 9, sp = st / 9;
+                rw[k] = zero4;
+                if (e < NWQ && (gb0 + mbq) * 32 < g.cpgp)
+                    rw[k] = *reinterpret_cast<const f32x4 *>(wb + (size_t)(ck * BI_OC + 2 * sp + hh) * g.Kp + (size_t)t * g.cpgp +
+                                                             (gb0 + mbq) * 32 + 4 * q);
+            }
+#pragma unroll
+            for (int k = 0; k < (NWQ + BI_TR * 64 - 1) / (BI_TR * 64); ++k) {
+                const int e = tid + BI_TR * 64 * k;
+                if (e < NWQ) *reinterpret_cast<f32x4 *>(wsl + e * 4) = rw[k];
+            }
+        }
         __syncthreads();
 
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
-            int cnt = qv ? (int)inv.cnt[((size_t)b * 9 + t) * HW + Qc] : 0;
-            if (cnt == INV_OVERFLOW) cnt = 0;
+            // entries of this tap were fetched while the previous tap ran; request the next tap's now
+            int cnt = ncnt;
+            int eo[INV_CAP];
+            float ew[INV_CAP];
+#pragma unroll
+            for (int e = 0; e < INV_CAP; ++e) { eo[e] = neo[e]; ew[e] = new_[e]; }
+            fetch_list(t == 8 ? 0 : t + 1);
             int maxc = cnt;
 #pragma unroll
             for (int o = 32; o > 0; o >>= 1) maxc = max(maxc, __shfl_xor(maxc, o));
             if (maxc == 0) continue;
-            int eo[INV_CAP];
-            float ew[INV_CAP];
-            const size_t base = ((size_t)b * 9 + t) * INV_CAP * HW + Qc;
 #pragma unroll
             for (int e = 0; e < INV_CAP; ++e) {
-                eo[e] = 0;
-                ew[e] = 0.f;
-                if (e < maxc && e < cnt) {
-                    const int P = inv.idx[base + (size_t)e * HW];
-                    const int py = P / g.Wo, px = P - py * g.Wo;
-                    eo[e] = (py - Y0) * BI_WW + (px - X0) + h * BI_PLANE;
-                    ew[e] = inv.w[base + (size_t)e * HW];
-                }
+                const int P = eo[e];                                   // packed (py << 16 | px), 0 weight when unused
+                eo[e] = e < cnt ? ((P >> 16) - Y0) * BI_WW + ((P & 0xffff) - X0) + h * BI_PLANE : 0;
+                ew[e] = e < cnt ? ew[e] : 0.f;
             }
-            const float *wrow = wb + (size_t)(ck * BI_OC + h) * g.Kp + (size_t)t * g.cpgp + p;
+            const float *wrow = wsl + (t * MB * 2 + h) * 32 + p;
 #pragma unroll
             for (int s = 0; s < BI_OC / 2; ++s) {
                 const float *pl = lds + 2 * s * BI_PLANE;
                 float val = 0.f;
 #pragma unroll
                 for (int e = 0; e < INV_CAP; ++e)
+#ifdef BIT_ABL_NOLDS
+                    if (e < maxc) val += ew[e] * (float)eo[e];
+#else
                     if (e < maxc) val += ew[e] * pl[eo[e]];
+#endif
 #pragma unroll
                 for (int mb = 0; mb < MB; ++mb)
-                    if ((gb0 + mb) * 32 < g.cpgp)
-                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(size_t)(2 * s) * g.Kp + (gb0 + mb) * 32], val, acc[mb], 0, 0, 0);
+#ifdef BIT_ABL_NOMFMA
+                    acc[mb][s] += val;
+#else
+                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(s * 9 * MB + mb) * 64], val, acc[mb], 0, 0, 0);
+#endif
             }
         }
     }
@@ -1882,6 +1928,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     inv.cnt = (unsigned char *)absmax + 256;
     inv.idx = (int *)(inv.cnt + (cells + 255) / 256 * 256);
     inv.w = (float *)(inv.idx + cells * INV_CAP);
+    inv.packed = 0;
     const size_t ntile = (size_t)B * ((g.HoWo + 31) / 32);
     unsigned char *far_flag = (unsigned char *)(((uintptr_t)(inv.w + cells * INV_CAP) + 255) / 256 * 256);
     int *far_list = (int *)(far_flag + (ntile + 255) / 256 * 256);
@@ -1922,26 +1969,28 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
                            (g.HoWo + 31) / 32, far_flag, far_list);
         const int HWin = H * W;
+#ifndef DCN_NO_BWD_TILE
+        // tiled grad_input: one 64-channel slice per workgroup; wider inputs re-stage the dY window and re-read the lists per
+        // slice and lose to the register-gather kernel (measured: 128->128 1.56 vs 1.48 ms, 256->256 2.25 vs 1.64 ms per backward)
+        const bool bi_tile_ok = tile_shape && nblk <= 2 && H < 65536 && W < 65536 && getenv("DCD_NO_BI_TILE") == nullptr;
+#else
+        const bool bi_tile_ok = false;
+#endif
+        inv.packed = bi_tile_ok ? 1 : 0;
         hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         bool bi_tiled = false;
 #ifndef DCN_NO_BWD_TILE
-        if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
-            H >= 8 && W >= 32 && getenv("DCD_BI_TILE") != nullptr) {   // opt-in: measured round 1 at 1.4 ms vs 0.65 ms (64->64), see DESIGN.md
+        if (bi_tile_ok) {
             static bool attr_set = false;
-            const size_t ldsb = (size_t)BI_OC * BI_PLANE * sizeof(float);
+            const size_t ldsb = (size_t)(BI_OC * BI_PLANE + (BI_OC / 2) * 9 * 2 * 2 * 32) * sizeof(float);
             if (!attr_set) {
-                if (hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+                if (hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
                     return DCD_ERR_LAUNCH;
                 attr_set = true;
             }
             const int tiles_x = (W + 31) / 32, tiles_y = (H + BI_TR - 1) / BI_TR;
-            if (nblk <= 2)
-                hipLaunchKernelGGL(dcn_bwd_input_tile_f32<2>, dim3(tiles_x * tiles_y, B, 1), dim3(BI_TR * 64), ldsb, stream, grad_output, wb,
-                                   inv, grad_input, g, tiles_x);
-            else
-                hipLaunchKernelGGL(dcn_bwd_input_tile_f32<4>, dim3(tiles_x * tiles_y, B, (nblk + 3) / 4), dim3(BI_TR * 64), ldsb, stream,
-                                   grad_output, wb, inv, grad_input, g, tiles_x);
+            hipLaunchKernelGGL(dcn_bwd_input_tile_f32<2>, dim3(tiles_x * tiles_y, B, (nblk + 1) / 2), dim3(BI_TR * 64), ldsb, stream,
+                               grad_output, wb, inv, grad_input, g, tiles_x);
             bi_tiled = true;
         }
 #endif
