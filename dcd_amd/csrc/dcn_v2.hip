@@ -1846,7 +1846,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
 #ifndef DCN_NO_FWD_TILE
     // workgroup-tiled LDS kernel: the DLA-34 shape (3x3, stride 1, pad 1, dil 1, dg 1); maps of at least 16 rows
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
-        H >= 8 && W >= 32) {
+        H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr) {
         const int nchunk = (Cin + TL_CH - 1) / TL_CH, nz = (Cout + TL_OB - 1) / TL_OB;
         const size_t nwl = (size_t)nz * nchunk * TL_W_FLOATS;
         if (nwl <= 2 * nw) {                                          // Wl lives in the [Wf | Wb] area
@@ -1944,7 +1944,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
 
     const bool tile_shape = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 &&
-                            (W & 3) == 0 && H >= 8 && W >= 32;
+                            (W & 3) == 0 && H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr;
     const bool bd_tile_ok = tile_shape && g.Cop == 64;   // Cout 128 (64 dY registers per lane) spills at two waves per SIMD
     {
         ZeroRanges z;
@@ -2050,8 +2050,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     }
     bool dw_tiled = false;
 #ifndef DCN_NO_BWD_TILE
-    if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
-        H >= 8 && W >= 32) {
+    if (tile_shape) {
         static bool attr_set = false;
         const size_t ldsb = (size_t)(DW_IN_FLOATS + DW_DY_FLOATS) * sizeof(float);
         if (!attr_set) {

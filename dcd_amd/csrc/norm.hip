@@ -45,6 +45,28 @@ __device__ inline void block_sum2(double &a, double &b)
     }
 }
 
+// (sum0, sum1) of channel c: from the combined array, or -- local (non-synchronised) case -- by reducing the S partials of
+// the two-stage reduction right here (first wave, fixed order), which saves the separate combine launch.
+__device__ inline void channel_sums(const double *__restrict__ combined, const double *__restrict__ partial, int S, int c,
+                                    double &s0, double &s1)
+{
+    if (!partial) { s0 = combined[2 * c]; s1 = combined[2 * c + 1]; return; }
+    __shared__ double bc[2];
+    if (threadIdx.x < 64) {
+        double a = 0.0, b = 0.0;
+        for (int s = threadIdx.x; s < S; s += 64) {
+            a += partial[((long)c * S + s) * 2 + 0];
+            b += partial[((long)c * S + s) * 2 + 1];
+        }
+        a = wave_sum(a);
+        b = wave_sum(b);
+        if (threadIdx.x == 0) { bc[0] = a; bc[1] = b; }
+    }
+    __syncthreads();
+    s0 = bc[0];
+    s1 = bc[1];
+}
+
 struct Plane {
     int B, C, cpp;      // cpp = chunks per plane
     long HW;
@@ -103,8 +125,8 @@ __global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ part
 // stats != nullptr: training, batch statistics from (sum, sumsq, count); else eval with (mean_in, var_in).
 __global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, const float *__restrict__ residual,
                                                const float *__restrict__ weight, const float *__restrict__ bias,
-                                               const double *__restrict__ stats, double count,
-                                               float *__restrict__ running_mean, float *__restrict__ running_var,
+                                               const double *__restrict__ stats, const double *__restrict__ partial, int S,
+                                               double count, float *__restrict__ running_mean, float *__restrict__ running_var,
                                                long long *__restrict__ num_batches_tracked, float momentum, float eps,
                                                int relu, float *__restrict__ y, float *__restrict__ save_mean,
                                                float *__restrict__ save_invstd, Plane g)
@@ -112,9 +134,11 @@ __global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, cons
     const int c = blockIdx.y;
     const int b = blockIdx.x / g.cpp, k = blockIdx.x - b * g.cpp;
     float mean, invstd;
-    if (stats) {
-        const double m = stats[2 * c] / count;
-        double var = stats[2 * c + 1] / count - m * m;
+    if (stats || partial) {
+        double s0, s1;
+        channel_sums(stats, partial, S, c, s0, s1);
+        const double m = s0 / count;
+        double var = s1 / count - m * m;
         var = var < 0.0 ? 0.0 : var;
         mean = (float)m;
         invstd = (float)(1.0 / sqrt(var + (double)eps));
@@ -208,14 +232,16 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ d
 __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy, const float *__restrict__ y,
                                                    const float *__restrict__ x, const float *__restrict__ weight,
                                                    const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
-                                                   const double *__restrict__ sums, double count, float *__restrict__ dx,
+                                                   const double *__restrict__ sums, const double *__restrict__ partial, int S,
+                                                   double count, float *__restrict__ dx,
                                                    float *__restrict__ dres, float *__restrict__ dweight,
                                                    float *__restrict__ dbias, Plane g)
 {
     const int c = blockIdx.y;
     const int b = blockIdx.x / g.cpp, k = blockIdx.x - b * g.cpp;
     const float mean = save_mean[c], invstd = save_invstd[c];
-    const double s0 = sums[2 * c], s1 = sums[2 * c + 1];
+    double s0, s1;
+    channel_sums(sums, partial, S, c, s0, s1);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
         if (dweight) dweight[c] = (float)(s1 * (double)invstd);
         if (dbias) dbias[c] = (float)s0;
@@ -299,8 +325,9 @@ int dcd_bn_train_apply(void *stream_, const float *x, const float *residual, con
     if (!x || !y || !stats || !save_mean || !save_invstd || bad_shape(B, C, HW) || !(count >= 1.0)) return DCD_ERR_BAD_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return DCD_ERR_BAD_ARG;
     const Plane g = make_plane(B, C, HW);
-    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, stats, count, running_mean,
-                       running_var, (long long *)num_batches_tracked, momentum, eps, relu, y, save_mean, save_invstd, g);
+    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, stats, (const double *)nullptr, 0,
+                       count, running_mean, running_var, (long long *)num_batches_tracked, momentum, eps, relu, y, save_mean,
+                       save_invstd, g);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
@@ -312,7 +339,8 @@ int dcd_bn_eval_apply(void *stream_, const float *x, const float *residual, cons
     (void)hipGetLastError();
     if (!x || !y || !running_mean || !running_var || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
     const Plane g = make_plane(B, C, HW);
-    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, (const double *)nullptr, 1.0,
+    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, (const double *)nullptr,
+                       (const double *)nullptr, 0, 1.0,
                        const_cast<float *>(running_mean), const_cast<float *>(running_var), (long long *)nullptr, 0.f, eps,
                        relu, y, (float *)nullptr, (float *)nullptr, g);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
@@ -342,7 +370,45 @@ int dcd_bn_backward_apply(void *stream_, const float *grad_y, const float *y, co
         return DCD_ERR_BAD_ARG;
     const Plane g = make_plane(B, C, HW);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd, sums,
-                       count, grad_x, grad_residual, grad_weight, grad_bias, g);
+                       (const double *)nullptr, 0, count, grad_x, grad_residual, grad_weight, grad_bias, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+/* Local (single-rank) training forward: statistics + apply in two launches, no combine pass, no stats tensor. */
+int dcd_bn_train_forward(void *stream_, const float *x, const float *residual, const float *weight, const float *bias,
+                         float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                         int relu, float *y, float *save_mean, float *save_invstd, int B, int C, int64_t HW, void *ws,
+                         size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !y || !save_mean || !save_invstd || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
+    hipLaunchKernelGGL(bn_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, x, residual, weight, bias, (const double *)nullptr,
+                       (const double *)ws, S, (double)B * (double)HW, running_mean, running_var, (long long *)num_batches_tracked,
+                       momentum, eps, relu, y, save_mean, save_invstd, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+/* Local backward: sums + apply in two launches. */
+int dcd_bn_backward(void *stream_, const float *grad_y, const float *y, const float *x, const float *weight,
+                    const float *save_mean, const float *save_invstd, float *grad_x, float *grad_residual, float *grad_weight,
+                    float *grad_bias, int B, int C, int64_t HW, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !save_invstd || !grad_x || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws);
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd,
+                       (const double *)nullptr, (const double *)ws, S, (double)B * (double)HW, grad_x, grad_residual, grad_weight,
+                       grad_bias, g);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

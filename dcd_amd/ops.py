@@ -264,21 +264,26 @@ class _BatchNormAct(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dev, st = x.device, _lib.stream_of(x)
-        stats = torch.empty((C, 2), dtype=torch.float64, device=dev)
         ws = _bn_ws(C, dev)
-        _lib.check(L.dcd_bn_stats(st, x.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
         count = float(B * HW)
-        if group is not None:
-            import torch.distributed as dist
-            dist.all_reduce(stats, group=group)
-            count *= dist.get_world_size(group)
         y = torch.empty_like(x)
         save_mean = torch.empty(C, dtype=torch.float32, device=dev)
         save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
-        _lib.check(L.dcd_bn_train_apply(st, x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias), stats.data_ptr(),
-                                        count, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
-                                        float(momentum), float(eps), int(bool(relu)), y.data_ptr(), save_mean.data_ptr(),
-                                        save_invstd.data_ptr(), B, C, HW), "dcd_bn_train_apply")
+        if group is None:
+            _lib.check(L.dcd_bn_train_forward(st, x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias),
+                                              _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                              float(momentum), float(eps), int(bool(relu)), y.data_ptr(), save_mean.data_ptr(),
+                                              save_invstd.data_ptr(), B, C, HW, ws.data_ptr(), ws.numel()), "dcd_bn_train_forward")
+        else:
+            import torch.distributed as dist
+            stats = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            _lib.check(L.dcd_bn_stats(st, x.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
+            dist.all_reduce(stats, group=group)
+            count *= dist.get_world_size(group)
+            _lib.check(L.dcd_bn_train_apply(st, x.data_ptr(), _lib.ptr(residual), _lib.ptr(weight), _lib.ptr(bias), stats.data_ptr(),
+                                            count, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                            float(momentum), float(eps), int(bool(relu)), y.data_ptr(), save_mean.data_ptr(),
+                                            save_invstd.data_ptr(), B, C, HW), "dcd_bn_train_apply")
         ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
         ctx.count, ctx.group, ctx.has_res = count, group, residual is not None
         return y
@@ -292,31 +297,31 @@ class _BatchNormAct(torch.autograd.Function):
         B, C = x.shape[0], x.shape[1]
         HW = x.numel() // (B * C)
         dev, st = x.device, _lib.stream_of(x)
-        sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
         ws = _bn_ws(C, dev)
-        _lib.check(L.dcd_bn_backward_stats(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), save_mean.data_ptr(), B, C, HW,
-                                           sums.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_backward_stats")
-        gw = gb = None
-        if ctx.group is not None:
-            # weight / bias gradients stay local (DDP averages them); the input gradient needs the global sums
-            import torch.distributed as dist
-            gw = (sums[:, 1] * save_invstd.double()).float()
-            gb = sums[:, 0].float()
-            dist.all_reduce(sums, group=ctx.group)
-        else:
-            gw = torch.empty(C, dtype=torch.float32, device=dev)
-            gb = torch.empty(C, dtype=torch.float32, device=dev)
         gx = torch.empty_like(x)
         want_res = ctx.has_res and ctx.needs_input_grad[1]
         gres = None
         if want_res:
             gres = torch.empty_like(x) if y is not None else gy      # no ReLU: d(residual) is grad_y itself
-        local = ctx.group is None
-        _lib.check(L.dcd_bn_backward_apply(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
-                                           save_invstd.data_ptr(), sums.data_ptr(), ctx.count, gx.data_ptr(),
-                                           gres.data_ptr() if (want_res and y is not None) else None,
-                                           gw.data_ptr() if local else None, gb.data_ptr() if local else None, B, C, HW),
-                   "dcd_bn_backward_apply")
+        gres_ptr = gres.data_ptr() if (want_res and y is not None) else None
+        if ctx.group is None:
+            gw = torch.empty(C, dtype=torch.float32, device=dev)
+            gb = torch.empty(C, dtype=torch.float32, device=dev)
+            _lib.check(L.dcd_bn_backward(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
+                                         save_invstd.data_ptr(), gx.data_ptr(), gres_ptr, gw.data_ptr(), gb.data_ptr(), B, C, HW,
+                                         ws.data_ptr(), ws.numel()), "dcd_bn_backward")
+        else:
+            # weight / bias gradients stay local (DDP averages them); the input gradient needs the global sums
+            import torch.distributed as dist
+            sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            _lib.check(L.dcd_bn_backward_stats(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), save_mean.data_ptr(), B, C, HW,
+                                               sums.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_backward_stats")
+            gw = (sums[:, 1] * save_invstd.double()).float()
+            gb = sums[:, 0].float()
+            dist.all_reduce(sums, group=ctx.group)
+            _lib.check(L.dcd_bn_backward_apply(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
+                                               save_invstd.data_ptr(), sums.data_ptr(), ctx.count, gx.data_ptr(), gres_ptr, None, None,
+                                               B, C, HW), "dcd_bn_backward_apply")
         return (gx, gres, gw if weight is not None else None, gb if weight is not None else None,
                 None, None, None, None, None, None, None)
 

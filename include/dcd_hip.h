@@ -190,6 +190,17 @@ int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, con
                           const float *save_mean, const float *save_invstd, const double *sums, double count,
                           float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,
                           int64_t HW);
+/* Single-rank shortcuts (no statistics exchange): stats + apply fused into two launches, the apply kernels sum the
+ * partials of the two-stage reduction themselves.  Same arithmetic and outputs as the call pairs above with
+ * count = B*HW. */
+int dcd_bn_train_forward(void *stream, const float *x, const float *residual, const float *weight, const float *bias,
+                         float *running_mean, float *running_var, int64_t *num_batches_tracked, float momentum, float eps,
+                         int relu, float *y, float *save_mean, float *save_invstd, int B, int C, int64_t HW,
+                         void *workspace, size_t workspace_bytes);
+int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const float *x, const float *weight,
+                    const float *save_mean, const float *save_invstd, float *grad_x, float *grad_residual,
+                    float *grad_weight, float *grad_bias, int B, int C, int64_t HW, void *workspace,
+                    size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution without bias: forward and backward-data (Winograd

@@ -1,0 +1,31 @@
+"""Idle gaps between consecutive kernels in the last train step of a rocprofv3 rocpd db (steps delimited by the fused-Adam
+launches): prof_gaps.py <dir> [min_gap_us]"""
+import glob, sqlite3, sys
+f = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
+thr = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
+cur = sqlite3.connect(f).cursor()
+adam = [r[0] for r in cur.execute("select end from kernels where name like '%multi_tensor_apply%' order by end")]
+groups = []
+for e in adam:
+    if not groups or e - groups[-1] > 5e6:
+        groups.append(e)
+    else:
+        groups[-1] = e
+t0, t1 = groups[-2], groups[-1]
+rows = cur.execute("select name, start, end from kernels where start >= ? and end <= ? order by start", (t0, t1)).fetchall()
+busy = sum(e - s for _, s, e in rows)
+print("step window %.2f ms, kernel time %.2f ms, %d kernels" % ((t1 - t0) / 1e6, busy / 1e6, len(rows)))
+gaps = []
+prev_end, prev_name = t0, "(previous step)"
+for name, s, e in rows:
+    if s - prev_end > 0:
+        gaps.append((s - prev_end, prev_name, name, (s - t0) / 1e6))
+    if e > prev_end:
+        prev_end, prev_name = e, name
+tot = sum(g[0] for g in gaps)
+print("total idle %.2f ms in %d gaps; gaps >= %.0f us:" % (tot / 1e6, len(gaps), thr))
+small = sum(g[0] for g in gaps if g[0] < thr * 1e3)
+print("  sum of gaps below threshold: %.2f ms" % (small / 1e6))
+for g in sorted(gaps, reverse=True)[:25]:
+    if g[0] >= thr * 1e3:
+        print("  %8.1f us at %7.2f ms  after %-45s before %s" % (g[0] / 1e3, g[3], g[1].replace("(anonymous namespace)::", "")[:45], g[2].replace("(anonymous namespace)::", "")[:45]))
