@@ -181,25 +181,29 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #endif
         const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
+        // A operands of the chunk: 4 nu x 2 output blocks x 4 channel steps
+        f32x4 a0[4], a1[4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
-            // B column pair and signs:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
-            constexpr int CA[4] = {0, 1, 1, 1}, CB[4] = {2, 2, 2, 3};
-            constexpr float TA[4] = {1.f, 1.f, -1.f, 1.f}, TB[4] = {-1.f, 1.f, 1.f, -1.f};
-            const f32x4 a0 = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
-            const f32x4 a1 = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
+            a0[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
+            a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
+        }
 #pragma unroll
-            for (int s = 0; s < 4; ++s) {
-                const float *q1 = cp1 + 2 * s * WN_PLANE, *q2 = cp2 + 2 * s * WN_PLANE;
+        for (int s = 0; s < 4; ++s) {
+            // row transform once per channel step: t[b] = sa d[ra][b] + sb d[rb][b], b = 0..3 (four ds_read2_b32), then the
+            // four column combinations  nu 0: t0 - t2   1: t1 + t2   2: t2 - t1   3: t1 - t3
+            const float *q1 = cp1 + 2 * s * WN_PLANE, *q2 = cp2 + 2 * s * WN_PLANE;
 #ifdef WN_ABL_NOLDS
-                const float u1 = sa * (float)s, u2 = sb + (float)nu; (void)q1; (void)q2;
+            const float t0 = sa * (float)s, t1 = sb, t2 = sa + sb, t3 = (float)ck; (void)q1; (void)q2;
 #else
-                const float u1 = TA[nu] * q1[CA[nu]] + TB[nu] * q1[CB[nu]];
-                const float u2 = TA[nu] * q2[CA[nu]] + TB[nu] * q2[CB[nu]];
+            const float t0 = sa * q1[0] + sb * q2[0], t1 = sa * q1[1] + sb * q2[1];
+            const float t2 = sa * q1[2] + sb * q2[2], t3 = sa * q1[3] + sb * q2[3];
 #endif
-                const float val = sa * u1 + sb * u2;
-                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[s], val, acc[nu][0], 0, 0, 0);
-                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[s], val, acc[nu][1], 0, 0, 0);
+            const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[nu][s], v[nu], acc[nu][0], 0, 0, 0);
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[nu][s], v[nu], acc[nu][1], 0, 0, 0);
             }
         }
 #ifndef WN_ABL_NOSTAGE
