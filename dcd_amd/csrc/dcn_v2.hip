@@ -566,10 +566,19 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
+    // Workgroup-uniform escape for large learned offsets: when more than half of the (wave, tap) pairs hold a sample that
+    // left the window, the per-lane fallback below would redo most of the work on top of the LDS path -- so the LDS path is
+    // skipped and every sample of this tile goes through the global-memory path.
+    int wave_far_taps = 0;
+#pragma unroll
+    for (int t = 0; t < 9; ++t) wave_far_taps += __any((farbits >> t) & 1u) ? 1 : 0;
+    const bool global_mode = __syncthreads_count(lane < wave_far_taps) * 2 > 9 * TL_ROWS;
+    if (global_mode) farbits = pv ? 0x1ffu : 0u;
+
     commit(lds);
     __syncthreads();
 
-    for (int ck = 0; ck < nchunk; ++ck) {
+    for (int ck = 0; ck < (global_mode ? 0 : nchunk); ++ck) {
         const float *buf = lds + (ck & 1) * TL_BUF;
 #ifndef TL_ABL_NOSTAGE
         if (ck + 1 < nchunk) issue(ck + 1);
@@ -654,6 +663,14 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
 // tap, fall back to atomics inside dcn_bwd_data_f32 -- correct for any input, fast for realistic offsets.
 // ---------------------------------------------------------------------------------------------
 constexpr float TL_NEAR = 3.f;   // tiled kernels: |offset| below this stays inside every staged window
+// Device-side choice between "tiled kernel + far-only pass" and "generic kernel alone", taken identically by every kernel of
+// a call from the offset scan's result: when more than half of the 32-pixel tiles hold a far sample (large learned offsets),
+// the tiled kernels would mostly produce zeros and the far-only pass would redo nearly everything.
+__device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int total_tiles)
+{
+    return far_scal && (int64_t)far_scal[1] * 2 > (int64_t)total_tiles;
+}
+
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
 constexpr int INV_RCAP = 3;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
 constexpr int INV_OVERFLOW = 255;
@@ -1056,7 +1073,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
     int tile = bx * 4 + wave;
     // far-only mode (far_scal != nullptr): the tiled kernel produced grad_offset / grad_mask of every sample displaced by
     // less than TL_NEAR; this launch visits the listed tiles and OVERWRITES the entries of the remaining samples only.
-    const bool far_mode = far_scal != nullptr;
+    const bool far_mode = far_scal != nullptr && !far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32));   // else: everything
     if (far_mode) {
         const int tiles_per_img = (g.HoWo + 31) / 32;
         const int L = (b * (int)gridDim.x + bx) * 4 + wave;
@@ -1205,8 +1222,10 @@ __global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const flo
                                                                    const float *__restrict__ msk, const float *__restrict__ wb,
                                                                    const float *__restrict__ gy, float *__restrict__ gin,
                                                                    float *__restrict__ goff, float *__restrict__ gmsk, Geom g,
-                                                                   int tiles_x, int nsplit, InvLists inv)
+                                                                   int tiles_x, int nsplit, InvLists inv,
+                                                                   const unsigned *__restrict__ far_scal)
 {
+    if (far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32))) return;      // the generic kernel does the whole job instead
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [32][BD_PLANE]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -1402,7 +1421,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
 {
     // far-only mode (far_scal != nullptr): the tiled kernel took every sample with |offset| < TL_NEAR; this kernel adds the
     // rest, walking only the tiles dcn_offset_absmax listed (far_scal[1] of them; usually zero -> uniform early exit).
-    const bool far_only_absmax = far_scal != nullptr;
+    const bool far_only_absmax = far_scal != nullptr && !far_dominated(far_scal, g.B * tiles_per_img);          // else: everything
     if (far_only_absmax && far_scal[1] == 0u) return;
     extern __shared__ __attribute__((aligned(16))) float smem[];
     float *colT = smem;                       // [4][32][33]
@@ -1455,13 +1474,18 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     };
     float v[16][4], dyr[MB * 4];
     Tap s;
+    bool act_cur = true, act_next = true;      // does this wave contribute to tile ti / ti+1 (always, outside far-only mode)
     auto stage_gather = [&](int ti, const TapRaw &raw) {
         int b, P, Pc, ho, wo; bool pv;
         tile_coords(ti, b, P, pv, Pc, ho, wo);
         s = finish_tap(raw, g, t, ho, wo, pv && rbv);
         if (far_only_absmax && fabsf(raw.oh) < TL_NEAR && fabsf(raw.ow) < TL_NEAR) s.m = 0.f;     // near sample: already counted
+        // far-only mode: a listed tile usually has ONE far sample, i.e. eight of the nine taps (waves) have nothing to add:
+        // they skip their 64 gathers and 16*MB MFMAs and only keep the barriers and their share of the dY tile
+        act_next = !far_only_absmax || __any(s.m != 0.f);
         const float *in_g = in + ((size_t)b * g.C + (size_t)grp * g.cpg) * HW;
         const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
+        if (act_next)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int cc = blk * 32 + 2 * q + h;
@@ -1485,10 +1509,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     TapRaw raw_next = {0.f, 0.f, 0.f};
     if (t0 < t1) {
         stage_gather(t0, stage_raw(t0));
+        act_cur = act_next;
         if (t0 + 1 < t1) raw_next = stage_raw(t0 + 1);
     }
     for (int ti = t0; ti < t1; ++ti) {
         // registers of tile ti -> LDS: sampled columns colT[row][pixel], dY tile dyT[o][pixel]
+        const bool act = act_cur;
+        if (act)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
             const int row = 2 * q + h;
@@ -1504,11 +1531,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
             const TapRaw raw = raw_next;
             if (ti + 2 < t1) raw_next = stage_raw(ti + 2);
             stage_gather(ti + 1, raw);
+            act_cur = act_next;
         }
         // contraction over the 32 pixels of tile ti
 #ifdef DW_ABL_NOMFMA
         if (ti < 0)
 #endif
+        if (act)
 #pragma unroll 4
         for (int k = 0; k < 16; ++k) {
             const float a = myT[p * 33 + 2 * k + h];
@@ -1563,8 +1592,9 @@ constexpr int DW_NT = DW_TR * 3 * 64;                 // 384 threads
 __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                                 const float *__restrict__ msk, const float *__restrict__ gy,
                                                                 float *__restrict__ part, Geom g, int tiles_x, int tiles_y,
-                                                                int nsplit)
+                                                                int nsplit, const unsigned *__restrict__ far_scal)
 {
+    if (far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32))) return;      // the generic kernel does the whole job instead
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [DW_IN_FLOATS | DW_DY_FLOATS]
     float *win = lds, *dyt = lds + DW_IN_FLOATS;
     const int tid = threadIdx.x;
@@ -1756,8 +1786,10 @@ __global__ __launch_bounds__(DW_NT, 3) void dcn_bwd_weight_tile_f32(const float 
 
 // grad_weight[o][c][t] += sum over the pixel splits of the tiled kernel's partials.  grid.y split-groups each sum a slice
 // of the splits (coalesced over the 288-float rows) and add it to the zero-filled gradient: <= 16 atomics per address.
-__global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict__ gw, Geom g, int ncb, int nzo, int nsplit)
+__global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict__ gw, Geom g, int ncb, int nzo, int nsplit,
+                              const unsigned *__restrict__ far_scal)
 {
+    if (far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32))) return;      // no partials were written
     constexpr int PER = 2 * 32 * DW_CB * 9;                // floats per partial
     const int n = ncb * nzo * PER;
     const int s0 = (int)((int64_t)blockIdx.y * nsplit / gridDim.y), s1 = (int)((int64_t)(blockIdx.y + 1) * nsplit / gridDim.y);
@@ -2027,10 +2059,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         dim3 gridt(tiles_x * tiles_y, B, nsp), blockt(BD_TR * 64);
         if (g.Cop == 64)
             hipLaunchKernelGGL(dcn_bwd_data_tile_f32<32>, gridt, blockt, ldsb, stream, input, offset, mask, wb, grad_output, grad_input,
-                               grad_offset, grad_mask, g, tiles_x, nsp, inv);
+                               grad_offset, grad_mask, g, tiles_x, nsp, inv, (const unsigned *)absmax);
         else
             hipLaunchKernelGGL(dcn_bwd_data_tile_f32<64>, gridt, blockt, ldsb, stream, input, offset, mask, wb, grad_output, grad_input,
-                               grad_offset, grad_mask, g, tiles_x, nsp, inv);
+                               grad_offset, grad_mask, g, tiles_x, nsp, inv, (const unsigned *)absmax);
         bd_tiled = true;
     }
 #endif
@@ -2066,10 +2098,11 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (S < 1) S = 1;
         if (S > total) S = total;
         hipLaunchKernelGGL(dcn_bwd_weight_tile_f32, dim3(ncb, S, nzo), dim3(DW_NT), ldsb, stream, input, offset, mask, grad_output,
-                           dw_part, g, tiles_x, tiles_y, S);
+                           dw_part, g, tiles_x, tiles_y, S, (const unsigned *)absmax);
         const int nred = ncb * nzo * 2 * 32 * DW_CB * 9;
         const int rgroups = S >= 16 ? 16 : S;
-        hipLaunchKernelGGL(dcn_dw_reduce, dim3((nred + 255) / 256, rgroups), dim3(256), 0, stream, dw_part, grad_weight, g, ncb, nzo, S);
+        hipLaunchKernelGGL(dcn_dw_reduce, dim3((nred + 255) / 256, rgroups), dim3(256), 0, stream, dw_part, grad_weight, g, ncb, nzo, S,
+                           (const unsigned *)absmax);
         dw_tiled = true;
     }
 #endif

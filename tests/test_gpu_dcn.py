@@ -43,6 +43,7 @@ CASES = [
     (2, 64, 64, 24, 64, 1, 0.5),     # sub-pixel offsets: everything from the staged window
     (1, 12, 70, 17, 36, 1, 1.5),     # ragged: C % 8 != 0, Cout > 64 with a partial slice, partial tiles, some far samples
     (1, 32, 64, 16, 32, 1, 4.0),     # many samples beyond the 3-px window -> per-lane global fallback
+    (2, 64, 64, 16, 64, 1, 12.0),    # offsets of many pixels everywhere: tiled kernels stand down (device-side switch)
 ]
 
 
