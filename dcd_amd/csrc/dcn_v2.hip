@@ -316,6 +316,24 @@ __global__ __launch_bounds__(256) void dcn_fwd_f32(const float *__restrict__ in,
     }
 }
 
+// ---- constants of the workgroup-tiled forward (defined here: the rescue mode of dcn_fwd9_f32 reads its weight layout)
+constexpr int TL_WW = 40;                   // window cols  c0-4 .. c0+35 (16-byte aligned rows)
+constexpr int TL_CH = 8;                    // channels per chunk
+constexpr int TL_OB = 64;                   // output channels per workgroup (two 32-wide MFMA blocks)
+constexpr int TL_W_FLOATS = 9 * TL_OB * TL_CH;            // 4608: [tap][o][h][4 steps]
+constexpr int TL_NW = TL_W_FLOATS / 4;                    // 1152 dwordx4 per chunk (weights)
+// TR = waves per workgroup = tile rows (8: 16-row window, 1 workgroup / CU; 4: 12-row window, 2 workgroups / CU)
+template <int TR> struct TileCfg {
+    static constexpr int WH = TR + 8;                             // window rows r0-4 .. r0+TR+3
+    static constexpr int PLANE = (WH * TL_WW) % 64 == 32 ? WH * TL_WW : WH * TL_WW + 32;   // odd/even planes 32 banks apart
+    static constexpr int IN_FLOATS = TL_CH * PLANE;
+    static constexpr int BUF = IN_FLOATS + TL_W_FLOATS;           // floats per buffer
+    static constexpr int NIN = TL_CH * WH * (TL_WW / 4);          // dwordx4 per chunk (window)
+    static constexpr int NT = TR * 64;                            // threads
+    static constexpr int KIN = (NIN + NT - 1) / NT, KW = (TL_NW + NT - 1) / NT;
+};
+
+
 // ---------------------------------------------------------------------------------------------
 // Forward, 3x3 fast path: CHANNEL-outer / TAP-inner.
 // The generic kernel above walks every channel plane once per tap, so a wave's reuse distance is Cin planes and
@@ -333,22 +351,42 @@ __global__ void dcn_prep_weights9(const float *__restrict__ w, float *__restrict
     }
 }
 
-template <int MB>
+// RESCUE = true: second pass of the tiled forward.  Waves map to (row, 32-column segment) of the tiled kernel's regions and
+// run only where that kernel flagged its region as dominated by far samples (rescue_flags, rows_per_region).
+template <int MB, bool RESCUE = false>
 __global__ __launch_bounds__(256) void dcn_fwd9_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                     const float *__restrict__ msk, const float *__restrict__ wf9,
-                                                    const float *__restrict__ bias, float *__restrict__ out, Geom g)
+                                                    const float *__restrict__ bias, float *__restrict__ out, Geom g,
+                                                    const unsigned char *__restrict__ rescue_flags = nullptr, int tiles_x = 0,
+                                                    int rows_per_region = 0, int nchunk = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     int bx = blockIdx.x, b = blockIdx.y;
     xcd_remap(bx, b);
     const int tile = bx * 4 + wave;
-    if (tile * 32 >= g.HoWo) return;
     const int ob0 = blockIdx.z * MB;
-    const int P = tile * 32 + p;
-    const bool pv = P < g.HoWo;
-    const int Pc = pv ? P : g.HoWo - 1;
-    const int ho = Pc / g.Wo, wo = Pc - ho * g.Wo;
+    int P, ho, wo;
+    bool pv;
+    if (RESCUE) {
+        const int row = tile / tiles_x, cseg = tile - row * tiles_x;
+        if (row >= g.Ho) return;
+        const int regions_y = (g.Ho + rows_per_region - 1) / rows_per_region;
+        if (!rescue_flags[((size_t)b * regions_y + row / rows_per_region) * tiles_x + cseg]) return;
+        ho = row;
+        wo = cseg * 32 + p;
+        pv = wo < g.Wo;
+        if (!pv) wo = g.Wo - 1;
+        P = ho * g.Wo + wo;
+    } else {
+        if (tile * 32 >= g.HoWo) return;
+        P = tile * 32 + p;
+        pv = P < g.HoWo;
+        if (!pv) P = g.HoWo - 1;
+        ho = P / g.Wo;
+        wo = P - ho * g.Wo;
+    }
+    const int Pc = P;
     const unsigned HW4 = (unsigned)(g.H * g.W) * 4u;
     const unsigned Cop4 = (unsigned)g.Cop * 4u;
 
@@ -416,7 +454,7 @@ __global__ __launch_bounds__(256) void dcn_fwd9_f32(const float *__restrict__ in
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
             const int o = obase + (r & 3) + 8 * (r >> 2);
-            if (pv && o < g.Co) out_b[(size_t)o * g.HoWo + P] = acc[mb][r] + bias[o];
+            if (pv && o < g.Co) out_b[(size_t)o * g.HoWo + Pc] = acc[mb][r] + bias[o];
         }
     }
 }
@@ -438,27 +476,20 @@ __global__ __launch_bounds__(256) void dcn_fwd9_f32(const float *__restrict__ in
 //   * each bilinear corner pair is one ds_read2_b32.  Samples displaced by 3 px or more fall outside the window and are
 //     gathered from global memory by their lane after the chunk loop (correct for any offset, fast for realistic ones).
 // ---------------------------------------------------------------------------------------------
-constexpr int TL_WW = 40;                   // window cols  c0-4 .. c0+35 (16-byte aligned rows)
-constexpr int TL_CH = 8;                    // channels per chunk
-constexpr int TL_OB = 64;                   // output channels per workgroup (two 32-wide MFMA blocks)
-constexpr int TL_W_FLOATS = 9 * TL_OB * TL_CH;            // 4608: [tap][o][h][4 steps]
-constexpr int TL_NW = TL_W_FLOATS / 4;                    // 1152 dwordx4 per chunk (weights)
-// TR = waves per workgroup = tile rows (8: 16-row window, 1 workgroup / CU; 4: 12-row window, 2 workgroups / CU)
-template <int TR> struct TileCfg {
-    static constexpr int WH = TR + 8;                             // window rows r0-4 .. r0+TR+3
-    static constexpr int PLANE = (WH * TL_WW) % 64 == 32 ? WH * TL_WW : WH * TL_WW + 32;   // odd/even planes 32 banks apart
-    static constexpr int IN_FLOATS = TL_CH * PLANE;
-    static constexpr int BUF = IN_FLOATS + TL_W_FLOATS;           // floats per buffer
-    static constexpr int NIN = TL_CH * WH * (TL_WW / 4);          // dwordx4 per chunk (window)
-    static constexpr int NT = TR * 64;                            // threads
-    static constexpr int KIN = (NIN + NT - 1) / NT, KW = (TL_NW + NT - 1) / NT;
-};
-
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
 // Wl[z][chunk][tap][o(64)][h(2)][s(4)] = W[z*64+o][chunk*8 + 2s + h][tap]   (zero padded)
-__global__ void dcn_prep_weights_tile(const float *__restrict__ w, float *__restrict__ wl, Geom g, int nchunk, int nz)
+__global__ void dcn_prep_weights_tile(const float *__restrict__ w, float *__restrict__ wl, Geom g, int nchunk, int nz,
+                                      unsigned *__restrict__ flags, int nflag_words, float *__restrict__ wf9)
 {
+    for (int i = blockIdx.x * blockDim.x + threadIdx.x; i < nflag_words; i += gridDim.x * blockDim.x) flags[i] = 0u;
+    if (wf9) {                                   // weights of the rescue pass (dcn_fwd9_f32 layout [c*9+t][Cout_pad])
+        const int K = g.C * 9, n9 = K * g.Cop;
+        for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n9; idx += gridDim.x * blockDim.x) {
+            const int k = idx / g.Cop, o = idx - k * g.Cop;
+            wf9[idx] = (o < g.Co) ? w[(size_t)o * K + k] : 0.f;
+        }
+    }
     const int n = nz * nchunk * TL_W_FLOATS;
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         int r = idx;
@@ -476,7 +507,8 @@ template <int TR>
 __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                         const float *__restrict__ msk, const float *__restrict__ wl,
                                                         const float *__restrict__ bias, float *__restrict__ out, Geom g,
-                                                        int tiles_x, int nchunk)
+                                                        int tiles_x, int nchunk, unsigned char *__restrict__ rescue_flags,
+                                                        const float *__restrict__ wf9)
 {
     typedef TileCfg<TR> T;
     constexpr int TL_ROWS = TR, TL_WH = T::WH, TL_PLANE = T::PLANE, TL_IN_FLOATS = T::IN_FLOATS, TL_BUF = T::BUF,
@@ -566,19 +598,26 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-    // Workgroup-uniform escape for large learned offsets: when more than half of the (wave, tap) pairs hold a sample that
-    // left the window, the per-lane fallback below would redo most of the work on top of the LDS path -- so the LDS path is
-    // skipped and every sample of this tile goes through the global-memory path.
+    // Workgroup-uniform escape for large learned offsets: when more than a quarter of the (wave, tap) pairs hold a sample that
+    // left the window, the per-lane fallback below would redo most of the work on top of the LDS path -- the region is
+    // flagged instead and left to the register-gather kernel that the host launches right after this one (rescue mode).
     int wave_far_taps = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) wave_far_taps += __any((farbits >> t) & 1u) ? 1 : 0;
-    const bool global_mode = __syncthreads_count(lane < wave_far_taps) * 2 > 9 * TL_ROWS;
-    if (global_mode) farbits = pv ? 0x1ffu : 0u;
+    __shared__ int far_pairs;
+    if (tid == 0) far_pairs = 0;
+    __syncthreads();
+    if (lane == 0) atomicAdd(&far_pairs, wave_far_taps);
+    __syncthreads();
+    if (far_pairs * 4 > 9 * TL_ROWS) {      // > 25 % of the (wave, tap) pairs: the serial per-lane fallback would dominate
+        if (tid == 0) rescue_flags[(size_t)b * gridDim.x + bx] = 1;      // dcn_fwd9_f32<2, true> computes this region
+        return;
+    }
 
     commit(lds);
     __syncthreads();
 
-    for (int ck = 0; ck < (global_mode ? 0 : nchunk); ++ck) {
+    for (int ck = 0; ck < nchunk; ++ck) {
         const float *buf = lds + (ck & 1) * TL_BUF;
 #ifndef TL_ABL_NOSTAGE
         if (ck + 1 < nchunk) issue(ck + 1);
@@ -623,15 +662,32 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
             if (!__any((farbits >> t) & 1u)) continue;
             const bool mine = (farbits >> t) & 1u;
             const Tap s = make_tap(off_b, msk_b, g, t, t, ho, wo, Pc, pv);
-            for (int c = h; c < ((g.C + 1) & ~1); c += 2) {
-                const bool live = mine && c < g.C;
-                const float *gp = in_b + (size_t)(live ? c : 0) * HW;
-                const f32x2 gt = ldg2(gp, (unsigned)s.pt * 4u), gb = ldg2(gp, (unsigned)s.pb * 4u);
-                const float val = live ? (s.a0 * gt.x + s.a1 * gt.y + s.b0 * gb.x + s.b1 * gb.y) * s.m : 0.f;
-                const int ck = c >> 3, st = (c & 7) >> 1;
-                const float *wr = wl_z + (size_t)ck * TL_W_FLOATS + ((size_t)(t * TL_OB + p) * 2 + h) * 4 + st;
-                acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[0], val, acc[0], 0, 0, 0);
-                acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wr[32 * 8], val, acc[1], 0, 0, 0);
+            // weights from the coalesced rescue layout Wf9[c*9+t][Cout_pad]; loads of four channel pairs are issued together
+            const float *w9 = wf9 + (size_t)t * g.Cop + z * TL_OB + p;
+            const bool second = z * TL_OB + 32 < g.Cop;
+            const int cend = (g.C + 1) & ~1;
+            for (int c0 = h; c0 < cend; c0 += 8) {
+                f32x2 gt[4], gb[4];
+                float wa[4], wb2[4];
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 2 * u;
+                    const int cc = c < g.C ? c : g.C - 1;
+                    const float *gp = in_b + (size_t)cc * HW;
+                    gt[u] = ldg2(gp, (unsigned)s.pt * 4u);
+                    gb[u] = ldg2(gp, (unsigned)s.pb * 4u);
+                    const float *wr = w9 + (size_t)cc * 9 * g.Cop;
+                    wa[u] = wr[0];
+                    wb2[u] = second ? wr[32] : 0.f;
+                }
+#pragma unroll
+                for (int u = 0; u < 4; ++u) {
+                    const int c = c0 + 2 * u;
+                    const bool live = mine && c < g.C;
+                    const float val = live ? (s.a0 * gt[u].x + s.a1 * gt[u].y + s.b0 * gb[u].x + s.b1 * gb[u].y) * s.m : 0.f;
+                    acc[0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[u], val, acc[0], 0, 0, 0);
+                    acc[1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb2[u], val, acc[1], 0, 0, 0);
+                }
             }
         }
     }
@@ -1894,17 +1950,38 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                     return DCD_ERR_LAUNCH;
                 attr_set = true;
             }
-            hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
-                               dim3(256), 0, stream, weight, wf, g, nchunk, nz);
             const int tiles_x = (g.Wo + 31) / 32;
             const bool rows8 = tile_rows == 8 && (int64_t)tiles_x * ((g.Ho + 7) / 8) * B * nz >= 512;
-            if (rows8)
-                hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(tiles_x * ((g.Ho + 7) / 8), B, nz), dim3(512),
-                                   2 * TileCfg<8>::BUF * sizeof(float), stream, input, offset, mask, wf, bias, output, g, tiles_x, nchunk);
-            else
-                hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(tiles_x * ((g.Ho + 3) / 4), B, nz), dim3(256),
-                                   2 * TileCfg<4>::BUF * sizeof(float), stream, input, offset, mask, wf, bias, output, g, tiles_x, nchunk);
-            return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+            const int TRr = rows8 ? 8 : 4;
+            const int regions = tiles_x * ((g.Ho + TRr - 1) / TRr);
+            // region flags ("far samples dominate here: left to the rescue pass") live behind the weight area
+            const int nflag_words = (B * regions + 3) / 4;
+            unsigned char *flags = (unsigned char *)(wf + 2 * nw);
+            const size_t n9 = (size_t)Cin * 9 * g.Cop;
+            if (nwl <= nw && n9 <= nw && workspace_bytes >= 2 * nw * sizeof(float) + (size_t)nflag_words * 4) {
+                float *wf9 = wf + nw;                         // [Wl | Wf9 | flags]
+                hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
+                                   dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
+                if (rows8)
+                    hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9);
+                else
+                    hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(regions, B, nz), dim3(256), 2 * TileCfg<4>::BUF * sizeof(float), stream,
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9);
+                // rescue pass: register-gather kernel over the flagged regions only (usually none: its waves exit at once)
+                const int nb9 = g.Cop / 32, mb9 = nb9 >= 4 ? 4 : nb9 >= 2 ? 2 : 1;
+                dim3 gridr((tiles_x * g.Ho + 3) / 4, B, (nb9 + mb9 - 1) / mb9);
+                if (mb9 == 4)
+                    hipLaunchKernelGGL((dcn_fwd9_f32<4, true>), gridr, dim3(256), 0, stream, input, offset, mask, wf9, bias, output, g,
+                                       (const unsigned char *)flags, tiles_x, TRr, nchunk);
+                else if (mb9 == 2)
+                    hipLaunchKernelGGL((dcn_fwd9_f32<2, true>), gridr, dim3(256), 0, stream, input, offset, mask, wf9, bias, output, g,
+                                       (const unsigned char *)flags, tiles_x, TRr, nchunk);
+                else
+                    hipLaunchKernelGGL((dcn_fwd9_f32<1, true>), gridr, dim3(256), 0, stream, input, offset, mask, wf9, bias, output, g,
+                                       (const unsigned char *)flags, tiles_x, TRr, nchunk);
+                return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+            }
         }
     }
 #endif

@@ -5,7 +5,7 @@ shutil.copy(main, main + ".bak")
 try:
     for f in sorted(glob.glob(os.path.join(R, "tools", "micro", "libdcd_*.so"))):
         shutil.copy(f, main)
-        out = subprocess.run([sys.executable, os.path.join(R, "tools", "time_dcn_layers.py"), "8", "f32", "0.5"], capture_output=True, text=True).stdout
+        out = subprocess.run([sys.executable, os.path.join(R, "tools", "time_dcn_layers.py"), "8", "f32", os.environ.get("DCD_VAR_SCALE", "0.5")], capture_output=True, text=True).stdout
         print(os.path.basename(f))
         print("\n".join(l for l in out.splitlines() if "fwd" in l))
 finally:
