@@ -76,6 +76,43 @@ def enable_sync_bn(model, group=None):
     return model
 
 
+def step_schedulers(scheduler, warmup_scheduler, iteration, cfg):
+    """The reference's per-iteration rule (DGDE/engine/trainer.py:90-95,152-155): the cosine warm-up drives the learning rate
+    for the first SOLVER.WARMUP_STEPS iterations (when SOLVER.LR_WARMUP), the step-decay LambdaLR afterwards; both are stepped
+    with the absolute iteration number."""
+    warmup_iters = cfg.SOLVER.WARMUP_STEPS if cfg.SOLVER.LR_WARMUP else -1
+    if iteration < warmup_iters:
+        warmup_scheduler.step(iteration)
+    else:
+        scheduler.step(iteration)
+
+
+def checkpoint_state(model, optimizer=None, scheduler=None, **extra):
+    """Checkpoint dict in the reference's layout (DGDE/utils/check_point.py:31-43): {'model', 'optimizer', 'scheduler'} plus
+    the trainer's extras ('iteration', 'iter_per_epoch', DGDE/engine/trainer.py:167-171).  The model's state-dict keys equal the
+    reference's, so files written by either side load into the other."""
+    m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
+    data = {"model": m.state_dict()}
+    if optimizer is not None:
+        data["optimizer"] = optimizer.state_dict()
+    if scheduler is not None and hasattr(scheduler, "state_dict"):
+        data["scheduler"] = scheduler.state_dict()
+    data.update(extra)
+    return data
+
+
+def load_checkpoint_state(data, model, optimizer=None, scheduler=None):
+    """Inverse of checkpoint_state; returns the extras (iteration, iter_per_epoch, ...)."""
+    m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
+    data = dict(data)
+    m.load_state_dict(data.pop("model"))
+    if optimizer is not None and "optimizer" in data:
+        optimizer.load_state_dict(data.pop("optimizer"))
+    if scheduler is not None and "scheduler" in data:
+        scheduler.load_state_dict(data.pop("scheduler"))
+    return data
+
+
 def wrap_distributed(model, cfg, local_rank):
     """SyncBN (when MODEL.USE_SYNC_BN) + DistributedDataParallel over RCCL.  Unlike the reference no unused-parameter
     search is needed (the ImageNet `fc` is never attached), and gradients live in the all-reduce buckets."""

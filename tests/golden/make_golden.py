@@ -239,6 +239,36 @@ def golden_gen_data():
          keys=np.array(list(gd.keys())))
 
 
+def golden_solver():
+    """Trainer harness: per-parameter learning rates, the warm-up / step-decay schedule driven exactly as
+    DGDE/engine/trainer.py:152-155 drives it, and one AdamW step -- from the reference's own solver package.
+    `solver/fastai_optim.py:3` needs `collections.Iterable` (removed in Python 3.10): aliased to collections.abc.Iterable."""
+    import collections, collections.abc
+    collections.Iterable = collections.abc.Iterable
+    from solver import build_optimizer, build_scheduler
+    cfg = ref_cfg(["SOLVER.LR_WARMUP", True, "SOLVER.WARMUP_STEPS", 200, "SOLVER.MAX_ITERATION", 3000, "SOLVER.STEPS", (2000, 2600)])
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    opt = build_optimizer(net, cfg)
+    sched, warm = build_scheduler(opt, 100, cfg.SOLVER)
+    x = torch.linspace(-1, 1, 24).reshape(4, 6)
+    lrs_w, lrs_b = [], []
+    for it in range(3000):
+        if it < 3:
+            opt.zero_grad()
+            net(x).square().sum().backward()
+            opt.step()
+        if it < cfg.SOLVER.WARMUP_STEPS:
+            warm.step(it)
+        else:
+            sched.step(it)
+        lrs_w.append(opt.param_groups[0]["lr"])      # first parameter is a weight, second a bias
+        lrs_b.append(opt.param_groups[1]["lr"])
+    save("solver", lr_weight=np.array(lrs_w), lr_bias=np.array(lrs_b),
+         params_after_3_steps=np.concatenate([p.detach().numpy().ravel() for p in net.parameters()]),
+         n_groups=np.array(len(opt.param_groups)))
+
+
 def golden_model():
     from model.detector import KeypointDetector
     cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
@@ -303,6 +333,7 @@ def main():
     golden_decode()
     golden_loss_computation()
     golden_gen_data()
+    golden_solver()
     golden_model()
 
 

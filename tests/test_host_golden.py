@@ -196,6 +196,46 @@ def test_gen_data_for_gmw_matches_reference(cpu_backend):
     check_gen_data(torch.device("cpu"), 2e-5)
 
 
+def test_solver_schedule_and_step_match_reference(tmp_path):
+    """learning-rate trace over 3000 iterations (cosine warm-up, then step decay, stepped with the absolute
+    iteration like the reference's loop), bias parameters at twice the rate, three AdamW steps, checkpoint round trip."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.engine.trainer import build_optimizer, build_scheduler, checkpoint_state, load_checkpoint_state, step_schedulers
+    g = load("solver")
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "SOLVER.LR_WARMUP", True, "SOLVER.WARMUP_STEPS", 200,
+                        "SOLVER.MAX_ITERATION", 3000, "SOLVER.STEPS", (2000, 2600)])
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    opt = build_optimizer(net, cfg)
+    sched, warm = build_scheduler(opt, cfg)
+    x = torch.linspace(-1, 1, 24).reshape(4, 6)
+    lw, lb = [], []
+    for it in range(3000):
+        if it < 3:
+            opt.zero_grad()
+            net(x).square().sum().backward()
+            opt.step()
+        step_schedulers(sched, warm, it, cfg)
+        lw.append(opt.param_groups[0]["lr"])       # ours: group 0 = weights, group 1 = biases
+        lb.append(opt.param_groups[1]["lr"])
+    np.testing.assert_allclose(np.array(lw), g["lr_weight"], rtol=1e-12, atol=0)
+    np.testing.assert_allclose(np.array(lb), g["lr_bias"], rtol=1e-12, atol=0)
+    got = np.concatenate([p.detach().numpy().ravel() for p in net.parameters()])
+    np.testing.assert_allclose(got, g["params_after_3_steps"], rtol=2e-6, atol=1e-7)
+    # checkpoint layout round trip
+    path = tmp_path / "model_checkpoint.pth"
+    torch.save(checkpoint_state(net, opt, sched, iteration=2999, iter_per_epoch=100), path)
+    data = torch.load(path, weights_only=False)
+    assert set(data) == {"model", "optimizer", "scheduler", "iteration", "iter_per_epoch"}
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    opt2 = build_optimizer(net2, cfg)
+    sched2, _ = build_scheduler(opt2, cfg)
+    extra = load_checkpoint_state(data, net2, opt2, sched2)
+    assert extra == {"iteration": 2999, "iter_per_epoch": 100}
+    assert all(torch.equal(a, b) for a, b in zip(net.state_dict().values(), net2.state_dict().values()))
+    assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
+
+
 def test_whole_model_matches_reference(cpu_backend):
     check_model(torch.device("cpu"), 2e-4, 2e-3)
 
