@@ -728,7 +728,8 @@ __device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int tota
 }
 
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
-constexpr int INV_RCAP = 3;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
+constexpr int INV_RCAP = 8;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
+constexpr int INV_RTILE = 3;    // the tiled grad_input kernel's dY window covers lists built with a radius up to this
 constexpr int INV_OVERFLOW = 255;
 
 struct InvLists {
@@ -806,7 +807,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             const float dw_ = ((float)(px * g.sw - g.pw + j * g.dw) + ow) - (float)qx;
             if (fabsf(dh_) < 1.f && fabsf(dw_) < 1.f) {
                 if (cnt < INV_CAP) {
-                    inv.idx[base + (size_t)cnt * HW] = inv.packed ? ((py << 16) | px) : P;
+                    inv.idx[base + (size_t)cnt * HW] = (inv.packed && rm1 <= INV_RTILE) ? ((py << 16) | px) : P;
                     inv.w[base + (size_t)cnt * HW] = (1.f - fabsf(dh_)) * (1.f - fabsf(dw_)) * m_p[P];
                 }
                 ++cnt;
@@ -818,8 +819,10 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
 // grid = (ceil(in_tiles/4), B, ceil(total_channel_blocks/MB)); lane = (input cell l&31, output-channel parity l>>5)
 template <int MB>
 __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict__ gy, const float *__restrict__ wb,
-                                                         InvLists inv, float *__restrict__ gin, Geom g)
+                                                         InvLists inv, float *__restrict__ gin, Geom g, int partner_of_tiled = 0)
 {
+    // launched next to the tiled kernel: exactly one of the two runs, decided by the same device scalar
+    if (partner_of_tiled && inv_radius(inv.absmax_bits) <= INV_RTILE) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int HW = g.H * g.W;
@@ -943,6 +946,7 @@ template <int MB>
 __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float *__restrict__ gy, const float *__restrict__ wb,
                                                                     InvLists inv, float *__restrict__ gin, Geom g, int tiles_x)
 {
+    if (inv_radius(inv.absmax_bits) > INV_RTILE) return;       // listed pixels may lie outside the window: generic kernel runs
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [BI_OC][BI_PLANE] window | [8 pairs][9][MB][2][32] weights
     float *wsl = lds + BI_OC * BI_PLANE;
     const int tid = threadIdx.x;
@@ -2108,11 +2112,11 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         int mbi = total_blocks >= 8 ? 8 : total_blocks >= 4 ? 4 : total_blocks >= 2 ? 2 : 1;
         while (mbi > 1 && (int64_t)in_tiles * B * ((total_blocks + mbi - 1) / mbi) < 1024) mbi >>= 1;
         dim3 grid((in_tiles + 3) / 4, B, (total_blocks + mbi - 1) / mbi), block(256);
-        if (bi_tiled) { /* done above */ }
-        else if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
-        else if (mbi == 4) hipLaunchKernelGGL(dcn_bwd_input_f32<4>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
-        else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
-        else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g);
+        const int partner = bi_tiled ? 1 : 0;     // with the tiled kernel launched, this one only runs when the lists are too wide for it
+        if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
+        else if (mbi == 4) hipLaunchKernelGGL(dcn_bwd_input_f32<4>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
+        else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
+        else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
     }
     {
         int splits = (int)(((int64_t)B * g.HoWo + 16383) / 16384);
