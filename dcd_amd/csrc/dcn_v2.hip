@@ -598,18 +598,20 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
 #pragma unroll
         for (int r = 0; r < 16; ++r) acc[mb][r] = 0.f;
 
-    // Workgroup-uniform escape for large learned offsets: when more than a quarter of the (wave, tap) pairs hold a sample that
-    // left the window, the per-lane fallback below would redo most of the work on top of the LDS path -- the region is
-    // flagged instead and left to the register-gather kernel that the host launches right after this one (rescue mode).
+    // Workgroup-uniform escape for large learned offsets: when samples that left the window are common, the per-lane fallback
+    // below would redo most of the work on top of the LDS path -- the region is flagged instead and left to the
+    // register-gather kernel that the host launches right after this one (rescue mode).
     int wave_far_taps = 0;
 #pragma unroll
     for (int t = 0; t < 9; ++t) wave_far_taps += __any((farbits >> t) & 1u) ? 1 : 0;
-    __shared__ int far_pairs;
-    if (tid == 0) far_pairs = 0;
+    // cost model: a far tap adds one serial pass over all channels to ITS wave (~12 % of the wave's main loop each), the
+    // rescue kernel costs ~1.7x the main loop -> hand the region over when the worst wave has five or more far taps
+    __shared__ int far_worst;
+    if (tid == 0) far_worst = 0;
     __syncthreads();
-    if (lane == 0) atomicAdd(&far_pairs, wave_far_taps);
+    if (lane == 0) atomicMax(&far_worst, wave_far_taps);
     __syncthreads();
-    if (far_pairs * 4 > 9 * TL_ROWS) {      // > 25 % of the (wave, tap) pairs: the serial per-lane fallback would dominate
+    if (far_worst >= 5) {
         if (tid == 0) rescue_flags[(size_t)b * gridDim.x + bx] = 1;      // dcn_fwd9_f32<2, true> computes this region
         return;
     }
