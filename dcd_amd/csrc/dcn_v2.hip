@@ -757,8 +757,8 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
                                   int *__restrict__ far_list)
 {
     float m = 0.f;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const float v = fabsf(off[i]);
+    auto visit = [&](int64_t i, float raw) {
+        const float v = fabsf(raw);
         m = fmaxf(m, v);
         if (!(v < TL_NEAR)) {                                      // rare
             const int64_t plane = i / HoWo;
@@ -768,10 +768,23 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
             const unsigned bit = 1u << (8 * (tid_ & 3));
             if ((atomicOr(word, bit) & bit) == 0u) far_list[atomicAdd(scal + 1, 1u)] = tid_;
         }
+    };
+    const int64_t n4 = ((uintptr_t)off & 15) == 0 ? n >> 2 : 0;     // 16-byte loads when the tensor allows it
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(off + 4 * i);
+        visit(4 * i, v.x); visit(4 * i + 1, v.y); visit(4 * i + 2, v.z); visit(4 * i + 3, v.w);
     }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        visit(i, off[i]);
+    // one atomic per block: thousands of same-address atomics serialise in L2 (the earlier per-wave version spent most of
+    // its 40 us there)
 #pragma unroll
     for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
-    if ((threadIdx.x & 63) == 0) atomicMax(scal, __float_as_uint(m));   // non-negative floats order like their bits
+    __shared__ float part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __syncthreads();
+    if (threadIdx.x == 0)
+        atomicMax(scal, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));   // non-negative floats order like their bits
 }
 
 // one thread per (input cell q, tap segment, image)
@@ -1100,12 +1113,21 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
 // every wave of the data kernel serialised in L2 and cost more than the whole MFMA work).
 __global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo)
 {
+    // block (o, split): split s walks its slice of every image's plane with 16-byte loads, no per-element index division
     const int o = blockIdx.x;
-    const int64_t n = (int64_t)B * HoWo;
+    const int nq = HoWo >> 2;                                  // float4 per plane (planes are 16-byte aligned when HoWo % 4 == 0)
+    const bool vec = (HoWo & 3) == 0;
     float acc = 0.f;
-    for (int64_t i = (int64_t)blockIdx.y * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.y * 256) {
-        const int64_t b = i / HoWo, pp = i - b * HoWo;
-        acc += gy[((size_t)b * Co + o) * HoWo + pp];
+    for (int b = 0; b < B; ++b) {
+        const float *p = gy + ((size_t)b * Co + o) * HoWo;
+        if (vec) {
+            for (int i = blockIdx.y * 256 + threadIdx.x; i < nq; i += gridDim.y * 256) {
+                const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * i);
+                acc += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (int i = blockIdx.y * 256 + threadIdx.x; i < HoWo; i += gridDim.y * 256) acc += p[i];
+        }
     }
 #pragma unroll
     for (int d = 32; d > 0; d >>= 1) acc += __shfl_xor(acc, d);
@@ -2079,8 +2101,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     // (1) search radius from max |offset|, (2) inverse sample lists, (3) grad_input by gather + MFMA (plain stores)
     {
         const int64_t noff = (int64_t)B * dg * 2 * g.KK * g.HoWo;
-        int gsz = (int)((noff + 1023) / 1024);
-        if (gsz > 1024) gsz = 1024;
+        int gsz = (int)((noff + 4095) / 4096);
+        if (gsz > 512) gsz = 512;
         hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
                            (g.HoWo + 31) / 32, far_flag, far_list);
         const int HWin = H * W;
@@ -2121,8 +2143,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
     }
     {
-        int splits = (int)(((int64_t)B * g.HoWo + 16383) / 16384);
-        if (splits > 64) splits = 64;
+        int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);      // >= 4 float4 per thread and image
+        if (splits > 32) splits = 32;
+        if (splits < 1) splits = 1;
         hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
     }
     // (4) grad_offset / grad_mask (+ atomic fallback for what the lists do not cover)
