@@ -2,7 +2,8 @@
 
 Same inputs ({'cls','reg'} + list of ParamsList), same 13 loss keys and log keys, same arithmetic per term.
 What changed is how it executes on the GPU:
-  * one object-selection index (`reg_mask.nonzero()`, a single host sync) replaces ~40 boolean-mask gathers;
+  * no host synchronisation at all in training: all B*M object slots are processed, empty ones masked out of every sum
+    (the reference compacts with ~40 boolean-mask gathers, each a sync); data generation keeps the compact lists;
     every later "loss[mask].sum()" is a masked sum, so no further sync happens inside the step;
   * focal / GIoU / POI gather / pair-depth solve / 3-D IoU are single HIP launches (dcd_amd.ops);
   * the log dict is materialised with ONE device->host copy instead of ~20 `.item()` calls (:589-630);
@@ -138,7 +139,7 @@ class Loss_Computation():
         """Dense-keypoint L1 terms and the pair-depth term (detector_loss.py:176-215), with masked sums."""
         m2d = pred_targets['extra_kpts_2d_mask'].float()
         m3d = pred_targets['extra_kpts_3d_mask'].float()
-        instance_num = m2d.shape[0]
+        instance_num = pred_targets['obj_valid'].sum()          # number of annotated objects (device scalar)
         scale = instance_num / batch_weight
         l2d = self.loss_weights['extra_kpts_2d_loss'] * self.extra_kpts_2d_loss_fnc(
             preds['extra_kpts_2d'], pred_targets['extra_kpts_2d'], pred_targets['depth_3D']) * m2d
@@ -176,9 +177,19 @@ class Loss_Computation():
 
         reg_mask_gt = tv["reg_mask"]
         flat_mask = reg_mask_gt.reshape(-1).bool()
-        sel = flat_mask.nonzero(as_tuple=True)[0]                # the one host sync of the loss
-        n_obj = sel.numel()
         M = reg_mask_gt.shape[1]
+        if self.is_gen:
+            sel = flat_mask.nonzero(as_tuple=True)[0]            # data generation needs the compact lists (host sync)
+            obj_valid = torch.ones_like(sel, dtype=torch.bool)
+        else:
+            # No host sync: every one of the B*M slots is processed.  Empty slots point at the first annotated object, so
+            # all arithmetic below stays finite, and `obj_valid` zeroes their contribution in every reduction -- the sums
+            # equal the reference's sums over the compacted object list (detector_loss.py:217-230).
+            slots = torch.arange(batch * M, device=flat_mask.device)
+            first = torch.argmax(flat_mask.to(torch.uint8))
+            sel = torch.where(flat_mask, slots, first)
+            obj_valid = flat_mask
+        n_obj = sel.numel()
 
         def pick(t, *shape):
             return t.reshape(batch * M, *shape).index_select(0, sel)
@@ -189,7 +200,7 @@ class Loss_Computation():
         boxes = pick(tv['bboxes'], 4)
         box_h, box_w = boxes[:, 3] - boxes[:, 1], boxes[:, 2] - boxes[:, 0]
         target_regression_2D = torch.cat((points - boxes[:, :2], boxes[:, 2:] - points), dim=1).float()
-        mask_regression_2D = (box_h > 0) & (box_w > 0)
+        mask_regression_2D = (box_h > 0) & (box_w > 0) & obj_valid
 
         target_clses = pick(tv["cls_ids"])
         target_depths_3D = pick(tv['locations'][..., -1])
@@ -222,8 +233,9 @@ class Loss_Computation():
                    'Calib_P': pick(tv["Calib_P"], 3, 4)}
         preds = {'reg_2D': pred_regression_2D, 'offset_3D': pred_offset_3D, 'orien_3D': pred_orientation_3D,
                  'dims_3D': pred_dimensions_3D}
-        reg_nums = {'reg_2D': mask_regression_2D.sum(), 'reg_3D': n_obj, 'reg_obj': n_obj}
+        reg_nums = {'reg_2D': mask_regression_2D.sum(), 'reg_3D': obj_valid.sum(), 'reg_obj': obj_valid.sum()}
         weights = {'object_weights': pick(tv["reg_weight"])}
+        targets['obj_valid'] = obj_valid
 
         if self.pred_direct_depth:
             preds['depth_3D'] = enc.decode_depth(pois[:, k2c('depth')].squeeze(-1), targets['Calib_P'])
@@ -253,7 +265,8 @@ class Loss_Computation():
             ek = pick(tv["extra_kpts_2d"], tv["extra_kpts_2d"].shape[2], 3)
             targets['extra_kpts_2d'] = ek[..., :2]
             targets['extra_kpts_3d'] = pick(tv["extra_kpts_3d"], tv["extra_kpts_3d"].shape[2], 3)
-            found = targets['find_pcl'].bool().unsqueeze(-1).expand_as(ek[..., 2])
+            targets['find_pcl'] = targets['find_pcl'].bool() & obj_valid
+            found = targets['find_pcl'].unsqueeze(-1).expand_as(ek[..., 2])
             targets['extra_kpts_2d_mask'] = (ek[..., 2] != 0) & found
             targets['extra_kpts_3d_mask'] = found
             reg_nums['extra_kpts_2d'] = targets['extra_kpts_2d_mask'].sum()
@@ -316,37 +329,38 @@ class Loss_Computation():
         reg_2D_loss = lw['bbox_loss'] * (giou_l * m2f).sum() / batch_weight
         iou_2D = (iou * m2f).sum() / torch.clamp(m2f.sum(), min=1)
 
+        ov = pt['obj_valid'].float()                             # 1 for annotated objects, 0 for the padded slots
         trunc = pt['trunc_mask_3D'].bool().float()
 
         # direct depth (+ aleatoric uncertainty)
         depth_3D_loss = lw['depth_loss'] * self.depth_loss(preds['depth_3D'], pt['depth_3D'], reduction='none')
-        real_depth_3D_loss = depth_3D_loss.detach().sum() / batch_weight
+        real_depth_3D_loss = (depth_3D_loss.detach() * ov).sum() / batch_weight
         if self.depth_with_uncertainty:
             depth_3D_loss = depth_3D_loss * torch.exp(-preds['depth_uncertainty']) + preds['depth_uncertainty'] * lw['depth_loss']
-        depth_3D_loss = depth_3D_loss.sum() / batch_weight
+        depth_3D_loss = (depth_3D_loss * ov).sum() / batch_weight
 
         # projected-centre offset; truncated objects use the log form
         off_l = self.reg_loss_fnc(preds['offset_3D'], pt['offset_3D'], reduction='none').sum(dim=1)
         if self.separate_trunc_offset:
             t_l = off_l if self.trunc_offset_loss_type == 'L1' else torch.log(1 + off_l)
-            trunc_offset_loss = lw['trunc_offset_loss'] * (t_l * trunc).sum() / batch_weight
-            offset_3D_loss = lw['offset_loss'] * (off_l * (1 - trunc)).sum() / batch_weight
+            trunc_offset_loss = lw['trunc_offset_loss'] * (t_l * trunc * ov).sum() / batch_weight
+            offset_3D_loss = lw['offset_loss'] * (off_l * (1 - trunc) * ov).sum() / batch_weight
         else:
-            offset_3D_loss = lw['offset_loss'] * off_l.sum() / batch_weight
+            offset_3D_loss = lw['offset_loss'] * (off_l * ov).sum() / batch_weight
 
         if self.multibin:
             orien_3D_loss = lw['orien_loss'] * Real_MultiBin_loss(preds['orien_3D'], pt['orien_3D'],
                                                                   num_bin=self.orien_bin_size,
-                                                                  row_mask=pt['ori_mask'].bool()) / batch_weight
+                                                                  row_mask=pt['ori_mask'].bool() & pt['obj_valid']) / batch_weight
         else:
             raise NotImplementedError("only INPUT.ORIENTATION == 'multi-bin' is on the DGDE path")
 
         dims_3D_loss = self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * \
             self.dim_weight.to(preds['dims_3D'])
-        dims_3D_loss = lw['dims_loss'] * dims_3D_loss.sum() / batch_weight
+        dims_3D_loss = lw['dims_loss'] * (dims_3D_loss.sum(dim=1) * ov).sum() / batch_weight
 
         with torch.no_grad():
-            pred_IoU_3D = get_iou_3d(preds['corners_3D'], pt['corners_3D']).mean()
+            pred_IoU_3D = (get_iou_3d(preds['corners_3D'], pt['corners_3D']) * ov).sum() / ov.sum()   # mean over the objects
 
         loss_dict = {'hm_loss': hm_loss, 'bbox_loss': reg_2D_loss, 'dims_loss': dims_3D_loss, 'orien_loss': orien_3D_loss,
                      'offset_loss': offset_3D_loss}
@@ -354,15 +368,15 @@ class Loss_Computation():
         if self.separate_trunc_offset:
             loss_dict['trunc_offset_loss'] = trunc_offset_loss
         if self.compute_corner_loss:
-            loss_dict['corner_loss'] = lw['corner_loss'] * self.reg_loss_fnc(
-                preds['corners_3D'], pt['corners_3D'], reduction='none').sum() / batch_weight
+            loss_dict['corner_loss'] = lw['corner_loss'] * (self.reg_loss_fnc(
+                preds['corners_3D'], pt['corners_3D'], reduction='none').sum(dim=(1, 2)) * ov).sum() / batch_weight
         if self.pred_direct_depth:
             loss_dict['depth_loss'] = depth_3D_loss
             log_tensors['depth_loss'] = real_depth_3D_loss
 
         if self.compute_keypoint_corner:
             kl = lw['keypoint_loss'] * self.keypoint_loss_fnc(preds['keypoints'], pt['keypoints'],
-                                                              reduction='none').sum(dim=2) * pt['keypoints_mask']
+                                                              reduction='none').sum(dim=2) * pt['keypoints_mask'] * ov[:, None]
             loss_dict['keypoint_loss'] = kl.sum() / batch_weight
 
         if self.compute_extra_kpts_corner:
@@ -375,32 +389,83 @@ class Loss_Computation():
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
             kd = preds['keypoints_depths']
             km = pt['keypoints_depth_mask'].bool().float()
+            ovk = ov[:, None]
             tgt = pt['depth_3D'].unsqueeze(-1).expand_as(kd)
             w = lw['keypoint_depth_loss']
             v_l = w * self.reg_loss_fnc(kd, tgt, reduction='none')
             i_l = w * self.reg_loss_fnc(kd.detach(), tgt, reduction='none')
-            log_tensors['keypoint_depth_loss'] = (v_l.detach() * km).sum() / batch_weight
+            log_tensors['keypoint_depth_loss'] = (v_l.detach() * km * ovk).sum() / batch_weight
             if self.corner_with_uncertainty:
                 cu = preds['corner_offset_uncertainty']
                 v_l = v_l * torch.exp(-cu) + w * cu
                 i_l = i_l * torch.exp(-cu)
-            v_sum = (v_l * km).sum() / batch_weight
-            i_sum = (i_l * (1 - km)).sum() / batch_weight
+            v_sum = (v_l * km * ovk).sum() / batch_weight
+            i_sum = (i_l * (1 - km) * ovk).sum() / batch_weight
             loss_dict['keypoint_depth_loss'] = v_sum + i_sum if self.modify_invalid_keypoint_depths else v_sum
 
-        # ---- logging: one device->host copy for every scalar
+        # ---- logging: one device->host copy for every scalar, made only when somebody reads the log dict (the reference
+        # calls .item() twenty times inside the forward, detector_loss.py:589-630).  Reading forces the sync and the
+        # reference's NaN/Inf check (:633-639: it drops into pdb; we raise).
         names = list(log_tensors) + [k for k in loss_dict if k not in log_tensors]
         vals = [log_tensors[k] if k in log_tensors else loss_dict[k].detach() for k in names]
         if self.compute_extra_kpts_corner:
             names.append('extra_all_MAE')
             vals.append(all_mae)
-        host = torch.stack([v.float().reshape(()) for v in vals]).tolist()
-        log_loss_dict = dict(zip(names, host))
-        for k in loss_dict:   # the reference drops into pdb on NaN/Inf (detector_loss.py:633-639); raise instead
-            v = log_loss_dict[k]
-            if v != v or v in (float('inf'), float('-inf')):
-                raise FloatingPointError("non-finite loss %s: %s" % (k, log_loss_dict))
-        return loss_dict, log_loss_dict
+        packed = torch.stack([v.float().reshape(()) for v in vals])
+        return loss_dict, LazyLogDict(names, packed, list(loss_dict))
+
+
+class LazyLogDict(dict):
+    """dict of Python floats that is filled from ONE device tensor on first access, so that building it does not
+    synchronise the host with the GPU in the middle of a train step."""
+
+    def __init__(self, names, packed, loss_keys):
+        super().__init__()
+        self._names, self._packed, self._loss_keys = names, packed, loss_keys
+
+    def _fill(self):
+        if self._packed is not None:
+            host = self._packed.tolist()
+            self._packed = None
+            super().update(zip(self._names, host))
+            for k in self._loss_keys:
+                v = super().__getitem__(k)
+                if v != v or v in (float('inf'), float('-inf')):
+                    raise FloatingPointError("non-finite loss %s: %s" % (k, dict(self)))
+
+    def __getitem__(self, k):
+        self._fill()
+        return super().__getitem__(k)
+
+    def __iter__(self):
+        self._fill()
+        return super().__iter__()
+
+    def __len__(self):
+        return len(self._names)
+
+    def __contains__(self, k):
+        return k in self._names
+
+    def keys(self):
+        self._fill()
+        return super().keys()
+
+    def values(self):
+        self._fill()
+        return super().values()
+
+    def items(self):
+        self._fill()
+        return super().items()
+
+    def get(self, k, default=None):
+        self._fill()
+        return super().get(k, default)
+
+    def __repr__(self):
+        self._fill()
+        return super().__repr__()
 
 
 def Real_MultiBin_loss(vector_ori, gt_ori, num_bin=4, row_mask=None):
