@@ -57,7 +57,7 @@ class Anno_Encoder():
     # ------------------------------------------------------------------------------------------
     def _calib_table(self, calibs, device):
         """(len(calibs), 6) float32 rows [c_u, c_v, f_u, f_v, b_x, b_y]; cached for the last list seen."""
-        key = (id(calibs), str(device))
+        key = (tuple(id(c) for c in calibs), str(device))      # the LIST is rebuilt every step, the Calibration objects are not
         if self._calib_cache[0] != key:
             rows = [[float(c.c_u), float(c.c_v), float(c.f_u), float(c.f_v), float(c.b_x), float(c.b_y)] for c in calibs]
             self._calib_cache = (key, torch.tensor(rows, dtype=torch.float32, device=device))
@@ -87,7 +87,9 @@ class Anno_Encoder():
         dims = dims.view(-1, 3)
         locs = locs.view(-1, 3)
         N = rotys.shape[0]
-        sign = self._corner_sign.to(device=dims.device, dtype=dims.dtype)
+        if self._corner_sign.device != dims.device or self._corner_sign.dtype != dims.dtype:   # one host->device copy, ever
+            self._corner_sign = self._corner_sign.to(device=dims.device, dtype=dims.dtype)
+        sign = self._corner_sign
         obj = (dims * 0.5).unsqueeze(-1) * sign.unsqueeze(0)              # (N,3,8): x<-l, y<-h, z<-w
         ry = self.rad_to_matrix(rotys, N).to(obj.dtype)
         box_3d = torch.matmul(ry, obj) + locs.unsqueeze(-1)

@@ -355,8 +355,9 @@ class Loss_Computation():
         else:
             raise NotImplementedError("only INPUT.ORIENTATION == 'multi-bin' is on the DGDE path")
 
-        dims_3D_loss = self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * \
-            self.dim_weight.to(preds['dims_3D'])
+        if self.dim_weight.device != preds['dims_3D'].device:      # one host->device copy, ever (a per-step copy from
+            self.dim_weight = self.dim_weight.to(preds['dims_3D'])  # pageable memory synchronises the stream)
+        dims_3D_loss = self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * self.dim_weight
         dims_3D_loss = lw['dims_loss'] * (dims_3D_loss.sum(dim=1) * ov).sum() / batch_weight
 
         with torch.no_grad():
