@@ -1,0 +1,130 @@
+// upsample.hip -- depthwise transposed convolution of IDAUp (DGDE/model/backbone/dla_dcn.py:412-438):
+//   nn.ConvTranspose2d(o, o, 2f, stride=f, padding=f/2, output_padding=0, groups=o, bias=False), f in {2, 4, 8},
+// the learnable bilinear up-sampling between the DCN projection and node convolutions (weights initialised by
+// fill_up_weights, :386-395).  MIOpen has no solver for it and falls back to naive / im2col kernels: the eight layers cost
+// 5.1 ms per bs-8 step (tools/time_upsample.py) for 4 multiply-adds per output element.  Here:
+//   forward        y[b,c,Y,X] = sum over the 2x2 inputs (iy, ix) whose kernel window covers (Y, X) of x * w[c, Y+p-iy f, X+p-ix f]
+//   backward       one pass over grad_y per input element: its (2f)^2 patch gives grad_x (dot with w) and the element's
+//                  contribution to grad_w (x * patch), reduced per block and added with (2f)^2 atomics per block.
+// All HBM-bound (forward: one write of y; backward: one read of grad_y); NCHW fp32, one (b, c) plane chunk per workgroup.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/dcd_hip.h"
+
+namespace {
+
+// grid = (ceil(Ho*Wo / 1024), B*C); 256 threads x 4 outputs (consecutive X)
+template <int F>
+__global__ __launch_bounds__(256) void up_dw_fwd(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                 int C, int H, int W)
+{
+    constexpr int K = 2 * F, P = F / 2;
+    __shared__ float ws[K * K];
+    const int plane = blockIdx.y, c = plane % C;
+    for (int i = threadIdx.x; i < K * K; i += 256) ws[i] = w[(size_t)c * K * K + i];
+    __syncthreads();
+    const int Ho = H * F, Wo = W * F;
+    const float *xp = x + (size_t)plane * H * W;
+    float *yp = y + (size_t)plane * Ho * Wo;
+    const int o0 = (blockIdx.x * 256 + threadIdx.x) * 4;
+    if (o0 >= Ho * Wo) return;
+    const int Y = o0 / Wo, X0 = o0 - Y * Wo;                  // Wo % 4 == 0: the four outputs share the row
+    const int iy1 = (Y + P) / F, iy0 = iy1 - 1;
+    const int ky1 = Y + P - iy1 * F, ky0 = ky1 + F;           // kernel rows used with input rows iy1 / iy0
+    float out[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+        const int X = X0 + u;
+        const int ix1 = (X + P) / F, ix0 = ix1 - 1;
+        const int kx1 = X + P - ix1 * F, kx0 = kx1 + F;
+        float acc = 0.f;
+        if (iy1 < H) {
+            if (ix1 < W) acc += xp[iy1 * W + ix1] * ws[ky1 * K + kx1];
+            if (ix0 >= 0) acc += xp[iy1 * W + ix0] * ws[ky1 * K + kx0];
+        }
+        if (iy0 >= 0) {
+            if (ix1 < W) acc += xp[iy0 * W + ix1] * ws[ky0 * K + kx1];
+            if (ix0 >= 0) acc += xp[iy0 * W + ix0] * ws[ky0 * K + kx0];
+        }
+        out[u] = acc;
+    }
+    *reinterpret_cast<float4 *>(yp + o0) = make_float4(out[0], out[1], out[2], out[3]);
+}
+
+// grid = (ceil(H*W / 256), B*C); one input element per thread
+template <int F>
+__global__ __launch_bounds__(256) void up_dw_bwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gy,
+                                                 float *__restrict__ gx, float *__restrict__ gw, int C, int H, int W)
+{
+    constexpr int K = 2 * F, P = F / 2;
+    __shared__ float ws[K * K];
+    __shared__ float red[4][K * K];
+    const int plane = blockIdx.y, c = plane % C;
+    for (int i = threadIdx.x; i < K * K; i += 256) ws[i] = w[(size_t)c * K * K + i];
+    __syncthreads();
+    const int Ho = H * F, Wo = W * F;
+    const int q = blockIdx.x * 256 + threadIdx.x;
+    const bool qv = q < H * W;
+    const int iy = qv ? q / W : 0, ix = qv ? q - iy * W : 0;
+    const float xv = qv ? x[(size_t)plane * H * W + q] : 0.f;
+    const float *gp = gy + (size_t)plane * Ho * Wo;
+    const int Y0 = iy * F - P, X0 = ix * F - P;
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+    float dx = 0.f;
+#pragma unroll
+    for (int ky = 0; ky < K; ++ky) {
+        const int Y = Y0 + ky;
+        const bool yv = qv && Y >= 0 && Y < Ho;
+#pragma unroll
+        for (int kx = 0; kx < K; ++kx) {
+            const int X = X0 + kx;
+            const float g = (yv && X >= 0 && X < Wo) ? gp[(size_t)Y * Wo + X] : 0.f;
+            dx += g * ws[ky * K + kx];
+            float s = g * xv;                                   // this element's share of grad_w[c][ky][kx]
+#pragma unroll
+            for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+            if (lane == 0) red[wave][ky * K + kx] = s;
+        }
+    }
+    if (qv) gx[(size_t)plane * H * W + q] = dx;
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256)
+        atomicAdd(gw + (size_t)c * K * K + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+}
+
+}  // namespace
+
+extern "C" {
+
+int dcd_upsample_dw_forward(void *stream_, const float *x, const float *weight, float *y, int B, int C, int H, int W, int f)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !weight || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return DCD_ERR_BAD_ARG;
+    if ((f != 2 && f != 4 && f != 8) || ((W * f) & 3)) return DCD_ERR_BAD_ARG;
+    const int no = H * f * W * f;
+    dim3 grid((no / 4 + 255) / 256, B * C), block(256);
+    if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W);
+    else if (f == 4) hipLaunchKernelGGL(up_dw_fwd<4>, grid, block, 0, stream, x, weight, y, C, H, W);
+    else hipLaunchKernelGGL(up_dw_fwd<8>, grid, block, 0, stream, x, weight, y, C, H, W);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_upsample_dw_backward(void *stream_, const float *x, const float *weight, const float *grad_y, float *grad_x,
+                             float *grad_weight, int B, int C, int H, int W, int f)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !weight || !grad_y || !grad_x || !grad_weight || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535)
+        return DCD_ERR_BAD_ARG;
+    if (f != 2 && f != 4 && f != 8) return DCD_ERR_BAD_ARG;
+    hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)C * 4 * f * f, stream);
+    dim3 grid((H * W + 255) / 256, B * C), block(256);
+    if (f == 2) hipLaunchKernelGGL(up_dw_bwd<2>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
+    else if (f == 4) hipLaunchKernelGGL(up_dw_bwd<4>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
+    else hipLaunchKernelGGL(up_dw_bwd<8>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+}  // extern "C"

@@ -5,6 +5,7 @@ suite) takes the stock op, which is what the reference uses everywhere (DGDE/mod
 DGDE/model/head/detector_predictor.py:52-58).  `DCD_CONV_WINOGRAD=0` switches the kernel off (A/B timing)."""
 import os
 
+import torch
 from torch import nn
 
 from dcd_amd import ops
@@ -19,3 +20,18 @@ class Conv2d(nn.Conv2d):
                 and ops.conv3x3_supported(x, self.weight)):
             return ops.conv3x3(x, self.weight)
         return super().forward(x)
+
+
+class DepthwiseUpsample(nn.ConvTranspose2d):
+    """`nn.ConvTranspose2d(o, o, 2f, stride=f, padding=f//2, output_padding=0, groups=o, bias=False)` of IDAUp
+    (DGDE/model/backbone/dla_dcn.py:416-418) on csrc/upsample.hip; same parameter / state-dict key (`weight`).  MIOpen has no
+    solver for this shape and runs naive / im2col kernels (5.1 ms per step for the eight layers)."""
+
+    def forward(self, x, output_size=None):
+        f = self.stride[0]
+        if (_ENABLED and output_size is None and x.is_cuda and x.dtype == torch.float32 and self.bias is None
+                and self.groups == self.in_channels == self.out_channels and self.stride == (f, f) and f in (2, 4, 8)
+                and self.kernel_size == (2 * f, 2 * f) and self.padding == (f // 2, f // 2) and self.output_padding == (0, 0)
+                and self.dilation == (1, 1) and (x.shape[3] * f) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535):
+            return ops.upsample_dw(x, self.weight, f)
+        return super().forward(x, output_size)

@@ -399,3 +399,37 @@ class _Conv3x3(torch.autograd.Function):
 
 def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
+
+
+# ----------------------------------------------------------------------------------------------
+# Depthwise transposed convolution of IDAUp (kernel 2f, stride f, padding f/2, groups = channels)
+# ----------------------------------------------------------------------------------------------
+class _UpsampleDW(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight, f):
+        _lib.require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H * f, W * f), dtype=torch.float32, device=x.device)
+        st = _lib.lib().dcd_upsample_dw_forward(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H, W, f)
+        _lib.check(st, "dcd_upsample_dw_forward")
+        ctx.save_for_backward(x, weight)
+        ctx.f = f
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        B, C, H, W = x.shape
+        gx, gw = torch.empty_like(x), torch.empty_like(weight)
+        st = _lib.lib().dcd_upsample_dw_backward(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), gy.data_ptr(), gx.data_ptr(),
+                                                 gw.data_ptr(), B, C, H, W, ctx.f)
+        _lib.check(st, "dcd_upsample_dw_backward")
+        return gx, gw, None
+
+
+def upsample_dw(x, weight, f):
+    """y = conv_transpose2d(x, weight, stride=f, padding=f//2, groups=C) for weight (C,1,2f,2f)."""
+    return _UpsampleDW.apply(x, weight, f)

@@ -217,6 +217,15 @@ size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout);
 int dcd_conv3x3(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
                 int Cout, int backward_data, void *workspace, size_t workspace_bytes);
 
+/* ------------------------------------------------------------------------------------------------
+ * Depthwise transposed convolution of IDAUp: nn.ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)
+ * (DGDE/model/backbone/dla_dcn.py:416-421; weights from fill_up_weights :386-395, learnable), f in {2,4,8}.
+ * x (B,C,H,W) -> y (B,C,H*f,W*f); weight (C,1,2f,2f).  Requires (W*f) % 4 == 0.  Backward overwrites grad_x and grad_weight.
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_upsample_dw_forward(void *stream, const float *x, const float *weight, float *y, int B, int C, int H, int W, int f);
+int dcd_upsample_dw_backward(void *stream, const float *x, const float *weight, const float *grad_y, float *grad_x,
+                             float *grad_weight, int B, int C, int H, int W, int f);
+
 #ifdef __cplusplus
 }
 #endif

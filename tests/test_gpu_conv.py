@@ -59,3 +59,30 @@ def test_conv3x3_bad_arguments(cuda):
     assert L.dcd_conv3x3(_lib.stream_of(x), x.data_ptr(), x.data_ptr(), x.data_ptr(), 1, 64, 9, 30, 64, 0, x.data_ptr(), 1 << 30) == 1
     x2 = torch.randn(1, 64, 8, 32, device=cuda)
     assert L.dcd_conv3x3(_lib.stream_of(x2), x2.data_ptr(), x2.data_ptr(), x2.data_ptr(), 1, 64, 8, 32, 64, 0, x2.data_ptr(), 16) == 2
+
+
+@pytest.mark.parametrize("B,C,H,W,f", [(2, 8, 5, 6, 2), (1, 64, 24, 80, 4), (2, 16, 12, 40, 2), (1, 3, 4, 2, 8)])
+def test_depthwise_upsample_matches_conv_transpose(cuda, B, C, H, W, f):
+    """IDAUp's depthwise ConvTranspose2d (csrc/upsample.hip) against torch's conv_transpose2d in fp64."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(C + f)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(C, 1, 2 * f, 2 * f, generator=g)
+    gy = torch.randn(B, C, H * f, W * f, generator=g)
+    xd, wd = x.double().requires_grad_(), w.double().requires_grad_()
+    ref = F.conv_transpose2d(xd, wd, stride=f, padding=f // 2, groups=C)
+    ref.backward(gy.double())
+    xg, wg = x.to(cuda).requires_grad_(), w.to(cuda).requires_grad_()
+    y = ops.upsample_dw(xg, wg, f)
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref.detach(), "forward", 1e-6)
+    _close(xg.grad.cpu(), xd.grad, "grad_input", 1e-5)
+    _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+
+
+def test_depthwise_upsample_module_dispatch(cuda):
+    from dcd_amd.model.layers.conv import DepthwiseUpsample
+    up = DepthwiseUpsample(16, 16, 4, stride=2, padding=1, output_padding=0, groups=16, bias=False).to(cuda)
+    x = torch.randn(2, 16, 12, 40, device=cuda)
+    ref = F.conv_transpose2d(x, up.weight, stride=2, padding=1, groups=16)
+    _close(up(x).detach().cpu(), ref.detach().double().cpu(), "module forward", 1e-5)
