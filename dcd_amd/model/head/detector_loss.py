@@ -171,7 +171,11 @@ class Loss_Computation():
     def prepare_predictions(self, targets_variables, predictions):
         """Select the annotated objects, gather their predictions and decode them (detector_loss.py:217-403)."""
         pred_regression = predictions['reg']
-        batch, channel, feat_h, feat_w = pred_regression.shape
+        reg_pois = predictions.get('reg_pois')                 # (B, M, C): heads already evaluated at the object centres
+        if reg_pois is not None:
+            batch, channel = reg_pois.shape[0], reg_pois.shape[2]
+        else:
+            batch, channel, feat_h, feat_w = pred_regression.shape
         enc = self.anno_encoder
         tv = targets_variables
 
@@ -217,7 +221,10 @@ class Loss_Computation():
         target_bboxes_3D = torch.cat((target_locations_3D, target_dimensions_3D, target_rotys_3D[:, None]), dim=1)
 
         # predictions at the object centres: direct strided gather, no NHWC copy (utils.py:120-145)
-        pois = select_point_of_interest(batch, tv["target_centers"], pred_regression).view(-1, channel).index_select(0, sel)
+        if reg_pois is not None:
+            pois = reg_pois.reshape(-1, channel).index_select(0, sel)
+        else:
+            pois = select_point_of_interest(batch, tv["target_centers"], pred_regression).view(-1, channel).index_select(0, sel)
         k2c = self.key2channel
         pred_regression_2D = F.relu(pois[:, k2c('2d_dim')]).float()
         pred_offset_3D = pois[:, k2c('3d_offset')].float()

@@ -12,7 +12,7 @@ from torch import nn
 from torch.nn import functional as F
 
 from dcd_amd.model import registry
-from dcd_amd.model.layers.utils import sigmoid_hm
+from dcd_amd.model.layers.utils import select_point_of_interest, sigmoid_hm
 from dcd_amd.model.make_layers import group_norm, _fill_fc_weights
 from dcd_amd.model.backbone.DCNv2.dcn_v2 import DCN
 from dcd_amd.model.layers.norm import BatchNorm2d
@@ -87,6 +87,11 @@ class _predictor(nn.Module):
         self.edge_fusion_kernel_size = cfg.MODEL.HEAD.EDGE_FUSION_KERNEL_SIZE
         self.edge_fusion_relu = cfg.MODEL.HEAD.EDGE_FUSION_RELU
         self.exact_edge_gather = True   # False -> F.grid_sample exactly as the reference
+        # Training evaluates the regression heads ONLY at the annotated object centres (the loss reads nothing else,
+        # detector_loss.py:231-233): the 11 dense 1x1 convolutions, the 415-channel concatenation and -- in backward -- a
+        # zero-filled 415-channel gradient map, its 12 slices, 12 dense 1x1 data/weight gradients all disappear.  The result
+        # is `reg_pois` (B, MAX_OBJECTS, 415); `reg` is then None.  False restores the reference's dense training output.
+        self.sparse_training_heads = True
         if self.enable_edge_fusion:
             norm1d = nn.BatchNorm1d if cfg.MODEL.HEAD.EDGE_FUSION_NORM == 'BN' else nn.Identity
             k = self.edge_fusion_kernel_size
@@ -153,7 +158,66 @@ class _predictor(nn.Module):
             ci = torch.arange(out.shape[1], device=out.device).view(1, -1, 1)
             out.index_put_((bi, ci, yi, xi), vals * valid.unsqueeze(1), accumulate=True)
 
+    def _edge_fusion_at_pois(self, reg_feature, targets, centers_lin):
+        """Edge-fusion term of the 3d_offset head at the object centres: what `_edge_fusion` would have accumulated into the
+        dense map at those cells (detector_predictor.py:172-196, duplicates of a border cell included)."""
+        b = reg_feature.shape[0]
+        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])          # B x K x 2 (x, y)
+        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
+        K = edge_indices.shape[1]
+        bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
+        yi = edge_indices[:, :, 1].long().view(b, 1, K)
+        xi = edge_indices[:, :, 0].long().view(b, 1, K)
+        ci = torch.arange(self.head_conv, device=reg_feature.device).view(1, -1, 1)
+        edge_offset_output = self.trunc_offset_conv(reg_feature[bi, ci, yi, xi])             # B x 2 x K
+        valid = torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens           # B x K
+        edge_lin = (edge_indices[:, :, 1].long() * reg_feature.shape[3] + edge_indices[:, :, 0].long())
+        hit = (centers_lin.unsqueeze(2) == edge_lin.unsqueeze(1)) & valid.unsqueeze(1)       # B x M x K
+        return torch.bmm(hit.to(edge_offset_output.dtype), edge_offset_output.transpose(1, 2))  # B x M x 2
+
+    def _forward_sparse(self, features, targets):
+        """Training forward with the regression heads evaluated at the object centres only."""
+        feat_cls_in = self.cls_head_pre(features) if self.deeper_head else features
+        feature_cls = self.class_head[:-1](feat_cls_in)
+        output_cls = self.class_head[-1](feature_cls)
+        feat_reg_in = self.reg_head_pre(features) if self.deeper_head else features
+        b, _, h, w = feature_cls.shape
+        centers = torch.stack([t.get_field("target_centers") for t in targets])              # B x M x 2 (x, y)
+        centers_lin = centers[:, :, 1].long() * w + centers[:, :, 0].long()                  # B x M
+        M = centers_lin.shape[1]
+        outs = []
+        for i, feat_layer in enumerate(self.reg_features):
+            reg_feature = feat_layer(feat_reg_in)
+            at = select_point_of_interest(b, centers_lin, reg_feature).reshape(b * M, self.head_conv)   # B*M x 256
+            for j, out_head in enumerate(self.reg_heads[i]):
+                o = F.linear(at, out_head.weight.view(out_head.out_channels, self.head_conv), out_head.bias).view(b, M, -1)
+                if self.enable_edge_fusion and i == self.offset_index[0] and j == self.offset_index[1]:
+                    # the class map gets its edge term densely (it is consumed densely by the focal loss)
+                    o = o + self._edge_fusion_at_pois(reg_feature, targets, centers_lin)
+                    self._edge_fusion_cls(feature_cls, output_cls, targets)
+                outs.append(o)
+        output_cls = sigmoid_hm(output_cls)
+        return {'cls': output_cls.float(), 'reg': None, 'reg_pois': torch.cat(outs, dim=2).float()}
+
+    def _edge_fusion_cls(self, feature_cls, output_cls, targets):
+        """The class-map half of `_edge_fusion` (dense: the focal loss reads every cell)."""
+        b = feature_cls.shape[0]
+        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])
+        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
+        K = edge_indices.shape[1]
+        bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
+        yi = edge_indices[:, :, 1].long().view(b, 1, K)
+        xi = edge_indices[:, :, 0].long().view(b, 1, K)
+        ci = torch.arange(self.head_conv, device=feature_cls.device).view(1, -1, 1)
+        edge_cls_output = self.trunc_heatmap_conv(feature_cls[bi, ci, yi, xi])
+        valid = (torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens).to(edge_cls_output.dtype)
+        co = torch.arange(output_cls.shape[1], device=output_cls.device).view(1, -1, 1)
+        output_cls.index_put_((bi, co, yi, xi), edge_cls_output * valid.unsqueeze(1), accumulate=True)
+
     def forward(self, features, targets):
+        if (self.training and self.sparse_training_heads and targets is not None and self.exact_edge_gather
+                and self.output_width == features.shape[3] and self.output_height == features.shape[2]):
+            return self._forward_sparse(features, targets)
         feat_cls_in = self.cls_head_pre(features) if self.deeper_head else features
         feature_cls = self.class_head[:-1](feat_cls_in)
         output_cls = self.class_head[-1](feature_cls)

@@ -83,7 +83,16 @@ def check_model(device, tol, gtol):
     images = images.to(device)
     targets = [t.to(device) for t in targets]
     feats = model.backbone(images)
+    model.heads.predictor.sparse_training_heads = False      # the reference's dense training output, for the map slices
     pred = model.heads.predictor(feats, targets)
+    model.heads.predictor.sparse_training_heads = True       # default: heads evaluated at the object centres only
+    sparse = model.heads.predictor(feats, targets)
+    assert sparse["reg"] is None
+    cx = torch.stack([t.get_field("target_centers") for t in targets]).long()
+    bidx = torch.arange(cx.shape[0], device=cx.device).view(-1, 1).expand(-1, cx.shape[1])
+    dense_at = pred["reg"][bidx, :, cx[:, :, 1], cx[:, :, 0]]                       # B x M x 415
+    assert (sparse["reg_pois"] - dense_at).abs().max().item() <= 1e-4 * max(dense_at.abs().max().item(), 1.0)
+    assert (sparse["cls"] - pred["cls"]).abs().max().item() <= 1e-5
     def rel(a, key):
         a = a.detach().cpu().numpy()
         return np.abs(a - g[key]).max() / (np.abs(g[key]).max() + 1e-12)
