@@ -253,7 +253,7 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
     const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
     if ((g.HW & 3) == 0) {
         for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
-            float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
+            float4 d = dy ? *reinterpret_cast<const float4 *>(dy + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
             if (y) {
                 const float4 o = *reinterpret_cast<const float4 *>(y + base + i);
@@ -268,12 +268,75 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
         }
     } else {
         for (long i = lo + threadIdx.x; i < hi; i += BT) {
-            float d = dy[base + i];
+            float d = dy ? dy[base + i] : 0.f;
             if (y) d = y[base + i] <= 0.f ? 0.f : d;
             if (dres) dres[base + i] = d;
             dx[base + i] = (d - a - (x[base + i] - mean) * bq) * k1;
         }
     }
+}
+
+// ---- BN (+ReLU) evaluated at a list of positions only (training forward of the regression-head trunks: the loss reads the
+// normalised features at <= 40 object centres per image, plus the 832 border cells for the edge-fusion branch).
+// grid = (C); block c finalises its channel (mean / invstd from the stats partials or combined sums, running statistics)
+// and normalises the gathered values.  pos (B, N) linear pixel indices; x_at / y_at (B, N, C).
+__global__ __launch_bounds__(BT) void bn_at_forward(const float *__restrict__ x, const int64_t *__restrict__ pos,
+                                                    const float *__restrict__ weight, const float *__restrict__ bias,
+                                                    const double *__restrict__ stats, const double *__restrict__ partial, int S,
+                                                    double count, float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                    long long *__restrict__ num_batches_tracked, float momentum, float eps,
+                                                    int relu, float *__restrict__ x_at, float *__restrict__ y_at,
+                                                    float *__restrict__ save_mean, float *__restrict__ save_invstd, int B, int C,
+                                                    long HW, int N)
+{
+    const int c = blockIdx.x;
+    double s0, s1;
+    channel_sums(stats, partial, S, c, s0, s1);
+    const double m = s0 / count;
+    double var = s1 / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+    }
+    const float scale = invstd * (weight ? weight[c] : 1.f);
+    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+    for (int e = threadIdx.x; e < B * N; e += BT) {
+        const int b = e / N;
+        const float v = x[((long)b * C + c) * HW + pos[e]];
+        float o = fmaf(v, scale, shift);
+        if (relu) o = o < 0.f ? 0.f : o;
+        x_at[(long)e * C + c] = v;
+        y_at[(long)e * C + c] = o;
+    }
+}
+
+// backward sums over the listed entries: dz = g * [y > 0];  sums[c] = (sum dz, sum dz (x - mean));  dzk = dz * invstd * w
+__global__ __launch_bounds__(BT) void bn_at_backward_sums(const float *__restrict__ g, const float *__restrict__ x_at,
+                                                          const float *__restrict__ y_at, const float *__restrict__ weight,
+                                                          const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                          int relu, int total, int C, double *__restrict__ sums,
+                                                          float *__restrict__ dzk)
+{
+    const int c = blockIdx.x;
+    const float mean = save_mean[c], k1 = save_invstd[c] * (weight ? weight[c] : 1.f);
+    double d0 = 0.0, d1 = 0.0;
+    for (int e = threadIdx.x; e < total; e += BT) {
+        float d = g[(long)e * C + c];
+        if (relu) d = y_at[(long)e * C + c] <= 0.f ? 0.f : d;
+        d0 += (double)d;
+        d1 += (double)d * (double)(x_at[(long)e * C + c] - mean);
+        dzk[(long)e * C + c] = d * k1;
+    }
+    block_sum2(d0, d1);
+    if (threadIdx.x == 0) { sums[2 * c] = d0; sums[2 * c + 1] = d1; }
 }
 
 inline Plane make_plane(int B, int C, long HW)
@@ -366,7 +429,7 @@ int dcd_bn_backward_apply(void *stream_, const float *grad_y, const float *y, co
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
-    if (!grad_y || !x || !save_mean || !save_invstd || !sums || !grad_x || bad_shape(B, C, HW) || !(count >= 1.0))
+    if (!x || !save_mean || !save_invstd || !sums || !grad_x || bad_shape(B, C, HW) || !(count >= 1.0))   // grad_y NULL = zeros
         return DCD_ERR_BAD_ARG;
     const Plane g = make_plane(B, C, HW);
     hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd, sums,
@@ -409,6 +472,45 @@ int dcd_bn_backward(void *stream_, const float *grad_y, const float *y, const fl
     hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd,
                        (const double *)nullptr, (const double *)ws, S, (double)B * (double)HW, grad_x, grad_residual, grad_weight,
                        grad_bias, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+/* BN (+ReLU) in training mode evaluated at listed positions only.  Statistics over the whole tensor as usual: either
+ * `stats` (C x 2 combined sums, e.g. all-reduced) is given, or (stats == NULL) they are computed here. */
+int dcd_bn_at_forward(void *stream_, const float *x, const int64_t *pos, const float *weight, const float *bias,
+                      const double *stats, double count, float *running_mean, float *running_var,
+                      int64_t *num_batches_tracked, float momentum, float eps, int relu, float *x_at, float *y_at,
+                      float *save_mean, float *save_invstd, int B, int C, int64_t HW, int N, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !pos || !x_at || !y_at || !save_mean || !save_invstd || bad_shape(B, C, HW) || N <= 0 || !(count >= 1.0))
+        return DCD_ERR_BAD_ARG;
+    if ((running_mean == nullptr) != (running_var == nullptr)) return DCD_ERR_BAD_ARG;
+    const Plane g = make_plane(B, C, HW);
+    int S = 0;
+    if (!stats) {
+        if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+        S = slices(g);
+        hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
+    }
+    hipLaunchKernelGGL(bn_at_forward, dim3(C), dim3(BT), 0, stream, x, pos, weight, bias, stats, stats ? (const double *)nullptr : (const double *)ws,
+                       S, count, running_mean, running_var, (long long *)num_batches_tracked, momentum, eps, relu, x_at, y_at,
+                       save_mean, save_invstd, B, C, (long)HW, N);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+/* sums (C x 2 doubles) and the scaled sparse gradient dzk (B*N, C) of the entries; then dcd_bn_backward_apply with
+ * grad_y = NULL (dense part of grad_x) and a scatter-add of dzk finish the backward. */
+int dcd_bn_at_backward_sums(void *stream_, const float *grad_at, const float *x_at, const float *y_at, const float *weight,
+                            const float *save_mean, const float *save_invstd, int relu, int total, int C, double *sums,
+                            float *dzk)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_at || !x_at || !y_at || !save_mean || !save_invstd || !sums || !dzk || total <= 0 || C <= 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(bn_at_backward_sums, dim3(C), dim3(BT), 0, stream, grad_at, x_at, y_at, weight, save_mean, save_invstd, relu,
+                       total, C, sums, dzk);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

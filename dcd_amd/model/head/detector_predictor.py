@@ -158,25 +158,18 @@ class _predictor(nn.Module):
             ci = torch.arange(out.shape[1], device=out.device).view(1, -1, 1)
             out.index_put_((bi, ci, yi, xi), vals * valid.unsqueeze(1), accumulate=True)
 
-    def _edge_fusion_at_pois(self, reg_feature, targets, centers_lin):
+    def _edge_fusion_at_pois(self, edge_feature, edge_lin, valid, centers_lin):
         """Edge-fusion term of the 3d_offset head at the object centres: what `_edge_fusion` would have accumulated into the
-        dense map at those cells (detector_predictor.py:172-196, duplicates of a border cell included)."""
-        b = reg_feature.shape[0]
-        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])          # B x K x 2 (x, y)
-        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
-        K = edge_indices.shape[1]
-        bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
-        yi = edge_indices[:, :, 1].long().view(b, 1, K)
-        xi = edge_indices[:, :, 0].long().view(b, 1, K)
-        ci = torch.arange(self.head_conv, device=reg_feature.device).view(1, -1, 1)
-        edge_offset_output = self.trunc_offset_conv(reg_feature[bi, ci, yi, xi])             # B x 2 x K
-        valid = torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens           # B x K
-        edge_lin = (edge_indices[:, :, 1].long() * reg_feature.shape[3] + edge_indices[:, :, 0].long())
+        dense map at those cells (detector_predictor.py:172-196, duplicates of a border cell included).
+        edge_feature (B, 256, K): trunk output at the border cells."""
+        edge_offset_output = self.trunc_offset_conv(edge_feature)                            # B x 2 x K
         hit = (centers_lin.unsqueeze(2) == edge_lin.unsqueeze(1)) & valid.unsqueeze(1)       # B x M x K
         return torch.bmm(hit.to(edge_offset_output.dtype), edge_offset_output.transpose(1, 2))  # B x M x 2
 
     def _forward_sparse(self, features, targets):
-        """Training forward with the regression heads evaluated at the object centres only."""
+        """Training forward with the regression heads evaluated at the object centres only.  The trunks' BN + ReLU is
+        evaluated at those positions too (`BatchNorm2d.forward_at`): its dense output map is never written, and its backward
+        needs one read of the conv output and one write of the gradient instead of seven tensor passes."""
         feat_cls_in = self.cls_head_pre(features) if self.deeper_head else features
         feature_cls = self.class_head[:-1](feat_cls_in)
         output_cls = self.class_head[-1](feature_cls)
@@ -185,15 +178,27 @@ class _predictor(nn.Module):
         centers = torch.stack([t.get_field("target_centers") for t in targets])              # B x M x 2 (x, y)
         centers_lin = centers[:, :, 1].long() * w + centers[:, :, 0].long()                  # B x M
         M = centers_lin.shape[1]
+        if self.enable_edge_fusion:
+            edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])      # B x K x 2 (x, y)
+            edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
+            K = edge_indices.shape[1]
+            edge_lin = edge_indices[:, :, 1].long() * w + edge_indices[:, :, 0].long()       # B x K
+            edge_valid = torch.arange(K, device=edge_lin.device).view(1, K) < edge_lens      # B x K
         outs = []
         for i, feat_layer in enumerate(self.reg_features):
-            reg_feature = feat_layer(feat_reg_in)
-            at = select_point_of_interest(b, centers_lin, reg_feature).reshape(b * M, self.head_conv)   # B*M x 256
+            fused = i == self.offset_index[0] and self.enable_edge_fusion
+            pos = torch.cat((centers_lin, edge_lin), dim=1) if fused else centers_lin
+            conv, norm = feat_layer[0], feat_layer[1]
+            if hasattr(norm, "forward_at") and isinstance(feat_layer[2], nn.Identity):
+                at_all = norm.forward_at(conv(feat_reg_in), pos)                             # B x N x 256
+            else:                                                                             # GN / leaky-relu configurations
+                at_all = select_point_of_interest(b, pos, feat_layer(feat_reg_in))
+            at = at_all[:, :M].reshape(b * M, self.head_conv)
             for j, out_head in enumerate(self.reg_heads[i]):
                 o = F.linear(at, out_head.weight.view(out_head.out_channels, self.head_conv), out_head.bias).view(b, M, -1)
-                if self.enable_edge_fusion and i == self.offset_index[0] and j == self.offset_index[1]:
+                if fused and j == self.offset_index[1]:
+                    o = o + self._edge_fusion_at_pois(at_all[:, M:].transpose(1, 2), edge_lin, edge_valid, centers_lin)
                     # the class map gets its edge term densely (it is consumed densely by the focal loss)
-                    o = o + self._edge_fusion_at_pois(reg_feature, targets, centers_lin)
                     self._edge_fusion_cls(feature_cls, output_cls, targets)
                 outs.append(o)
         output_cls = sigmoid_hm(output_cls)

@@ -85,3 +85,13 @@ class BatchNorm2d(nn.BatchNorm2d):
             return self._stock(x, residual)      # gradients through frozen statistics: stock autograd
         return ops.batch_norm_act_eval(x, residual, self.weight, self.bias, self.running_mean, self.running_var, self.eps,
                                        self.fuse_relu)
+
+    def forward_at(self, x, pos):
+        """Training-mode BN (+ReLU) whose output is needed only at `pos` (B,N) linear pixel indices: returns (B,N,C).
+        Statistics and running buffers are those of the dense op.  CPU tensors (tests) take the dense stock path + gather."""
+        if x.is_cuda and x.dtype == torch.float32 and self.training and self.momentum is not None:
+            return ops.batch_norm_act_at(x, pos, self.weight, self.bias, self.running_mean, self.running_var,
+                                         self.num_batches_tracked, self.momentum, self.eps, self.fuse_relu, self.sync_group)
+        y = self.forward(x)
+        b, c = y.shape[0], y.shape[1]
+        return y.flatten(2).gather(2, pos.long().unsqueeze(1).expand(b, c, pos.shape[1])).transpose(1, 2)

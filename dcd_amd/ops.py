@@ -433,3 +433,75 @@ class _UpsampleDW(torch.autograd.Function):
 def upsample_dw(x, weight, f):
     """y = conv_transpose2d(x, weight, stride=f, padding=f//2, groups=C) for weight (C,1,2f,2f)."""
     return _UpsampleDW.apply(x, weight, f)
+
+
+# ----------------------------------------------------------------------------------------------
+# Batch norm (+ReLU), training mode, evaluated at listed positions only
+# ----------------------------------------------------------------------------------------------
+class _BatchNormActAt(torch.autograd.Function):
+    """y_at (B,N,C) = act(batch_norm(x))[b, :, pos[b,n]].  Statistics (and running buffers) exactly as the dense op; the dense
+    normalised map is never written.  Backward: the gradient w.r.t. x is dense (every pixel feels the batch statistics) but
+    needs one read of x and one write, instead of the seven tensor passes of the dense BN + ReLU backward."""
+
+    @staticmethod
+    def forward(ctx, x, pos, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu, group):
+        _lib.require_cuda(x, pos, weight, bias)
+        L = _lib.lib()
+        x = _f32c(x)
+        pos = pos.contiguous().long()
+        B, C = x.shape[0], x.shape[1]
+        HW = x.numel() // (B * C)
+        N = pos.shape[1]
+        dev, st = x.device, _lib.stream_of(x)
+        ws = _bn_ws(C, dev)
+        count = float(B * HW)
+        stats = None
+        if group is not None:
+            import torch.distributed as dist
+            stats = torch.empty((C, 2), dtype=torch.float64, device=dev)
+            _lib.check(L.dcd_bn_stats(st, x.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
+            dist.all_reduce(stats, group=group)
+            count *= dist.get_world_size(group)
+        x_at = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        y_at = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        save_mean = torch.empty(C, dtype=torch.float32, device=dev)
+        save_invstd = torch.empty(C, dtype=torch.float32, device=dev)
+        _lib.check(L.dcd_bn_at_forward(st, x.data_ptr(), pos.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), _lib.ptr(stats), count,
+                                       _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
+                                       float(momentum), float(eps), int(bool(relu)), x_at.data_ptr(), y_at.data_ptr(),
+                                       save_mean.data_ptr(), save_invstd.data_ptr(), B, C, HW, N, ws.data_ptr(), ws.numel()),
+                   "dcd_bn_at_forward")
+        ctx.save_for_backward(x, pos, x_at, y_at, weight, save_mean, save_invstd)
+        ctx.count, ctx.group, ctx.relu = count, group, bool(relu)
+        return y_at
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g_at):
+        x, pos, x_at, y_at, weight, save_mean, save_invstd = ctx.saved_tensors
+        L = _lib.lib()
+        g_at = _f32c(g_at)
+        B, C, H, W = x.shape
+        HW, N = H * W, pos.shape[1]
+        dev, st = x.device, _lib.stream_of(x)
+        sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+        dzk = torch.empty((B, N, C), dtype=torch.float32, device=dev)
+        _lib.check(L.dcd_bn_at_backward_sums(st, g_at.data_ptr(), x_at.data_ptr(), y_at.data_ptr(), _lib.ptr(weight),
+                                             save_mean.data_ptr(), save_invstd.data_ptr(), int(ctx.relu), B * N, C, sums.data_ptr(),
+                                             dzk.data_ptr()), "dcd_bn_at_backward_sums")
+        gw = (sums[:, 1] * save_invstd.double()).float()       # local sums: DDP averages the parameter gradients
+        gb = sums[:, 0].float()
+        if ctx.group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=ctx.group)
+        gx = torch.empty_like(x)
+        _lib.check(L.dcd_bn_backward_apply(st, None, None, x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
+                                           save_invstd.data_ptr(), sums.data_ptr(), ctx.count, gx.data_ptr(), None, None, None,
+                                           B, C, HW), "dcd_bn_backward_apply")
+        _lib.check(L.dcd_poi_scatter_add(st, dzk.data_ptr(), pos.data_ptr(), B, C, H, W, N, gx.data_ptr()), "dcd_poi_scatter_add")
+        return (gx, None, gw if weight is not None else None, gb if weight is not None else None, None, None, None, None, None,
+                None, None)
+
+
+def batch_norm_act_at(x, pos, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu, group=None):
+    return _BatchNormActAt.apply(x, pos, weight, bias, running_mean, running_var, num_batches_tracked, momentum, eps, relu, group)

@@ -190,6 +190,19 @@ int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, con
                           const float *save_mean, const float *save_invstd, const double *sums, double count,
                           float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,
                           int64_t HW);
+/* BN (+ReLU), training mode, evaluated at listed positions only (the regression-head trunks: the loss reads their output at
+ * the object centres and, for one head, the border cells).  pos (B,N) int64 linear pixel indices; x_at, y_at (B,N,C).
+ * stats NULL: statistics computed here (workspace needed); else the C x 2 combined (all-reduced) sums with the global count.
+ * Backward: dcd_bn_at_backward_sums -> [all-reduce sums] -> dcd_bn_backward_apply(grad_y = NULL: zeros, y = NULL) gives the
+ * dense part of grad_x, and dzk (B*N,C) is scatter-added at the positions (dcd_poi_scatter_add). */
+int dcd_bn_at_forward(void *stream, const float *x, const int64_t *pos, const float *weight, const float *bias,
+                      const double *stats, double count, float *running_mean, float *running_var,
+                      int64_t *num_batches_tracked, float momentum, float eps, int relu, float *x_at, float *y_at,
+                      float *save_mean, float *save_invstd, int B, int C, int64_t HW, int N, void *workspace,
+                      size_t workspace_bytes);
+int dcd_bn_at_backward_sums(void *stream, const float *grad_at, const float *x_at, const float *y_at, const float *weight,
+                            const float *save_mean, const float *save_invstd, int relu, int total, int C, double *sums,
+                            float *dzk);
 /* Single-rank shortcuts (no statistics exchange): stats + apply fused into two launches, the apply kernels sum the
  * partials of the two-stage reduction themselves.  Same arithmetic and outputs as the call pairs above with
  * count = B*HW. */

@@ -123,3 +123,35 @@ def test_bn_bad_arguments_raise(cuda):
     assert L.dcd_bn_stats(_lib.stream_of(xc), xc.data_ptr(), 2, 4, 9, None, None, 0) == 1
     st = torch.empty(8, dtype=torch.float64, device=cuda)
     assert L.dcd_bn_stats(_lib.stream_of(xc), xc.data_ptr(), 2, 4, 9, st.data_ptr(), None, 0) == 2
+
+
+@pytest.mark.parametrize("B,C,H,W,N", [(2, 16, 12, 40, 7), (8, 256, 24, 80, 40), (1, 5, 7, 9, 3)])
+def test_bn_relu_at_positions_matches_dense_then_gather(cuda, B, C, H, W, N):
+    """BatchNorm2d.forward_at (BN + ReLU evaluated at listed positions, dense input gradient from sparse output gradients)
+    against the stock ops in fp64: batch_norm -> relu -> gather, with repeated positions."""
+    from dcd_amd.model.layers.norm import BatchNorm2d
+    g = torch.Generator(device="cpu").manual_seed(B * 100 + C)
+    x = (torch.randn(B, C, H, W, generator=g) * 1.3 + 0.4)
+    pos = torch.randint(0, H * W, (B, N), generator=g)
+    pos[:, -1] = pos[:, 0]                                           # a repeated position
+    gout = torch.randn(B, N, C, generator=g)
+    w0, b0 = torch.rand(C, generator=g) + 0.5, torch.randn(C, generator=g) * 0.3
+    xd, wd, bd = x.double().requires_grad_(), w0.double().requires_grad_(), b0.double().requires_grad_()
+    rm, rv = torch.zeros(C, dtype=torch.float64), torch.ones(C, dtype=torch.float64)
+    y = F.relu(F.batch_norm(xd, rm, rv, wd, bd, True, 0.1, 1e-5))
+    ref = y.flatten(2).gather(2, pos.unsqueeze(1).expand(B, C, N)).transpose(1, 2)
+    ref.backward(gout.double())
+    bn = BatchNorm2d(C, fuse_relu=True).to(cuda).train()
+    with torch.no_grad():
+        bn.weight.copy_(w0)
+        bn.bias.copy_(b0)
+    xg = x.to(cuda).requires_grad_()
+    out = bn.forward_at(xg, pos.to(cuda))
+    out.backward(gout.to(cuda))
+    _close(out.detach().cpu(), ref.detach(), "y_at")
+    _close(xg.grad.cpu(), xd.grad, "grad_x")
+    _close(bn.weight.grad.cpu(), wd.grad, "grad_weight")
+    _close(bn.bias.grad.cpu(), bd.grad, "grad_bias")
+    _close(bn.running_mean.cpu(), rm, "running_mean")
+    _close(bn.running_var.cpu(), rv, "running_var")
+    assert int(bn.num_batches_tracked) == 1
