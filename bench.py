@@ -245,11 +245,17 @@ def main():
     if args.cpu_baseline_child:
         cpu_baseline_child(args)
         return
+    # RCCL prints its version banner on stdout when the first communicator is created; the contract is ONE JSON line on
+    # stdout, so everything else written to fd 1 during the run goes to stderr.
+    sys.stdout.flush()
+    real_stdout = os.dup(1)
+    os.dup2(2, 1)
     out = run_gpu(args)
+    sys.stdout.flush()
     if out is not None:
         if args.gpus == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args)
-        print(json.dumps(out))
+        os.write(real_stdout, (json.dumps(out) + "\n").encode())
 
 
 if __name__ == "__main__":

@@ -57,6 +57,8 @@ class Anno_Encoder():
     # ------------------------------------------------------------------------------------------
     def _calib_table(self, calibs, device):
         """(len(calibs), 6) float32 rows [c_u, c_v, f_u, f_v, b_x, b_y]; cached for the last list seen."""
+        if torch.is_tensor(calibs):                              # already a table (graph-captured loss)
+            return calibs
         key = (tuple(id(c) for c in calibs), str(device))      # the LIST is rebuilt every step, the Calibration objects are not
         if self._calib_cache[0] != key:
             rows = [[float(c.c_u), float(c.c_v), float(c.f_u), float(c.f_v), float(c.b_x), float(c.b_y)] for c in calibs]
@@ -134,8 +136,9 @@ class Anno_Encoder():
             rank = torch.cumsum(present, 0) - 1
             f_u = tab[rank[bi], 2]
         center_height = pred_keypoints[:, -2, 1] - pred_keypoints[:, -1, 1]
-        corner_02_height = pred_keypoints[:, [0, 2], 1] - pred_keypoints[:, [4, 6], 1]
-        corner_13_height = pred_keypoints[:, [1, 3], 1] - pred_keypoints[:, [5, 7], 1]
+        # strided slices, not index lists: a Python list index becomes a host->device copy on every call
+        corner_02_height = pred_keypoints[:, 0:3:2, 1] - pred_keypoints[:, 4:7:2, 1]
+        corner_13_height = pred_keypoints[:, 1:4:2, 1] - pred_keypoints[:, 5:8:2, 1]
         fh = f_u * pred_height_3D
         center_depth = fh / (F.relu(center_height) * self.down_ratio + self.EPS)
         corner_02_depth = (fh.unsqueeze(-1) / (F.relu(corner_02_height) * self.down_ratio + self.EPS)).mean(dim=1)

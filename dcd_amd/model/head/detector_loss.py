@@ -93,6 +93,9 @@ class Loss_Computation():
         self.corner_loss_depth = cfg.MODEL.HEAD.CORNER_LOSS_DEPTH
         self.eps = 1e-5
         self.is_gen = cfg.TEST.GENERATE_GMW
+        import os
+        self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
+        self._graph_key, self._graphed = None, None
         self.gen_data = {'kpts_2d': [], 'kpts_3d': [], 'pred_rot': [], 'gt_location': [], 'pred_location': [],
                          'weight_img': [], 'img_idx': []}
 
@@ -319,6 +322,41 @@ class Loss_Computation():
     def __call__(self, predictions, targets):
         targets_heatmap, targets_variables = self.prepare_targets(targets)
         pred_heatmap = predictions['cls']
+        reg_pois = predictions.get('reg_pois')
+        if (self.use_graph and reg_pois is not None and not self.is_gen and pred_heatmap.is_cuda and torch.is_grad_enabled()
+                and pred_heatmap.requires_grad and reg_pois.requires_grad):
+            return self._call_graphed(pred_heatmap, reg_pois, targets_heatmap, targets_variables)
+        loss_dict, names, packed = self._core(predictions, targets_heatmap, targets_variables)
+        return loss_dict, LazyLogDict(names, packed, list(loss_dict))
+
+    # ------------------------------------------------------------------------------------------
+    # HIP-graph path.  With the object slots static and no host synchronisation, the ~500 small kernels of the loss (and the
+    # ~500 of its backward) are captured once per input shape and replayed with two graph launches per step; eagerly the
+    # host needs ~15 us per op and the GPU idles through most of this section (tools/prof_gaps.py).
+    def _call_graphed(self, pred_heatmap, reg_pois, targets_heatmap, tv):
+        tv = dict(tv)
+        tv['calib'] = self.anno_encoder._calib_table(tv['calib'], pred_heatmap.device)
+        names = sorted(k for k, v in tv.items() if torch.is_tensor(v) and k != 'ori_imgs')
+        flat = [tv[k] for k in names]
+        key = (tuple(pred_heatmap.shape), tuple(reg_pois.shape), tuple((k, tuple(tv[k].shape), tv[k].dtype) for k in names))
+        if self._graph_key != key:
+            self._tv_names = names
+
+            def core_flat(cls, pois, hm, *fl):
+                tvv = dict(zip(self._tv_names, fl))
+                loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, tvv)
+                self._loss_keys, self._log_names = list(loss_dict), log_names
+                return tuple(loss_dict.values()) + (packed,)
+            sample = (pred_heatmap.detach().clone().requires_grad_(True), reg_pois.detach().clone().requires_grad_(True),
+                      targets_heatmap.detach().clone()) + tuple(t.detach().clone() for t in flat)
+            self._graphed = torch.cuda.make_graphed_callables(core_flat, sample)
+            self._graph_key = key
+        outs = self._graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
+        loss_dict = dict(zip(self._loss_keys, outs[:-1]))
+        return loss_dict, LazyLogDict(self._log_names, outs[-1].clone(), list(loss_dict))
+
+    def _core(self, predictions, targets_heatmap, targets_variables):
+        pred_heatmap = predictions['cls']
         pt, preds, reg_nums, weights = self.prepare_predictions(targets_variables, predictions)
         lw = self.loss_weights
         batch_weight = pred_heatmap.shape[0] * self.batch_weight_factor
@@ -420,7 +458,7 @@ class Loss_Computation():
             names.append('extra_all_MAE')
             vals.append(all_mae)
         packed = torch.stack([v.float().reshape(()) for v in vals])
-        return loss_dict, LazyLogDict(names, packed, list(loss_dict))
+        return loss_dict, names, packed
 
 
 class LazyLogDict(dict):
