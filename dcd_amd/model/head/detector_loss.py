@@ -95,7 +95,7 @@ class Loss_Computation():
         self.is_gen = cfg.TEST.GENERATE_GMW
         import os
         self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
-        self._graph_key, self._graphed = None, None
+        self._graphs = {}                      # input-shape key -> (graphed callable, {'loss_keys', 'log_names'})
         self.gen_data = {'kpts_2d': [], 'kpts_3d': [], 'pred_rot': [], 'gt_location': [], 'pred_location': [],
                          'weight_img': [], 'img_idx': []}
 
@@ -339,21 +339,24 @@ class Loss_Computation():
         names = sorted(k for k, v in tv.items() if torch.is_tensor(v) and k != 'ori_imgs')
         flat = [tv[k] for k in names]
         key = (tuple(pred_heatmap.shape), tuple(reg_pois.shape), tuple((k, tuple(tv[k].shape), tv[k].dtype) for k in names))
-        if self._graph_key != key:
-            self._tv_names = names
+        entry = self._graphs.get(key)
+        if entry is None:
+            meta = {}
 
             def core_flat(cls, pois, hm, *fl):
-                tvv = dict(zip(self._tv_names, fl))
-                loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, tvv)
-                self._loss_keys, self._log_names = list(loss_dict), log_names
+                loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, dict(zip(names, fl)))
+                meta['loss_keys'], meta['log_names'] = list(loss_dict), log_names
                 return tuple(loss_dict.values()) + (packed,)
             sample = (pred_heatmap.detach().clone().requires_grad_(True), reg_pois.detach().clone().requires_grad_(True),
                       targets_heatmap.detach().clone()) + tuple(t.detach().clone() for t in flat)
-            self._graphed = torch.cuda.make_graphed_callables(core_flat, sample)
-            self._graph_key = key
-        outs = self._graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
-        loss_dict = dict(zip(self._loss_keys, outs[:-1]))
-        return loss_dict, LazyLogDict(self._log_names, outs[-1].clone(), list(loss_dict))
+            if len(self._graphs) >= 4:                       # a few input shapes at most (e.g. the last, smaller batch)
+                self._graphs.pop(next(iter(self._graphs)))
+            entry = (torch.cuda.make_graphed_callables(core_flat, sample), meta)
+            self._graphs[key] = entry
+        graphed, meta = entry
+        outs = graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
+        loss_dict = dict(zip(meta['loss_keys'], outs[:-1]))
+        return loss_dict, LazyLogDict(meta['log_names'], outs[-1].clone(), list(loss_dict))
 
     def _core(self, predictions, targets_heatmap, targets_variables):
         pred_heatmap = predictions['cls']

@@ -126,3 +126,34 @@ def test_iou3d_kernel(cuda):
     got = ops.iou_3d(a.to(cuda), b.to(cuda)).cpu().numpy()
     assert ref.max() > 0.05
     np.testing.assert_allclose(got, ref, rtol=1e-4, atol=1e-5)
+
+
+def test_graphed_loss_equals_eager_loss_on_changing_targets(cuda):
+    """The HIP-graph replay of the loss section (forward + backward) must equal the eager computation for every batch fed
+    to it, not only the one it was captured on: two different synthetic batches, graph vs eager, losses and the gradients
+    that flow back into the predictor outputs."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.model.head.detector_loss import Loss_Computation
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    lc = Loss_Computation(cfg)
+    B, M, C, H, W = 2, cfg.DATASETS.MAX_OBJECTS, 415, 24, 80
+    g = torch.Generator().manual_seed(0)
+    for seed, n_obj in ((3, 3), (4, 5), (3, 3)):
+        _, targets = make_batch(B, seed=seed, n_objects=n_obj, input_size=(320, 96), device=cuda)
+        cls = torch.sigmoid(torch.randn(B, 1, H, W, generator=g)).clamp(1e-4, 1 - 1e-4).to(cuda)
+        pois = (torch.randn(B, M, C, generator=g) * 0.3).to(cuda)
+        res = []
+        for use_graph in (False, True):
+            lc.use_graph = use_graph
+            c, p = cls.clone().requires_grad_(), pois.clone().requires_grad_()
+            loss_dict, log = lc({'cls': c, 'reg': None, 'reg_pois': p}, targets)
+            sum(loss_dict.values()).backward()
+            res.append(({k: float(v) for k, v in loss_dict.items()}, c.grad.clone(), p.grad.clone(), dict(log)))
+        (l0, gc0, gp0, log0), (l1, gc1, gp1, log1) = res
+        for k in l0:
+            assert abs(l0[k] - l1[k]) <= 1e-5 * max(abs(l0[k]), 1e-3), (seed, k, l0[k], l1[k])
+        assert (gc0 - gc1).abs().max().item() <= 1e-6 * max(gc0.abs().max().item(), 1e-6)
+        assert (gp0 - gp1).abs().max().item() <= 1e-5 * max(gp0.abs().max().item(), 1e-6)
+        assert set(log0) == set(log1)
+    assert len(lc._graphs) == 1          # one capture served all three batches
