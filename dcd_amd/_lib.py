@@ -87,8 +87,10 @@ def ptr(t):
 
 
 def stream_of(t):
+    """Raw hipStream_t of torch's current stream on the tensor's device (the direct binding: `torch.cuda.current_stream()`
+    builds a Stream object per call, 6 us x 1100 calls per step)."""
     import torch
-    return torch.cuda.current_stream(t.device).cuda_stream
+    return torch._C._cuda_getCurrentRawStream(t.device.index)
 
 
 def require_cuda(*tensors):

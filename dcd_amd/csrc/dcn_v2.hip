@@ -1534,7 +1534,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
 
     const int total = far_only_absmax ? (int)far_scal[1] : g.B * tiles_per_img;
     const int t0 = (int)((int64_t)blockIdx.y * total / nsplit), t1 = (int)((int64_t)(blockIdx.y + 1) * total / nsplit);
+    if (t0 >= t1) return;                     // fewer listed tiles than splits: nothing to add, nothing to flush
     float *myT = colT + wave * 32 * 33;
+    bool any_act = false;                     // did this wave (tap) accumulate anything?  (wave-uniform)
 
     // Three-deep software pipeline over the (image, tile) sequence of this block:
     //   stage R: raw offset/mask loads of tile ti+2      (feeds address generation)
@@ -1599,6 +1601,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
     for (int ti = t0; ti < t1; ++ti) {
         // registers of tile ti -> LDS: sampled columns colT[row][pixel], dY tile dyT[o][pixel]
         const bool act = act_cur;
+        any_act |= act;
         if (act)
 #pragma unroll
         for (int q = 0; q < 16; ++q) {
@@ -1646,7 +1649,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_weight_f32(const float *__restric
         for (int it = 0; it < 16; ++it) {
             const int ol = 2 * it + h;
             const int o = (ob0 + mb) * 32 + ol;
-            if (rbv && o < g.Co && cc < g.cpg) atomicAdd(gw + ((size_t)o * g.C + grp * g.cpg + cc) * g.KK + t, myT[p * 33 + ol]);
+            if (any_act && rbv && o < g.Co && cc < g.cpg)
+                atomicAdd(gw + ((size_t)o * g.C + grp * g.cpg + cc) * g.KK + t, myT[p * 33 + ol]);
         }
     }
 }

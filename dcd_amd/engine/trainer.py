@@ -7,6 +7,7 @@ Mirrors the semantics of the reference's harness without copying it:
   train_step       <- DGDE/engine/trainer.py:121-155  forward, sum of losses, backward, clip, optimizer step
 """
 import math
+import weakref
 
 import torch
 from torch import nn
@@ -134,6 +135,29 @@ def wrap_distributed(model, cfg, local_rank):
     return nn.parallel.DistributedDataParallel(model, **kw)
 
 
+_PARAM_LISTS = weakref.WeakKeyDictionary()
+
+
+def _parameters_of(model):
+    """`list(model.parameters())`, built once per model: the module-tree walk costs 1.2 ms per step, which shows at one
+    image per GPU where the step is launch-bound (tools/cpu_profile_step.py)."""
+    params = _PARAM_LISTS.get(model)
+    if params is None:
+        params = _PARAM_LISTS[model] = list(model.parameters())
+    return params
+
+
+def clip_grad_norm(params, max_norm):
+    """`torch.nn.utils.clip_grad_norm_(params, max_norm)` (2-norm, the reference's call, DGDE/engine/trainer.py:144)
+    without its per-call grouping by device / dtype: three multi-tensor launches, no host sync."""
+    grads = [p.grad for p in params if p.grad is not None]
+    if not grads:
+        return torch.zeros(())
+    total = torch.linalg.vector_norm(torch.stack(torch._foreach_norm(grads)))
+    torch._foreach_mul_(grads, (max_norm / (total + 1e-6)).clamp(max=1.0))
+    return total
+
+
 def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler=None, iteration=None):
     """One optimisation step; returns (loss_dict, log_loss_dict)."""
     loss_dict, log_loss_dict = model(images, targets)
@@ -141,7 +165,7 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler
     optimizer.zero_grad(set_to_none=True)
     losses.backward()
     if grad_norm_clip and grad_norm_clip > 0:
-        nn.utils.clip_grad_norm_(model.parameters(), grad_norm_clip)
+        clip_grad_norm(_parameters_of(model), grad_norm_clip)
     optimizer.step()
     if scheduler is not None:
         scheduler.step(iteration) if iteration is not None else scheduler.step()
