@@ -249,6 +249,204 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     }
 }
 
+
+// ---------------------------------------------------------------------------------------------
+// Weight gradient of the same convolution, also in the Winograd domain:
+//   dL/dg = G^T [ sum_tiles (A E A^T) . (B^T d B) ] G        (E = 2x2 tile of dL/dY, d = 4x4 input tile)
+// i.e. sixteen [Cout x tiles] x [tiles x Cin] products (4 multiplies per output pixel and (k,c) pair instead of 9), then a
+// 4x4 -> 3x3 transform of the sums.  The contraction runs over TILES, so both MFMA operands want lane = channel:
+//   A[i = k][kk = tile parity]  = (A E A^T)[xi][nu] of output channel k,   B[kk][j = c] = (B^T d B)[xi][nu] of channel c,
+// both built on the fly from raw tiles in LDS (plane strides 2 * odd: 32 channels -> 32 distinct even banks, the ds_read2
+// partner on the odd ones).  One workgroup = 8 waves = 4 transform rows (xi) x 2 input-channel blocks; it owns 64 output x
+// 64 input channels (wave: 4 nu x 2 output blocks = 8 accumulators) and walks its share of the (image, tile row, 32-column)
+// strips: 64 x 4 x 40 input window + 64 x 2 x 32 dY tile per strip, prefetched through registers.  Partial sums go to the
+// workspace with coalesced stores; wino_wrw_reduce adds the splits in a fixed order and applies G^T . G.
+// Workgroups that share strips (the other channel blocks of the same split) are dealt to the same XCD so the re-reads hit L2.
+// ---------------------------------------------------------------------------------------------
+constexpr int WW_NT = 512;
+constexpr int WW_IROW = 40;                        // staged columns c0-4 .. c0+35
+constexpr int WW_IPLANE = 4 * WW_IROW + 2;         // 162 = 2 * 81
+constexpr int WW_DPLANE = 2 * 32 + 2;              // 66 = 2 * 33
+constexpr int WW_IN = 64 * WW_IPLANE;              // 10 368 floats
+constexpr int WW_DY = 64 * WW_DPLANE;              // 4 224 floats
+constexpr int WW_PART = 16 * 64 * 64;              // floats per partial result
+
+__global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict__ x, const float *__restrict__ gy,
+                                                         float *__restrict__ part, int Cin, int Cout, int B, int H, int W,
+                                                         int strips_x, int S, int ncg, int nblk)
+{
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [WW_IN | WW_DY]
+    float *win = lds, *dyt = lds + WW_IN;
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = tid >> 6;
+    const int p = lane & 31, h = lane >> 5;
+    const int xi = wave & 3, cb = wave >> 2;
+    // (split, channel block) of this workgroup; with S % 8 == 0 the nblk blocks of one split sit on one XCD
+    int split, blk;
+    {
+        const int L = blockIdx.x;
+        if ((S & 7) == 0) {
+            const int xcd = L & 7, u = L >> 3;
+            blk = u % nblk;
+            split = (u / nblk) * 8 + xcd;
+        } else {
+            blk = L % nblk;
+            split = L / nblk;
+        }
+    }
+    const int og = blk / ncg, cg = blk - og * ncg;
+    const int HW = H * W;
+    const int tiles_y = H >> 1;
+    const int T = B * tiles_y * strips_x;
+    const int t0 = (int)((int64_t)split * T / S), t1 = (int)((int64_t)(split + 1) * T / S);
+
+    const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
+    const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
+    // (A E)[xi][j] = ea E[0][j] + eb E[1][j]
+    const float ea = xi == 3 ? 0.f : 1.f, eb = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
+
+    // ---- staging maps (strip invariant)
+    constexpr int KIN = 64 * 4 * 10 / WW_NT;       // 5 dwordx4 per thread
+    constexpr int KDY = 64 * 2 * 8 / WW_NT;        // 2
+    int in_ch[KIN], in_row[KIN], in_q[KIN], dy_o[KDY], dy_row[KDY], dy_q[KDY];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+        const int e = tid + WW_NT * k;
+        in_ch[k] = e / 40;
+        const int rem = e - in_ch[k] * 40;
+        in_row[k] = rem / 10;
+        in_q[k] = rem - in_row[k] * 10;
+    }
+#pragma unroll
+    for (int k = 0; k < KDY; ++k) {
+        const int e = tid + WW_NT * k;
+        dy_o[k] = e >> 4;
+        const int rem = e & 15;
+        dy_row[k] = rem >> 3;
+        dy_q[k] = rem & 7;
+    }
+    f32x4 rin[KIN], rdy[KDY];
+    auto issue = [&](int t) {
+        const int b = t / (tiles_y * strips_x);
+        const int rem = t - b * (tiles_y * strips_x);
+        const int ty = rem / strips_x, sx = rem - ty * strips_x;
+        const int r0 = 2 * ty, c0 = 32 * sx;
+        const float *x_b = x + ((size_t)b * Cin + (size_t)cg * 64) * HW;
+        const float *g_b = gy + ((size_t)b * Cout + (size_t)og * 64) * HW;
+        const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            const int yy = r0 - 1 + in_row[k], xx = c0 - 4 + 4 * in_q[k];
+            rin[k] = zero4;
+            if (cg * 64 + in_ch[k] < Cin && yy >= 0 && yy < H && xx >= 0 && xx < W)
+                rin[k] = *reinterpret_cast<const f32x4 *>(x_b + (size_t)in_ch[k] * HW + yy * W + xx);
+        }
+#pragma unroll
+        for (int k = 0; k < KDY; ++k) {
+            const int yy = r0 + dy_row[k], xx = c0 + 4 * dy_q[k];
+            rdy[k] = zero4;
+            if (og * 64 + dy_o[k] < Cout && xx < W)
+                rdy[k] = *reinterpret_cast<const f32x4 *>(g_b + (size_t)dy_o[k] * HW + yy * W + xx);
+        }
+    };
+    auto commit = [&]() {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            float *d = win + in_ch[k] * WW_IPLANE + in_row[k] * WW_IROW + 4 * in_q[k];
+            *reinterpret_cast<f32x2 *>(d) = f32x2{rin[k].x, rin[k].y};
+            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rin[k].z, rin[k].w};
+        }
+#pragma unroll
+        for (int k = 0; k < KDY; ++k) {
+            float *d = dyt + dy_o[k] * WW_DPLANE + dy_row[k] * 32 + 4 * dy_q[k];
+            *reinterpret_cast<f32x2 *>(d) = f32x2{rdy[k].x, rdy[k].y};
+            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rdy[k].z, rdy[k].w};
+        }
+    };
+
+    f32x16 acc[4][2];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][ob][r] = 0.f;
+
+    // lane = (channel p, tile parity h): tile 2s+h of the strip has its 4x4 input patch at window columns 3+4s+2h .. +3
+    const float *ia = win + (cb * 32 + p) * WW_IPLANE + ra * WW_IROW + 3 + 2 * h;
+    const float *ib = win + (cb * 32 + p) * WW_IPLANE + rb * WW_IROW + 3 + 2 * h;
+    const float *d0 = dyt + p * WW_DPLANE + 2 * h, *d1 = d0 + 32 * WW_DPLANE;
+
+    if (t0 < t1) issue(t0);
+    for (int t = t0; t < t1; ++t) {
+        __syncthreads();                           // previous strip fully consumed
+        commit();
+        __syncthreads();
+        if (t + 1 < t1) issue(t + 1);
+#pragma unroll 2
+        for (int s = 0; s < 8; ++s) {
+            const float *q1 = ia + 4 * s, *q2 = ib + 4 * s;
+            const float u0 = sa * q1[0] + sb * q2[0], u1 = sa * q1[1] + sb * q2[1];
+            const float u2 = sa * q1[2] + sb * q2[2], u3 = sa * q1[3] + sb * q2[3];
+            const float v[4] = {u0 - u2, u1 + u2, u2 - u1, u1 - u3};
+            const float *e0 = d0 + 4 * s, *e1 = d1 + 4 * s;
+            const float a0 = ea * e0[0] + eb * e0[32], a1 = ea * e0[1] + eb * e0[33];
+            const float b0 = ea * e1[0] + eb * e1[32], b1 = ea * e1[1] + eb * e1[33];
+            const float wa[4] = {a0, a0 + a1, a0 - a1, -a1};
+            const float wb[4] = {b0, b0 + b1, b0 - b1, -b1};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) {
+                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
+                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][1], 0, 0, 0);
+            }
+        }
+    }
+
+    // acc[nu][ob][r] = M[xi][nu][k = 32 ob + (r&3) + 8 (r>>2) + 4h][c = 32 cb + p]  ->  part[blk][split][xi*4+nu][k][c]
+    float *mine = part + ((size_t)blk * S + split) * WW_PART;
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int ob = 0; ob < 2; ++ob)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) {
+                const int k = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+                mine[((xi * 4 + nu) * 64 + k) * 64 + cb * 32 + p] = acc[nu][ob][r];
+            }
+}
+
+// grid = (nblk * 4096 / 16), block = 256 = 16 positions x 16 (k,c) pairs: sums the S partials of its 16 pairs (fixed order:
+// reproducible), exchanges the 16 positions through LDS and writes dw = G^T M G.
+__global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__ part, float *__restrict__ gw, int Cin, int Cout, int S,
+                                                       int ncg)
+{
+    __shared__ float m[16][17];
+    const int tid = threadIdx.x;
+    const int pos = tid >> 4, l = tid & 15;
+    const int gidx = blockIdx.x * 16 + l;           // (blk, k, c)
+    const int blk = gidx >> 12, kc = gidx & 4095;
+    const float *src = part + ((size_t)blk * S * 16 + pos) * 4096 + kc;
+    float sum = 0.f;
+#pragma unroll 8
+    for (int sp = 0; sp < S; ++sp) sum += src[(size_t)sp * WW_PART];
+    m[pos][l] = sum;
+    __syncthreads();
+    if (pos < 9) {
+        const int a = pos / 3, b = pos - a * 3;
+        // G^T rows: a = 0: (1, .5, .5, 0)   1: (0, .5, -.5, 0)   2: (0, .5, .5, 1)
+        const float ga[4] = {a == 0 ? 1.f : 0.f, 0.5f, a == 1 ? -0.5f : 0.5f, a == 2 ? 1.f : 0.f};
+        const float gb[4] = {b == 0 ? 1.f : 0.f, 0.5f, b == 1 ? -0.5f : 0.5f, b == 2 ? 1.f : 0.f};
+        float r = 0.f;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi)
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu) r += ga[xi] * gb[nu] * m[xi * 4 + nu][l];
+        const int og = blk / ncg, cg = blk - og * ncg;
+        const int k = og * 64 + (kc >> 6), c = cg * 64 + (kc & 63);
+        if (k < Cout && c < Cin) gw[((size_t)k * Cin + c) * 9 + pos] = r;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -287,6 +485,51 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *o
     const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
     hipLaunchKernelGGL(wino_conv3x3_f32, dim3(tiles_x * tiles_y, B, nz), dim3(WN_NT), ldsb, stream, input, ul, output, Cc, H, W, Kk,
                        tiles_x, nchunk);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int &ncg, int &S, int &strips_x)
+{
+    nog = (Cout + 63) / 64;
+    ncg = (Cin + 63) / 64;
+    strips_x = (W + 31) / 32;
+    const int T = B * (H / 2) * strips_x;
+    S = 256 / (nog * ncg);                        // about one workgroup per CU
+    if (S >= 8) S &= ~7;
+    if (S < 1) S = 1;
+    if (S > T) S = T;
+}
+
+size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout)
+{
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    int nog, ncg, S, sx;
+    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, sx);
+    return (size_t)nog * ncg * S * WW_PART * sizeof(float);
+}
+
+int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
+                    int Cout, void *workspace, size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!input || !grad_output || !grad_weight || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    int nog, ncg, S, strips_x;
+    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x);
+    const int nblk = nog * ncg;
+    if (workspace_bytes < (size_t)nblk * S * WW_PART * sizeof(float)) return DCD_ERR_WORKSPACE;
+    static bool attr_set = false;
+    const size_t ldsb = (size_t)(WW_IN + WW_DY) * sizeof(float);
+    if (!attr_set) {
+        if (hipFuncSetAttribute((const void *)wino_wrw3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
+            return DCD_ERR_LAUNCH;
+        attr_set = true;
+    }
+    hipLaunchKernelGGL(wino_wrw3x3_f32, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout, B,
+                       H, W, strips_x, S, ncg, nblk);
+    hipLaunchKernelGGL(wino_wrw_reduce, dim3(nblk * 4096 / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout, S,
+                       ncg);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -9,6 +9,8 @@ reads like the reference's:
   nms_hm / select_topk / select_point_of_interest                   (DGDE/model/layers/utils.py:45-145)
 All of them run on the GPU only and raise if the HIP library is missing.
 """
+import os
+
 import torch
 
 from . import _lib
@@ -372,9 +374,25 @@ def _conv3x3_call(inp, weight, out_channels, backward_data):
     return out
 
 
+_WRW_ENABLED = os.environ.get("DCD_CONV_WRW", "1") != "0"        # 0: weight gradient on the stock op (A/B timing)
+
+
+def _conv3x3_wrw_call(x, gy, wshape):
+    L = _lib.lib()
+    B, Ci, H, W = x.shape
+    Co = wshape[0]
+    gw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
+    n = L.dcd_conv3x3_wrw_workspace_bytes(B, Ci, H, W, Co)
+    ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+    st = L.dcd_conv3x3_wrw(_lib.stream_of(x), x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Ci, H, W, Co, ws.data_ptr(), n)
+    _lib.check(st, "dcd_conv3x3_wrw")
+    return gw
+
+
 class _Conv3x3(torch.autograd.Function):
-    """y = conv2d(x, w, stride 1, padding 1) and dL/dx on csrc/conv.hip; dL/dw on the stock op (MIOpen's MFMA
-    implicit-GEMM weight-gradient kernels already run near the fp32 matrix peak)."""
+    """y = conv2d(x, w, stride 1, padding 1), dL/dx and dL/dw on csrc/conv.hip (Winograd F(2x2,3x3) on the fp32 matrix
+    pipe; MIOpen's implicit-GEMM weight gradient runs near the fp32 matrix peak but does 2.25x the multiplies and needs
+    NHWC transposes of both operands)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -392,8 +410,11 @@ class _Conv3x3(torch.autograd.Function):
         if ctx.needs_input_grad[0]:
             gx = _conv3x3_call(gy, weight, weight.shape[1], True)
         if ctx.needs_input_grad[1]:
-            gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
-                                                     [False, True, False])[1]
+            if _WRW_ENABLED:
+                gw = _conv3x3_wrw_call(x, gy, weight.shape)
+            else:
+                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
         return gx, gw
 
 

@@ -220,7 +220,7 @@ int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const flo
  * F(2x2,3x3) on the fp32 matrix pipe).  Replaces the stock `nn.Conv2d(.., 3, padding=1, bias=False)` calls of
  *   DGDE/model/backbone/dla_dcn.py:76-82 (BasicBlock.conv1/conv2 at stride 1) and
  *   DGDE/model/head/detector_predictor.py:52-58,112-118 (the 64->256 trunks of the class / regression heads),
- * i.e. torch's cudnn/MIOpen convolution and its input gradient.  The weight gradient stays on the stock op.
+ * i.e. torch's cudnn/MIOpen convolution and its input gradient (weight gradient: dcd_conv3x3_wrw below).
  * weight (Cout,Cin,3,3).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
  *                         backward_data = 1: input = grad_output (B,Cout,H,W) -> output = grad_input (B,Cin,H,W).
  * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(Cin, Cout) bytes
@@ -229,6 +229,14 @@ int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const flo
 size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout);
 int dcd_conv3x3(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
                 int Cout, int backward_data, void *workspace, size_t workspace_bytes);
+
+/* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
+ * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
+ * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).
+ * Same shape requirements; workspace: dcd_conv3x3_wrw_workspace_bytes(B, Cin, H, W, Cout) bytes, dead after the call. */
+size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int dcd_conv3x3_wrw(void *stream, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
+                    int Cout, void *workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * Depthwise transposed convolution of IDAUp: nn.ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)

@@ -12,6 +12,7 @@ CASES = [  # B, Cin, Cout, H, W
     (2, 72, 80, 10, 36),       # ragged: partial regions, partial channel chunk / output slice
     (1, 256, 64, 8, 32),       # small map: kernel called directly (the dispatcher would pick the stock op)
     (1, 128, 128, 48, 160),
+    (3, 64, 64, 96, 176),      # 5.5 column strips, many splits of the weight-gradient tiles
 ]
 
 
@@ -36,7 +37,7 @@ def test_conv3x3_forward_and_input_grad(cuda, B, C, K, H, W):
     y.backward(gy.to(cuda))
     _close(y.detach().cpu(), ref.detach(), "forward")
     _close(xg.grad.cpu(), xd.grad, "grad_input")
-    _close(wg.grad.cpu(), wd.grad, "grad_weight (stock op)", 1e-4)
+    _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
 
 
 def test_conv_module_dispatch(cuda):

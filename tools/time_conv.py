@@ -32,5 +32,8 @@ for C, K, H, W in SHAPES:
     b = t(lambda: F.conv2d(x, w, padding=1))
     c = t(lambda: ops._conv3x3_call(gy, w, C, True))
     d = t(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
+    e = t(lambda: ops._conv3x3_wrw_call(x, gy, w.shape))
+    f = t(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
+    print("%4d->%3d @%3dx%3d  wrw hip %.3f ms (%.0f TF eff) | miopen %.3f (%.0f)" % (C, K, H, W, e, fl / e / 1e9, f, fl / f / 1e9))
     print("%4d->%3d @%3dx%3d  fwd hip %.3f ms (%.0f TF eff) | miopen %.3f (%.0f)   bwd-data hip %.3f (%.0f) | miopen %.3f (%.0f)" % (
         C, K, H, W, a, fl / a / 1e9, b, fl / b / 1e9, c, fl / c / 1e9, d, fl / d / 1e9))
