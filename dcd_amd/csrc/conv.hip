@@ -259,7 +259,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 // both built on the fly from raw tiles in LDS (plane strides 2 * odd: 32 channels -> 32 distinct even banks, the ds_read2
 // partner on the odd ones).  One workgroup = 8 waves = 4 transform rows (xi) x 2 input-channel blocks; it owns 64 output x
 // 64 input channels (wave: 4 nu x 2 output blocks = 8 accumulators) and walks its share of the (image, tile row, 32-column)
-// strips: 64 x 4 x 40 input window + 64 x 2 x 32 dY tile per strip, prefetched through registers.  Partial sums go to the
+// strips: 64 x 4 x 40 input window + 64 x 2 x 32 dY tile per strip, prefetched through registers into one of two LDS buffers.  Partial sums go to the
 // workspace with coalesced stores; wino_wrw_reduce adds the splits in a fixed order and applies G^T . G.
 // Workgroups that share strips (the other channel blocks of the same split) are dealt to the same XCD so the re-reads hit L2.
 // ---------------------------------------------------------------------------------------------
@@ -269,14 +269,14 @@ constexpr int WW_IPLANE = 4 * WW_IROW + 2;         // 162 = 2 * 81
 constexpr int WW_DPLANE = 2 * 32 + 2;              // 66 = 2 * 33
 constexpr int WW_IN = 64 * WW_IPLANE;              // 10 368 floats
 constexpr int WW_DY = 64 * WW_DPLANE;              // 4 224 floats
+constexpr int WW_BUF = WW_IN + WW_DY;              // 14 592 floats (58 KB) per buffer
 constexpr int WW_PART = 16 * 64 * 64;              // floats per partial result
 
 __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ part, int Cin, int Cout, int B, int H, int W,
                                                          int strips_x, int S, int ncg, int nblk)
 {
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // [WW_IN | WW_DY]
-    float *win = lds, *dyt = lds + WW_IN;
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x [WW_IN | WW_DY]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -349,16 +349,16 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
                 rdy[k] = *reinterpret_cast<const f32x4 *>(g_b + (size_t)dy_o[k] * HW + yy * W + xx);
         }
     };
-    auto commit = [&]() {
+    auto commit = [&](float *buf) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k) {
-            float *d = win + in_ch[k] * WW_IPLANE + in_row[k] * WW_IROW + 4 * in_q[k];
+            float *d = buf + in_ch[k] * WW_IPLANE + in_row[k] * WW_IROW + 4 * in_q[k];
             *reinterpret_cast<f32x2 *>(d) = f32x2{rin[k].x, rin[k].y};
             *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rin[k].z, rin[k].w};
         }
 #pragma unroll
         for (int k = 0; k < KDY; ++k) {
-            float *d = dyt + dy_o[k] * WW_DPLANE + dy_row[k] * 32 + 4 * dy_q[k];
+            float *d = buf + WW_IN + dy_o[k] * WW_DPLANE + dy_row[k] * 32 + 4 * dy_q[k];
             *reinterpret_cast<f32x2 *>(d) = f32x2{rdy[k].x, rdy[k].y};
             *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rdy[k].z, rdy[k].w};
         }
@@ -372,26 +372,56 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][ob][r] = 0.f;
 
-    // lane = (channel p, tile parity h): tile 2s+h of the strip has its 4x4 input patch at window columns 3+4s+2h .. +3
-    const float *ia = win + (cb * 32 + p) * WW_IPLANE + ra * WW_IROW + 3 + 2 * h;
-    const float *ib = win + (cb * 32 + p) * WW_IPLANE + rb * WW_IROW + 3 + 2 * h;
-    const float *d0 = dyt + p * WW_DPLANE + 2 * h, *d1 = d0 + 32 * WW_DPLANE;
+    // lane = (channel p, strip half h): it walks the eight consecutive tiles 8h .. 8h+7, whose 4x4 input patches overlap by
+    // two columns -- the row-transformed columns u2,u3 of one tile are u0,u1 of the next, so a step reads two new columns
+    // per transform row (one ds_read2_b32 each) and the 2x2 dY tiles of its two output blocks.
+    const int lane_in = (cb * 32 + p) * WW_IPLANE + 3 + 16 * h;
+    const int lane_dy = p * WW_DPLANE + 16 * h;
 
-    if (t0 < t1) issue(t0);
+    // Two LDS buffers, one barrier per strip: while strip t is multiplied out of buffer t&1, the registers holding strip
+    // t+1 are written to the other buffer half-way through and re-loaded with strip t+2.
+    if (t0 < t1) {
+        issue(t0);
+        commit(lds);
+        if (t0 + 1 < t1) issue(t0 + 1);
+    }
+    __syncthreads();
     for (int t = t0; t < t1; ++t) {
-        __syncthreads();                           // previous strip fully consumed
-        commit();
-        __syncthreads();
-        if (t + 1 < t1) issue(t + 1);
-#pragma unroll 2
+        const float *bw = lds + ((t - t0) & 1) * WW_BUF;
+        float *nb = lds + (((t - t0) & 1) ^ 1) * WW_BUF;
+        const float *ia = bw + lane_in + ra * WW_IROW, *ib = bw + lane_in + rb * WW_IROW;
+        const float *d0 = bw + WW_IN + lane_dy, *d1 = d0 + 32 * WW_DPLANE;
+#ifdef WW_ABL_NOLDS
+        float u0 = sa, u1 = sb;
+#else
+        float u0 = sa * ia[0] + sb * ib[0], u1 = sa * ia[1] + sb * ib[1];
+#endif
+#pragma unroll
         for (int s = 0; s < 8; ++s) {
-            const float *q1 = ia + 4 * s, *q2 = ib + 4 * s;
-            const float u0 = sa * q1[0] + sb * q2[0], u1 = sa * q1[1] + sb * q2[1];
-            const float u2 = sa * q1[2] + sb * q2[2], u3 = sa * q1[3] + sb * q2[3];
-            const float v[4] = {u0 - u2, u1 + u2, u2 - u1, u1 - u3};
-            const float *e0 = d0 + 4 * s, *e1 = d1 + 4 * s;
+#ifndef WW_ABL_NOSTAGE
+            if (s == 4 && t + 1 < t1) {
+                commit(nb);
+                if (t + 2 < t1) issue(t + 2);
+            }
+#endif
+#ifdef WW_ABL_NOLDS
+            const float u2 = sa + (float)t, u3 = sb * (float)s;
+            const float a0 = ea * (float)t, a1 = eb, b0 = ea + (float)s, b1 = eb * (float)s;
+#else
+            const float u2 = sa * ia[2 * s + 2] + sb * ib[2 * s + 2], u3 = sa * ia[2 * s + 3] + sb * ib[2 * s + 3];
+#ifdef WW_DY_B32
+            const float *e0 = d0 + 2 * s, *e1 = d1 + 2 * s;
             const float a0 = ea * e0[0] + eb * e0[32], a1 = ea * e0[1] + eb * e0[33];
             const float b0 = ea * e1[0] + eb * e1[32], b1 = ea * e1[1] + eb * e1[33];
+#else
+            // 2x2 dY tile of each output block: two 8-byte-aligned pairs, 128 B apart (one ds_read2_b64)
+            const f32x2 g00 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s), g01 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 32);
+            const f32x2 g10 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s), g11 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 32);
+            const float a0 = ea * g00.x + eb * g01.x, a1 = ea * g00.y + eb * g01.y;
+            const float b0 = ea * g10.x + eb * g11.x, b1 = ea * g10.y + eb * g11.y;
+#endif
+#endif
+            const float v[4] = {u0 - u2, u1 + u2, u2 - u1, u1 - u3};
             const float wa[4] = {a0, a0 + a1, a0 - a1, -a1};
             const float wb[4] = {b0, b0 + b1, b0 - b1, -b1};
 #pragma unroll
@@ -399,10 +429,18 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
                 acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][1], 0, 0, 0);
             }
+            u0 = u2;
+            u1 = u3;
         }
+#ifndef WW_ABL_NOBAR
+        __syncthreads();
+#endif
     }
 
     // acc[nu][ob][r] = M[xi][nu][k = 32 ob + (r&3) + 8 (r>>2) + 4h][c = 32 cb + p]  ->  part[blk][split][xi*4+nu][k][c]
+#ifdef WW_ABL_NOEPI
+    if (acc[0][0][0] != 123.456f) return;
+#endif
     float *mine = part + ((size_t)blk * S + split) * WW_PART;
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
@@ -520,7 +558,7 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     const int nblk = nog * ncg;
     if (workspace_bytes < (size_t)nblk * S * WW_PART * sizeof(float)) return DCD_ERR_WORKSPACE;
     static bool attr_set = false;
-    const size_t ldsb = (size_t)(WW_IN + WW_DY) * sizeof(float);
+    const size_t ldsb = (size_t)2 * WW_BUF * sizeof(float);
     if (!attr_set) {
         if (hipFuncSetAttribute((const void *)wino_wrw3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
             return DCD_ERR_LAUNCH;

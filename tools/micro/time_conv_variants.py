@@ -7,6 +7,6 @@ try:
         shutil.copy(f, main)
         out = subprocess.run([sys.executable, os.path.join(R, "tools", "time_conv.py")], capture_output=True, text=True).stdout
         print(os.path.basename(f))
-        print("\n".join(l for l in out.splitlines()[:3]))
+        print("\n".join(l for l in out.splitlines()[:4]))
 finally:
     shutil.copy(main + ".bak", main)
