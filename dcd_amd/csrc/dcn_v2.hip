@@ -2139,6 +2139,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const int total_blocks = dg * nblk;
         int mbi = total_blocks >= 8 ? 8 : total_blocks >= 4 ? 4 : total_blocks >= 2 ? 2 : 1;
         while (mbi > 1 && (int64_t)in_tiles * B * ((total_blocks + mbi - 1) / mbi) < 1024) mbi >>= 1;
+        if (const char *e = getenv("DCD_BI_MB")) {              // A/B timing of the channel blocks per workgroup
+            const int v = atoi(e);
+            if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= total_blocks) mbi = v;
+        }
         dim3 grid((in_tiles + 3) / 4, B, (total_blocks + mbi - 1) / mbi), block(256);
         const int partner = bi_tiled ? 1 : 0;     // with the tiled kernel launched, this one only runs when the lists are too wide for it
         if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, partner);
