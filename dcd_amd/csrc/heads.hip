@@ -561,6 +561,31 @@ __global__ void iou3d_kernel(const float *__restrict__ A, const float *__restric
 
 inline int grid_for(int64_t n, int block) { int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
+// out = sum of n tensors (n <= 16) in one pass: the gradient of a feature map that fans out to the head trunks.
+struct SumSrcs {
+    const float *p[16];
+};
+
+__global__ __launch_bounds__(256) void sum_tensors_kernel(SumSrcs srcs, int n, float *out, int64_t n4, int64_t numel)
+{
+    const int64_t stride = (int64_t)gridDim.x * blockDim.x;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += stride) {
+        float4 a = reinterpret_cast<const float4 *>(srcs.p[0])[i];
+        for (int k = 1; k < n; ++k) {
+            const float4 v = reinterpret_cast<const float4 *>(srcs.p[k])[i];
+            a.x += v.x; a.y += v.y; a.z += v.z; a.w += v.w;
+        }
+        reinterpret_cast<float4 *>(out)[i] = a;
+    }
+    // tail (numel % 4 elements)
+    const int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t < numel) {
+        float a = srcs.p[0][t];
+        for (int k = 1; k < n; ++k) a += srcs.p[k][t];
+        out[t] = a;
+    }
+}
+
 }  // namespace
 
 extern "C" {
@@ -691,6 +716,26 @@ int dcd_iou3d(void *stream_, const float *pred_corners, const float *target_corn
     if (N == 0) return DCD_OK;
     if (!pred_corners || !target_corners || !iou || N < 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(iou3d_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred_corners, target_corners, N, iou);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_sum_tensors(void *stream_, const float *const *srcs, int n, float *out, int64_t numel)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (numel == 0) return DCD_OK;
+    if (!srcs || !out || n < 1 || n > 16 || numel < 0) return DCD_ERR_BAD_ARG;
+    SumSrcs a;
+    for (int k = 0; k < 16; ++k) {
+        a.p[k] = srcs[k < n ? k : 0];
+        if (!a.p[k] || ((uintptr_t)a.p[k] & 15)) return DCD_ERR_BAD_ARG;
+    }
+    if ((uintptr_t)out & 15) return DCD_ERR_BAD_ARG;
+    const int64_t n4 = numel / 4;
+    int64_t blocks = (n4 + 255) / 256;
+    if (blocks > 8192) blocks = 8192;
+    if (blocks < 1) blocks = 1;
+    hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, n4, numel);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -13,6 +13,7 @@ from torch.autograd.function import once_differentiable
 from torch.nn.modules.utils import _pair
 
 from dcd_amd import _ext as _backend
+from dcd_amd.model.layers.conv import Conv2d
 
 
 class _DCNv2(Function):
@@ -78,8 +79,8 @@ class DCN(DCNv2):
     def __init__(self, in_channels, out_channels, kernel_size, stride, padding, dilation=1, deformable_groups=1):
         super().__init__(in_channels, out_channels, kernel_size, stride, padding, dilation, deformable_groups)
         taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]
-        self.conv_offset_mask = nn.Conv2d(self.in_channels, 3 * taps, kernel_size=self.kernel_size,
-                                          stride=self.stride, padding=self.padding, bias=True)
+        self.conv_offset_mask = Conv2d(self.in_channels, 3 * taps, kernel_size=self.kernel_size,
+                                       stride=self.stride, padding=self.padding, bias=True)
         self.init_offset()
 
     def init_offset(self):

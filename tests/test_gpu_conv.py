@@ -87,3 +87,31 @@ def test_depthwise_upsample_module_dispatch(cuda):
     x = torch.randn(2, 16, 12, 40, device=cuda)
     ref = F.conv_transpose2d(x, up.weight, stride=2, padding=1, groups=16)
     _close(up(x).detach().cpu(), ref.detach().double().cpu(), "module forward", 1e-5)
+
+
+def test_fan_out_sums_gradients_in_one_pass(cuda):
+    from dcd_amd import ops
+    x = torch.randn(2, 5, 7, 9, device=cuda, requires_grad=True)          # 630 elements: exercises the non-multiple-of-4 tail
+    outs = ops.fan_out(x, 12)
+    ws = [torch.randn_like(x) for _ in outs]
+    sum((o * w).sum() for o, w in zip(outs, ws)).backward()
+    ref = torch.stack(ws).double().sum(0)
+    assert (x.grad.double() - ref).abs().max().item() < 1e-5
+    y = torch.randn(3, 4, device=cuda, requires_grad=True)
+    a, b_, c = ops.fan_out(y, 3)
+    (a.sum() * 2 + c.sum()).backward()                                    # one consumer unused
+    assert torch.allclose(y.grad, torch.full_like(y, 3.0))
+
+
+def test_conv_bias_gradient(cuda):
+    from dcd_amd.model.layers.conv import Conv2d
+    conv = Conv2d(32, 27, 3, padding=1, bias=True).to(cuda)
+    x = torch.randn(2, 32, 96, 352, device=cuda, requires_grad=True)
+    gy = torch.randn(2, 27, 96, 352, device=cuda)
+    conv(x).backward(gy)
+    got = (conv.bias.grad.clone(), conv.weight.grad.clone(), x.grad.clone())
+    conv.zero_grad(); x.grad = None
+    F.conv2d(x, conv.weight, conv.bias, padding=1).backward(gy)
+    _close(got[0].cpu(), conv.bias.grad.double().cpu(), "bias grad", 1e-5)
+    _close(got[1].cpu(), conv.weight.grad.double().cpu(), "weight grad", 1e-5)
+    _close(got[2].cpu(), x.grad.double().cpu(), "input grad", 1e-5)
