@@ -115,7 +115,7 @@ class DLA(nn.Module):
         super().__init__()
         self.channels = channels
         self.num_classes = num_classes
-        self.base_layer = nn.Sequential(nn.Conv2d(3, channels[0], 7, stride=1, padding=3, bias=False),
+        self.base_layer = nn.Sequential(Conv2d(3, channels[0], 7, stride=1, padding=3, bias=False),
                                         _bn(channels[0], relu=True), _relu_slot())
         self.level0 = self._make_conv_level(channels[0], channels[0], levels[0])
         self.level1 = self._make_conv_level(channels[0], channels[1], levels[1], stride=2)
@@ -128,8 +128,8 @@ class DLA(nn.Module):
     def _make_conv_level(inplanes, planes, convs, stride=1, dilation=1):
         mods = []
         for i in range(convs):
-            mods += [nn.Conv2d(inplanes, planes, 3, stride=stride if i == 0 else 1, padding=dilation, bias=False,
-                               dilation=dilation), _bn(planes, relu=True), _relu_slot()]
+            mods += [Conv2d(inplanes, planes, 3, stride=stride if i == 0 else 1, padding=dilation, bias=False,
+                            dilation=dilation), _bn(planes, relu=True), _relu_slot()]
             inplanes = planes
         return nn.Sequential(*mods)
 

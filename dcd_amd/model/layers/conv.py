@@ -12,6 +12,7 @@ from torch import nn
 from dcd_amd import ops
 
 _ENABLED = os.environ.get("DCD_CONV_WINOGRAD", "1") != "0"
+_STEM = os.environ.get("DCD_CONV_STEM", "1") != "0"          # 0: the two stem convolutions stay on the stock op (A/B timing)
 
 
 class Conv2d(nn.Conv2d):
@@ -20,6 +21,10 @@ class Conv2d(nn.Conv2d):
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
                 and ops.conv3x3_supported(x, self.weight)):
             return ops.conv3x3(x, self.weight)
+        if (_ENABLED and _STEM and self.bias is None and self.padding_mode == "zeros" and not isinstance(self.padding, str)
+                and ops.conv_stem_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups)
+                and (self.weight.shape[1] == 16 or not x.requires_grad)):
+            return ops.conv_stem(x, self.weight)
         if (_ENABLED and self.bias is not None and x.is_cuda and x.dtype == torch.float32 and self.groups == 1
                 and self.padding_mode == "zeros" and not isinstance(self.padding, str) and torch.is_grad_enabled()
                 and self.bias.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 1 << 16):

@@ -422,6 +422,61 @@ def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
 
 
+# ----------------------------------------------------------------------------------------------
+# Stem convolutions (3->16 7x7 and 16->16 3x3 at full resolution) on csrc/stem.hip
+# ----------------------------------------------------------------------------------------------
+def conv_stem_supported(x, weight, stride, padding, dilation, groups):
+    k = weight.shape[2]
+    return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[0] == 16 and weight.shape[2] == weight.shape[3]
+            and (weight.shape[1], k) in ((16, 3), (3, 7)) and tuple(stride) == (1, 1) and tuple(padding) == (k // 2, k // 2)
+            and tuple(dilation) == (1, 1) and groups == 1 and x.shape[3] % 4 == 0 and x.shape[2] * x.shape[3] >= 1 << 16)
+
+
+def _conv_stem_call(inp, weight, backward_data):
+    L = _lib.lib()
+    B, _, H, W = inp.shape
+    Co, Ci, k = weight.shape[0], weight.shape[1], weight.shape[2]
+    out = torch.empty((B, Ci if backward_data else Co, H, W), dtype=torch.float32, device=inp.device)
+    n = L.dcd_conv_stem_workspace_bytes(Ci, Co, k)
+    ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
+    st = L.dcd_conv_stem(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Ci, H, W, Co, k,
+                         1 if backward_data else 0, ws.data_ptr(), n)
+    _lib.check(st, "dcd_conv_stem")
+    return out
+
+
+class _ConvStem(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        ctx.save_for_backward(x, weight)
+        return _conv_stem_call(x, weight, False)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = _conv_stem_call(gy, weight, True)
+        if ctx.needs_input_grad[1]:
+            L = _lib.lib()
+            B, Ci, H, W = x.shape
+            Co, k = weight.shape[0], weight.shape[2]
+            gw = torch.empty_like(weight)
+            n = L.dcd_conv_stem_wrw_workspace_bytes(Ci, Co, k)
+            ws = torch.empty(n, dtype=torch.uint8, device=x.device)
+            st = L.dcd_conv_stem_wrw(_lib.stream_of(x), x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Ci, H, W, Co, k, ws.data_ptr(), n)
+            _lib.check(st, "dcd_conv_stem_wrw")
+        return gx, gw
+
+
+def conv_stem(x, weight):
+    return _ConvStem.apply(x, weight)
+
+
 class _FanOut(torch.autograd.Function):
     """n aliases of one tensor whose gradients are summed by ONE kernel (autograd would run n-1 pairwise additions, each
     a read-read-write pass over the map)."""

@@ -244,6 +244,22 @@ int dcd_conv3x3_wrw(void *stream, const float *input, const float *grad_output, 
                     int Cout, void *workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
+ * The low-channel, full-resolution convolutions of DLA-34's stem (csrc/stem.hip, v_mfma_f32_16x16x4_f32):
+ *   base_layer Conv2d(3, 16, 7, padding 3, bias=False)  DGDE/model/backbone/dla_dcn.py:236-240   (Cin 3,  ksize 7)
+ *   level0     Conv2d(16, 16, 3, padding 1, bias=False) DGDE/model/backbone/dla_dcn.py:241-242   (Cin 16, ksize 3)
+ * i.e. torch's conv2d / convolution_backward for those two call sites; any other (Cin, Cout, ksize) is a bad argument.
+ * stride 1, padding ksize/2, W % 4 == 0.  weight (16,Cin,k,k).  backward_data (Cin 16 only): input = grad_output -> output =
+ * grad_input.  dcd_conv_stem_wrw overwrites grad_weight (partials are combined with float atomics: order-dependent rounding).
+ * Workspaces: dcd_conv_stem_workspace_bytes / dcd_conv_stem_wrw_workspace_bytes, dead after the call's kernels complete.
+ * ---------------------------------------------------------------------------------------------- */
+size_t dcd_conv_stem_workspace_bytes(int Cin, int Cout, int ksize);
+int dcd_conv_stem(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W, int Cout,
+                  int ksize, int backward_data, void *workspace, size_t workspace_bytes);
+size_t dcd_conv_stem_wrw_workspace_bytes(int Cin, int Cout, int ksize);
+int dcd_conv_stem_wrw(void *stream, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
+                      int Cout, int ksize, void *workspace, size_t workspace_bytes);
+
+/* ------------------------------------------------------------------------------------------------
  * Depthwise transposed convolution of IDAUp: nn.ConvTranspose2d(C, C, 2f, stride=f, padding=f/2, groups=C, bias=False)
  * (DGDE/model/backbone/dla_dcn.py:416-421; weights from fill_up_weights :386-395, learnable), f in {2,4,8}.
  * x (B,C,H,W) -> y (B,C,H*f,W*f); weight (C,1,2f,2f).  Requires (W*f) % 4 == 0.  Backward overwrites grad_x and grad_weight.

@@ -115,3 +115,38 @@ def test_conv_bias_gradient(cuda):
     _close(got[0].cpu(), conv.bias.grad.double().cpu(), "bias grad", 1e-5)
     _close(got[1].cpu(), conv.weight.grad.double().cpu(), "weight grad", 1e-5)
     _close(got[2].cpu(), x.grad.double().cpu(), "input grad", 1e-5)
+
+
+@pytest.mark.parametrize("B,Ci,k,H,W", [(2, 16, 3, 40, 320), (1, 3, 7, 48, 384), (2, 16, 3, 19, 260), (1, 3, 7, 21, 196)])
+def test_stem_convolutions(cuda, B, Ci, k, H, W):
+    """csrc/stem.hip (16x16x4 MFMA direct conv) against torch's conv2d in fp64: forward, input gradient (16->16) and weight
+    gradient; the ragged cases have partial tiles in both directions."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(Ci * 100 + k)
+    x = torch.randn(B, Ci, H, W, generator=g)
+    w = torch.randn(16, Ci, k, k, generator=g) / (Ci * k * k) ** 0.5
+    gy = torch.randn(B, 16, H, W, generator=g)
+    xd, wd = x.double().requires_grad_(Ci == 16), w.double().requires_grad_()
+    ref = F.conv2d(xd, wd, padding=k // 2)
+    ref.backward(gy.double())
+    xg, wg = x.to(cuda).requires_grad_(Ci == 16), w.to(cuda).requires_grad_()
+    y = ops.conv_stem(xg, wg)
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref.detach(), "forward", 1e-5)
+    if Ci == 16:
+        _close(xg.grad.cpu(), xd.grad, "grad_input", 1e-5)
+    _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+
+
+def test_stem_dispatch(cuda):
+    from dcd_amd import ops
+    from dcd_amd.model.layers.conv import Conv2d
+    conv = Conv2d(16, 16, 3, padding=1, bias=False).to(cuda)
+    x = torch.randn(1, 16, 128, 512, device=cuda, requires_grad=True)
+    assert ops.conv_stem_supported(x, conv.weight, conv.stride, conv.padding, conv.dilation, conv.groups)
+    y = conv(x)
+    assert type(y.grad_fn).__name__ == "_ConvStemBackward"
+    base = Conv2d(3, 16, 7, padding=3, bias=False).to(cuda)
+    img = torch.randn(1, 3, 128, 512, device=cuda)
+    assert type(base(img).grad_fn).__name__ == "_ConvStemBackward"
+    assert type(base(img.requires_grad_()).grad_fn).__name__ != "_ConvStemBackward"      # no input gradient for the 7x7: stock op
