@@ -422,6 +422,40 @@ def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
 
 
+def conv3x3_wrw_only_supported(x, weight):
+    """Maps too small for the Winograd forward kernel (too few workgroups) where the weight-gradient kernel still wins
+    (256->256 @ 24x80: 0.14 vs 0.18 ms incl. the stock path's transposes; at 12x40 they tie, tools/time_conv.py)."""
+    return (_WRW_ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3
+            and weight.shape[3] == 3 and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] >= 64
+            and weight.shape[1] >= 64 and 24 * 80 <= x.shape[2] * x.shape[3] < 48 * 160)
+
+
+class _Conv3x3StockFwd(torch.autograd.Function):
+    """Stock forward and input gradient, weight gradient on csrc/conv.hip."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        ctx.save_for_backward(x, weight)
+        return torch.nn.functional.conv2d(x, weight, None, 1, 1)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
+                                                     [True, False, False])[0]
+        if ctx.needs_input_grad[1]:
+            gw = _conv3x3_wrw_call(_f32c(x), gy, weight.shape)
+        return gx, gw
+
+
+def conv3x3_stock_forward(x, weight):
+    return _Conv3x3StockFwd.apply(x, weight)
+
+
 # ----------------------------------------------------------------------------------------------
 # Stem convolutions (3->16 7x7 and 16->16 3x3 at full resolution) on csrc/stem.hip
 # ----------------------------------------------------------------------------------------------

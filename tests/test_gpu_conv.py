@@ -150,3 +150,17 @@ def test_stem_dispatch(cuda):
     img = torch.randn(1, 3, 128, 512, device=cuda)
     assert type(base(img).grad_fn).__name__ == "_ConvStemBackward"
     assert type(base(img.requires_grad_()).grad_fn).__name__ != "_ConvStemBackward"      # no input gradient for the 7x7: stock op
+
+
+def test_small_map_conv_uses_our_weight_gradient(cuda):
+    from dcd_amd.model.layers.conv import Conv2d
+    conv = Conv2d(64, 96, 3, padding=1, bias=False).to(cuda)
+    x = torch.randn(2, 64, 24, 80, device=cuda, requires_grad=True)
+    gy = torch.randn(2, 96, 24, 80, device=cuda)
+    y = conv(x)
+    assert type(y.grad_fn).__name__ == "_Conv3x3StockFwdBackward"
+    y.backward(gy)
+    xd, wd = x.detach().double().cpu().requires_grad_(), conv.weight.detach().double().cpu().requires_grad_()
+    F.conv2d(xd, wd, padding=1).backward(gy.double().cpu())
+    _close(conv.weight.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+    _close(x.grad.cpu(), xd.grad, "grad_input", 1e-4)
