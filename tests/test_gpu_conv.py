@@ -164,3 +164,50 @@ def test_small_map_conv_uses_our_weight_gradient(cuda):
     F.conv2d(xd, wd, padding=1).backward(gy.double().cpu())
     _close(conv.weight.grad.cpu(), wd.grad, "grad_weight", 2e-5)
     _close(x.grad.cpu(), xd.grad, "grad_input", 1e-4)
+
+
+@pytest.mark.parametrize("C,K,H,W", [(64, 256, 96, 320), (128, 128, 48, 160)])
+def test_conv3x3_full_size_against_stock_solver(cuda, C, K, H, W):
+    """BASELINE size (bs 8): our three Winograd kernels against the stock fp32 solver on the same device tensors.  Both are
+    fp32 algorithms of the same class, so the comparison is relative to the result's scale; plus linearity of the weight
+    gradient in dY (a size-independent property: wrw(x, a*g1 + g2) = a*wrw(x, g1) + wrw(x, g2))."""
+    from dcd_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(C + K)
+    x = torch.randn(8, C, H, W, device=cuda, generator=g)
+    w = torch.randn(K, C, 3, 3, device=cuda, generator=g) / (C * 9) ** 0.5
+    gy = torch.randn(8, K, H, W, device=cuda, generator=g)
+    y = ops._conv3x3_call(x, w, K, False)
+    gx = ops._conv3x3_call(gy, w, C, True)
+    gw = ops._conv3x3_wrw_call(x, gy, w.shape)
+    ry = F.conv2d(x, w, padding=1)
+    rgx, rgw, _ = torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, True, False])
+    for a, r, what in ((y, ry, "forward"), (gx, rgx, "grad_input"), (gw, rgw, "grad_weight")):
+        err = (a - r).abs().max().item()
+        assert err <= 1e-4 * r.abs().max().item(), "%s: %.3e vs scale %.3e" % (what, err, r.abs().max().item())
+    g2 = torch.randn(8, K, H, W, device=cuda, generator=g)
+    lin = ops._conv3x3_wrw_call(x, 0.5 * gy + g2, w.shape)
+    ref = 0.5 * gw + ops._conv3x3_wrw_call(x, g2, w.shape)
+    assert (lin - ref).abs().max().item() <= 2e-5 * ref.abs().max().item()
+    again = ops._conv3x3_wrw_call(x, gy, w.shape)
+    assert torch.equal(again, gw), "weight gradient must be bitwise reproducible (fixed-order partial sums)"
+
+
+def test_stem_full_size_against_stock_solver(cuda):
+    from dcd_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(5)
+    for Ci, k in ((3, 7), (16, 3)):
+        x = torch.randn(8, Ci, 384, 1280, device=cuda, generator=g)
+        w = torch.randn(16, Ci, k, k, device=cuda, generator=g) / (Ci * k * k) ** 0.5
+        gy = torch.randn(8, 16, 384, 1280, device=cuda, generator=g)
+        xg, wg = x.clone().requires_grad_(Ci == 16), w.clone().requires_grad_()
+        y = ops.conv_stem(xg, wg)
+        y.backward(gy)
+        xr, wr = x.clone().requires_grad_(Ci == 16), w.clone().requires_grad_()
+        r = F.conv2d(xr, wr, padding=k // 2)
+        r.backward(gy)
+        pairs = [(y.detach(), r.detach(), "forward"), (wg.grad, wr.grad, "grad_weight")]
+        if Ci == 16:
+            pairs.append((xg.grad, xr.grad, "grad_input"))
+        for a, b, what in pairs:
+            err = (a - b).abs().max().item()
+            assert err <= 1e-4 * b.abs().max().item(), "%dx%d %s: %.3e vs scale %.3e" % (k, k, what, err, b.abs().max().item())
