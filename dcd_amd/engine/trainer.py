@@ -160,9 +160,11 @@ def clip_grad_norm(params, max_norm):
 
 def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler=None, iteration=None):
     """One optimisation step; returns (loss_dict, log_loss_dict)."""
+    optimizer.zero_grad(set_to_none=True)        # before the forward: nothing on the host between the loss and its backward
     loss_dict, log_loss_dict = model(images, targets)
-    losses = sum(loss_dict.values())
-    optimizer.zero_grad(set_to_none=True)
+    losses = getattr(loss_dict, "total", None)
+    if losses is None:
+        losses = sum(loss_dict.values())
     losses.backward()
     if grad_norm_clip and grad_norm_clip > 0:
         clip_grad_norm(_parameters_of(model), grad_norm_clip)

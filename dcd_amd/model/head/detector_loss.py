@@ -346,7 +346,7 @@ class Loss_Computation():
             def core_flat(cls, pois, hm, *fl):
                 loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, dict(zip(names, fl)))
                 meta['loss_keys'], meta['log_names'] = list(loss_dict), log_names
-                return tuple(loss_dict.values()) + (packed,)
+                return tuple(loss_dict.values()) + (sum(loss_dict.values()), packed)
             sample = (pred_heatmap.detach().clone().requires_grad_(True), reg_pois.detach().clone().requires_grad_(True),
                       targets_heatmap.detach().clone()) + tuple(t.detach().clone() for t in flat)
             if len(self._graphs) >= 4:                       # a few input shapes at most (e.g. the last, smaller batch)
@@ -355,7 +355,8 @@ class Loss_Computation():
             self._graphs[key] = entry
         graphed, meta = entry
         outs = graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
-        loss_dict = dict(zip(meta['loss_keys'], outs[:-1]))
+        loss_dict = LossDict(zip(meta['loss_keys'], outs[:-2]))
+        loss_dict.total = outs[-2]               # the sum, formed inside the graph: `total.backward()` needs no eager adds
         return loss_dict, LazyLogDict(meta['log_names'], outs[-1].clone(), list(loss_dict))
 
     def _core(self, predictions, targets_heatmap, targets_variables):
@@ -462,6 +463,12 @@ class Loss_Computation():
             vals.append(all_mae)
         packed = torch.stack([v.float().reshape(()) for v in vals])
         return loss_dict, names, packed
+
+
+class LossDict(dict):
+    """The 13-entry loss dict of the reference (detector_loss.py:582-623) plus `total`, the sum of its values when that sum
+    was already formed on the device (graph path); `engine.trainer.train_step` back-propagates `total` when present."""
+    total = None
 
 
 class LazyLogDict(dict):

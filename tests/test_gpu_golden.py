@@ -148,7 +148,13 @@ def test_graphed_loss_equals_eager_loss_on_changing_targets(cuda):
             lc.use_graph = use_graph
             c, p = cls.clone().requires_grad_(), pois.clone().requires_grad_()
             loss_dict, log = lc({'cls': c, 'reg': None, 'reg_pois': p}, targets)
-            sum(loss_dict.values()).backward()
+            if use_graph:                      # the graph also forms the sum; train_step back-propagates that one tensor
+                total = loss_dict.total
+                assert abs(float(total) - sum(float(v) for v in loss_dict.values())) <= 1e-5 * abs(float(total))
+                total.backward()
+            else:
+                assert getattr(loss_dict, "total", None) is None
+                sum(loss_dict.values()).backward()
             res.append(({k: float(v) for k, v in loss_dict.items()}, c.grad.clone(), p.grad.clone(), dict(log)))
         (l0, gc0, gp0, log0), (l1, gc1, gp1, log1) = res
         for k in l0:
