@@ -74,20 +74,30 @@ __global__ void stem_prep_weights(const float *__restrict__ w, float *__restrict
     wp[e] = v;
 }
 
+// All loads of a thread are issued before the first LDS store (one exposed global-memory latency per tile, not one per quad).
 template <int CI, int KS, int PLANE>
 __device__ __forceinline__ void stage_window(float *__restrict__ win, const float *__restrict__ xb, int H, int W, int r0, int c0, int tid)
 {
     using C = StemCfg<CI, KS>;
     constexpr int Q = ST_RS / 4;                                  // 18 dwordx4 per row
+    constexpr int N = CI * C::ROWS * Q;
+    constexpr int IT = (N + 255) / 256;
     const int HW = H * W;
-    for (int e = tid; e < CI * C::ROWS * Q; e += 256) {
+    f32x4 v[IT];
+    int dst[IT];
+#pragma unroll
+    for (int i = 0; i < IT; ++i) {
+        const int e = tid + 256 * i;
         const int ch = e / (C::ROWS * Q), rem = e - ch * (C::ROWS * Q);
         const int row = rem / Q, q = rem - row * Q;
         const int yy = r0 - C::PAD + row, xx = c0 - 4 + 4 * q;
-        f32x4 v = {0.f, 0.f, 0.f, 0.f};
-        if (yy >= 0 && yy < H && xx >= 0 && xx < W) v = *reinterpret_cast<const f32x4 *>(xb + (size_t)ch * HW + (size_t)yy * W + xx);
-        *reinterpret_cast<f32x4 *>(win + ch * PLANE + row * ST_RS + 4 * q) = v;
+        v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+        dst[i] = e < N ? ch * PLANE + row * ST_RS + 4 * q : -1;
+        if (e < N && yy >= 0 && yy < H && xx >= 0 && xx < W) v[i] = *reinterpret_cast<const f32x4 *>(xb + (size_t)ch * HW + (size_t)yy * W + xx);
     }
+#pragma unroll
+    for (int i = 0; i < IT; ++i)
+        if (dst[i] >= 0) *reinterpret_cast<f32x4 *>(win + dst[i]) = v[i];
 }
 
 // grid = (tiles_x * tiles_y, B), block = 256.  x: (B, CI, H, W) -> y: (B, 16, H, W)
@@ -182,13 +192,24 @@ __global__ __launch_bounds__(256) void stem_wrw_f32(const float *__restrict__ x,
         __syncthreads();                                   // previous tile fully consumed
         stage_window<CI, KS, PLANE>(win, x + (size_t)b * CI * HW, H, W, r0, c0, tid);
         const float *gb = gy + (size_t)b * 16 * HW;
-        for (int e = tid; e < 16 * ST_R * (ST_C / 4); e += 256) {
-            const int o = e / (ST_R * 16), rem2 = e - o * (ST_R * 16);
-            const int row = rem2 >> 4, q = rem2 & 15;
-            const int yy = r0 + row, xx = c0 + 4 * q;
-            f32x4 v = {0.f, 0.f, 0.f, 0.f};
-            if (yy < H && xx < W) v = *reinterpret_cast<const f32x4 *>(gb + (size_t)o * HW + (size_t)yy * W + xx);
-            *reinterpret_cast<f32x4 *>(dyt + o * ST_DPLANE + row * ST_C + 4 * q) = v;
+        {
+            constexpr int ITD = 16 * ST_R * (ST_C / 4) / 256;          // 8 dwordx4 per thread
+            f32x4 v[ITD];
+#pragma unroll
+            for (int i = 0; i < ITD; ++i) {
+                const int e = tid + 256 * i;
+                const int o = e / (ST_R * 16), rem2 = e - o * (ST_R * 16);
+                const int row = rem2 >> 4, q = rem2 & 15;
+                const int yy = r0 + row, xx = c0 + 4 * q;
+                v[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+                if (yy < H && xx < W) v[i] = *reinterpret_cast<const f32x4 *>(gb + (size_t)o * HW + (size_t)yy * W + xx);
+            }
+#pragma unroll
+            for (int i = 0; i < ITD; ++i) {
+                const int e = tid + 256 * i;
+                const int o = e / (ST_R * 16), rem2 = e - o * (ST_R * 16);
+                *reinterpret_cast<f32x4 *>(dyt + o * ST_DPLANE + (rem2 >> 4) * ST_C + 4 * (rem2 & 15)) = v[i];
+            }
         }
         __syncthreads();
 #pragma unroll 1
