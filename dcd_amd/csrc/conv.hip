@@ -188,18 +188,30 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             a0[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
             a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
         }
+        // software pipeline over the four channel steps: the eight LDS values of step s+1 are requested before the eight
+        // MFMAs of step s are issued (in-order issue: otherwise their latency is exposed once the matrix pipe drains)
+        float qa[4], qb[4];
+#ifndef WN_ABL_NOLDS
+#pragma unroll
+        for (int j = 0; j < 4; ++j) { qa[j] = cp1[j]; qb[j] = cp2[j]; }
+#endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
             // row transform once per channel step: t[b] = sa d[ra][b] + sb d[rb][b], b = 0..3 (four ds_read2_b32), then the
             // four column combinations  nu 0: t0 - t2   1: t1 + t2   2: t2 - t1   3: t1 - t3
-            const float *q1 = cp1 + 2 * s * WN_PLANE, *q2 = cp2 + 2 * s * WN_PLANE;
 #ifdef WN_ABL_NOLDS
-            const float t0 = sa * (float)s, t1 = sb, t2 = sa + sb, t3 = (float)ck; (void)q1; (void)q2;
+            const float t0 = sa * (float)s, t1 = sb, t2 = sa + sb, t3 = (float)ck;
 #else
-            const float t0 = sa * q1[0] + sb * q2[0], t1 = sa * q1[1] + sb * q2[1];
-            const float t2 = sa * q1[2] + sb * q2[2], t3 = sa * q1[3] + sb * q2[3];
+            const float t0 = sa * qa[0] + sb * qb[0], t1 = sa * qa[1] + sb * qb[1];
+            const float t2 = sa * qa[2] + sb * qb[2], t3 = sa * qa[3] + sb * qb[3];
+            if (s + 1 < 4) {
+                const float *q1 = cp1 + 2 * (s + 1) * WN_PLANE, *q2 = cp2 + 2 * (s + 1) * WN_PLANE;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) { qa[j] = q1[j]; qb[j] = q2[j]; }
+            }
 #endif
             const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
+            __builtin_amdgcn_sched_barrier(0);               // keep the loads above ahead of the MFMAs below
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[nu][s], v[nu], acc[nu][0], 0, 0, 0);
@@ -391,10 +403,15 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         float *nb = lds + (((t - t0) & 1) ^ 1) * WW_BUF;
         const float *ia = bw + lane_in + ra * WW_IROW, *ib = bw + lane_in + rb * WW_IROW;
         const float *d0 = bw + WW_IN + lane_dy, *d1 = d0 + 32 * WW_DPLANE;
+        // software pipeline over the eight steps: the raw LDS values of step s+1 are requested before the eight MFMAs of
+        // step s are issued (in-order issue: loads placed after them would wait for the matrix pipe to accept all eight)
 #ifdef WW_ABL_NOLDS
         float u0 = sa, u1 = sb;
 #else
         float u0 = sa * ia[0] + sb * ib[0], u1 = sa * ia[1] + sb * ib[1];
+        float qa2 = ia[2], qa3 = ia[3], qb2 = ib[2], qb3 = ib[3];
+        f32x2 g00 = *reinterpret_cast<const f32x2 *>(d0), g01 = *reinterpret_cast<const f32x2 *>(d0 + 32);
+        f32x2 g10 = *reinterpret_cast<const f32x2 *>(d1), g11 = *reinterpret_cast<const f32x2 *>(d1 + 32);
 #endif
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
@@ -408,22 +425,20 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
             const float u2 = sa + (float)t, u3 = sb * (float)s;
             const float a0 = ea * (float)t, a1 = eb, b0 = ea + (float)s, b1 = eb * (float)s;
 #else
-            const float u2 = sa * ia[2 * s + 2] + sb * ib[2 * s + 2], u3 = sa * ia[2 * s + 3] + sb * ib[2 * s + 3];
-#ifdef WW_DY_B32
-            const float *e0 = d0 + 2 * s, *e1 = d1 + 2 * s;
-            const float a0 = ea * e0[0] + eb * e0[32], a1 = ea * e0[1] + eb * e0[33];
-            const float b0 = ea * e1[0] + eb * e1[32], b1 = ea * e1[1] + eb * e1[33];
-#else
+            const float u2 = sa * qa2 + sb * qb2, u3 = sa * qa3 + sb * qb3;
             // 2x2 dY tile of each output block: two 8-byte-aligned pairs, 128 B apart (one ds_read2_b64)
-            const f32x2 g00 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s), g01 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 32);
-            const f32x2 g10 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s), g11 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 32);
             const float a0 = ea * g00.x + eb * g01.x, a1 = ea * g00.y + eb * g01.y;
             const float b0 = ea * g10.x + eb * g11.x, b1 = ea * g10.y + eb * g11.y;
-#endif
+            if (s + 1 < 8) {
+                qa2 = ia[2 * s + 4]; qa3 = ia[2 * s + 5]; qb2 = ib[2 * s + 4]; qb3 = ib[2 * s + 5];
+                g00 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 2); g01 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 34);
+                g10 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 2); g11 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 34);
+            }
 #endif
             const float v[4] = {u0 - u2, u1 + u2, u2 - u1, u1 - u3};
             const float wa[4] = {a0, a0 + a1, a0 - a1, -a1};
             const float wb[4] = {b0, b0 + b1, b0 - b1, -b1};
+            __builtin_amdgcn_sched_barrier(0);               // keep the loads above ahead of the MFMAs below
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
