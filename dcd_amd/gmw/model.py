@@ -1,0 +1,104 @@
+"""GMW model (GMW/model/model.py:103-207) and its point-feature extractor (GMW/model/yi2018cvpr/model.py, ops.py).
+
+Same module tree, parameter names and construction order as the reference (so `torch.manual_seed(s); GMW()` gives the same
+weights and checkpoints are interchangeable): two extractors (4-D edges of the 2-D keypoints, 6-D edges of the 3-D ones),
+each `conv_in` + 12 residual blocks of 1x1 Conv1d with context normalisation; L2-normalised features -> pairwise distance
+matrix M (2628 x 2628 per object) -> `1 / diag(M)` as the regression weights and the Sinkhorn transport plan P.
+
+What differs from the reference is execution only: `edge_expand` gathers the 2628 upper-triangle pairs through a
+precomputed index (the reference expands to (B,73,73,C), transposes and `masked_select`s twice, model.py:128-152).
+The regression weights are `1 / diag(M)` of the same M that feeds Sinkhorn (the transport layer needs every entry).
+"""
+import torch
+from torch import nn
+from torch.nn import functional as F
+
+from .optimal_transport import RegularisedTransport
+
+
+def pairwise_l2_dist(x1, x2):
+    """res[..., i, j] = ||x1[..., i, :] - x2[..., j, :]||  (GMW/model/model.py:17-36: ||a||^2 + ||b||^2 - 2 a.b, clamped)."""
+    x1_norm2 = x1.pow(2).sum(dim=-1, keepdim=True)
+    x2_norm2 = x2.pow(2).sum(dim=-1, keepdim=True)
+    res = torch.baddbmm(x2_norm2.transpose(-2, -1), x1, x2.transpose(-2, -1), alpha=-2).add_(x1_norm2)
+    return res.clamp_min_(1e-30).sqrt_()
+
+
+class ContextNorm(nn.Module):
+    """`gcn` of yi2018cvpr/ops.py:5-17: per-sample, per-channel normalisation over the points (unbiased variance, eps 1e-3)."""
+
+    def forward(self, x):                                   # x: (B, C, K)
+        m = torch.mean(x, 2, keepdim=True)
+        v = torch.var(x, 2, keepdim=True)
+        return (x - m) * (1.0 / torch.sqrt(v + 1e-3))
+
+
+def _conv1d_layer(cin, cout, context_norm):
+    layers = [nn.Conv1d(cin, cout, 1)]
+    if context_norm:
+        layers.append(ContextNorm())
+    return nn.Sequential(*layers)
+
+
+class ResBlock(nn.Module):
+    """conv1d_resnet_block (ops.py:67-131) as configured by Net: preconv, conv1 + gcn, conv2 + gcn, ReLU, + input.
+    (`perform_bn` is hard-wired to False inside the block, ops.py:87-116, whatever `net_batchnorm` says.)"""
+
+    def __init__(self, channels, context_norm=True):
+        super().__init__()
+        self.preconv = _conv1d_layer(channels, channels, False)
+        self.conv1 = _conv1d_layer(channels, channels, context_norm)
+        self.conv2 = _conv1d_layer(channels, channels, context_norm)
+
+    def forward(self, x):
+        return F.relu(self.conv2(self.conv1(self.preconv(x)))) + x
+
+
+class FeatureExtractor(nn.Module):
+    """yi2018cvpr `Net` with its defaults (config.py:70-84): depth 12, 128 channels, context norm on."""
+
+    def __init__(self, in_channel, depth=12, channels=128):
+        super().__init__()
+        self.numlayer = depth
+        self.conv_in = _conv1d_layer(in_channel, channels, False)
+        for i in range(depth):
+            setattr(self, "conv_%d" % i, ResBlock(channels))
+
+    def forward(self, x):                                   # (B, C_in, K) -> (B, 128, K)
+        x = self.conv_in(x)
+        for i in range(self.numlayer):
+            x = getattr(self, "conv_%d" % i)(x)
+        return x
+
+
+class GMW(nn.Module):
+    def __init__(self, num_kpts=73, sinkhorn_lambda=10.0, sinkhorn_tolerance=1e-9):
+        super().__init__()
+        self.FeatureExtractor4d = FeatureExtractor(4)
+        self.FeatureExtractor6d = FeatureExtractor(6)
+        self.sinkhorn = RegularisedTransport(sinkhorn_lambda, sinkhorn_tolerance)
+        self.num_kpts = num_kpts
+        iu = torch.triu_indices(num_kpts, num_kpts, offset=1)       # row-major upper triangle = masked_select order
+        self.register_buffer("pair_i", iu[0], persistent=False)
+        self.register_buffer("pair_j", iu[1], persistent=False)
+
+    def edge_expand(self, f):
+        """(B, n, c) -> (B, n(n-1)/2, 2c): [f_i, f_j] for every pair i < j  (model.py:139-152)."""
+        return torch.cat((f.index_select(1, self.pair_i), f.index_select(1, self.pair_j)), dim=-1)
+
+    def graph_matching(self, f4d, f6d):
+        f4d = self.FeatureExtractor4d(f4d.transpose(-2, -1)).transpose(-2, -1)         # B x m x 128
+        f6d = self.FeatureExtractor6d(f6d.transpose(-2, -1)).transpose(-2, -1)
+        f4d = F.normalize(f4d, p=2, dim=-1)
+        f6d = F.normalize(f6d, p=2, dim=-1)
+        M = pairwise_l2_dist(f4d, f6d)
+        diag_feat = 1.0 / M.diagonal(offset=0, dim1=-2, dim2=-1)                         # graph_extract, model.py:154-157
+        b, m, n = M.size()
+        r = M.new_ones((b, m)) / m
+        c = M.new_ones((b, n)) / n
+        return self.sinkhorn(M, r, c), diag_feat
+
+    def forward(self, kpts_2d, kpts_3d, pred_rot=None, args=None):
+        """(B,73,2) K-normalised keypoints, (B,73,3) object-frame keypoints -> (reg_weights (B,2628), edge_P (B,2628,2628))."""
+        edge_P, reg_weights = self.graph_matching(self.edge_expand(kpts_2d), self.edge_expand(kpts_3d))
+        return reg_weights, edge_P

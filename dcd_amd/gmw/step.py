@@ -1,0 +1,42 @@
+"""One GMW optimisation step (GMW/main.py:447-466): edge depth candidates from the solver kernel, GMW forward,
+correspondence loss on the transport plan, weighted-depth regression loss, backward, AdamW step."""
+import torch
+
+
+def correspondence_loss(P, C_gt=None):
+    """mean over the batch of sum((1 - 2 C) P)  (GMW/lib/losses.py:22-26,115-119).  C_gt = None means the identity the
+    train loop uses (main.py:456): sum(P) - 2 trace(P), without materialising a (B, 2628, 2628) identity."""
+    if C_gt is None:
+        return (P.sum(dim=(-2, -1)) - 2.0 * P.diagonal(dim1=-2, dim2=-1).sum(-1)).mean()
+    return ((1.0 - 2.0 * C_gt) * P).sum(dim=(-2, -1)).mean()
+
+
+def compute_reg_loss(pre_depths, edge_weight, gt_depth, good_idx):
+    """softmax of the matching weights over the 1500 best-conditioned edges, weighted mean of their depths, L1 to the
+    ground truth (main.py:364-371)."""
+    d = pre_depths.gather(-1, good_idx)
+    w = edge_weight.gather(-1, good_idx).softmax(dim=-1)
+    z = (d * w).sum(-1)
+    return (z - gt_depth).abs().mean(), z
+
+
+def gmw_losses(model, kpts_2d, kpts_3d, pred_rot, gt_location, cls_weight=1.0, reg_weight=0.0, compute_z=None):
+    """(loss, cls_loss, reg_loss, pred_depth).  `compute_z` defaults to the HIP solver kernel (dcd_amd.ops.compute_z)."""
+    if compute_z is None:
+        from dcd_amd import ops
+        compute_z = ops.compute_z
+    pre_depths, good_idx = compute_z(kpts_2d, kpts_3d, pred_rot)
+    reg_weights, edge_P = model(kpts_2d, kpts_3d, pred_rot)
+    cls_loss = correspondence_loss(edge_P)
+    reg_loss, pred_depth = compute_reg_loss(pre_depths, reg_weights, gt_location[:, -1], good_idx)
+    return cls_weight * cls_loss + reg_weight * reg_loss, cls_loss, reg_loss, pred_depth
+
+
+def gmw_train_step(model, optimizer, kpts_2d, kpts_3d, pred_rot, gt_location, cls_weight=1.0, reg_weight=0.0, compute_z=None):
+    loss, cls_loss, reg_loss, pred_depth = gmw_losses(model, kpts_2d, kpts_3d, pred_rot, gt_location, cls_weight, reg_weight,
+                                                      compute_z)
+    optimizer.zero_grad()
+    if not torch.isnan(loss).any():                 # main.py:464-465
+        loss.backward()
+    optimizer.step()
+    return loss.detach(), cls_loss.detach(), reg_loss.detach(), pred_depth.detach()
