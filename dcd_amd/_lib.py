@@ -37,6 +37,8 @@ SIGNATURES = {
     "dcd_conv_stem": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_size_t]),
     "dcd_conv_stem_wrw_workspace_bytes": (c_size_t, [c_int] * 3),
     "dcd_conv_stem_wrw": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t]),
+    "dcd_context_norm_forward": (c_int, [c_void_p] * 4 + [c_int, c_int, c_float]),
+    "dcd_context_norm_backward": (c_int, [c_void_p] * 5 + [c_int, c_int]),
     "dcd_sum_tensors": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64]),
     "dcd_conv3x3_wrw_workspace_bytes": (c_size_t, [c_int] * 5),
     "dcd_conv3x3_wrw": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t]),

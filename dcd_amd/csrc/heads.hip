@@ -561,6 +561,49 @@ __global__ void iou3d_kernel(const float *__restrict__ A, const float *__restric
 
 inline int grid_for(int64_t n, int block) { int64_t g = (n + block - 1) / block; return (int)(g < 1 ? 1 : (g > 4096 ? 4096 : g)); }
 
+// Context normalisation of GMW's point-feature extractor (GMW/model/yi2018cvpr/ops.py:5-17): every (sample, channel) row of K
+// points is shifted to zero mean and scaled by 1 / sqrt(unbiased variance + eps).  One wave per row; the row (2628 floats for 73
+// keypoints) is read from L1/L2 three times (mean, variance, write) -- the stock chain is 7 launches forward and ~15 backward,
+// 48 times per step.  backward: dx = inv (dy - mean(dy) - y sum(dy y) / (K - 1)).
+__device__ __forceinline__ float wave_sum64(float v)
+{
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+    return v;
+}
+
+__global__ __launch_bounds__(256) void context_norm_fwd(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ inv_out,
+                                                        int rows, int K, float eps)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *xr = x + (size_t)row * K;
+    float s = 0.f;
+    for (int i = lane; i < K; i += 64) s += xr[i];
+    const float m = wave_sum64(s) / (float)K;
+    float q = 0.f;
+    for (int i = lane; i < K; i += 64) { const float d = xr[i] - m; q += d * d; }
+    const float var = wave_sum64(q) / (float)(K - 1);
+    const float inv = 1.f / sqrtf(var + eps);
+    float *yr = y + (size_t)row * K;
+    for (int i = lane; i < K; i += 64) yr[i] = (xr[i] - m) * inv;
+    if (lane == 0) inv_out[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void context_norm_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+                                                        const float *__restrict__ inv_in, float *__restrict__ dx, int rows, int K)
+{
+    const int row = blockIdx.x * 4 + (threadIdx.x >> 6), lane = threadIdx.x & 63;
+    if (row >= rows) return;
+    const float *gr = dy + (size_t)row * K, *yr = y + (size_t)row * K;
+    float s0 = 0.f, s1 = 0.f;
+    for (int i = lane; i < K; i += 64) { const float g = gr[i]; s0 += g; s1 += g * yr[i]; }
+    const float mean_g = wave_sum64(s0) / (float)K, c = wave_sum64(s1) / (float)(K - 1);
+    const float inv = inv_in[row];
+    float *dr = dx + (size_t)row * K;
+    for (int i = lane; i < K; i += 64) dr[i] = inv * (gr[i] - mean_g - yr[i] * c);
+}
+
 // out = sum of n tensors (n <= 16) in one pass: the gradient of a feature map that fans out to the head trunks.
 struct SumSrcs {
     const float *p[16];
@@ -716,6 +759,26 @@ int dcd_iou3d(void *stream_, const float *pred_corners, const float *target_corn
     if (N == 0) return DCD_OK;
     if (!pred_corners || !target_corners || !iou || N < 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(iou3d_kernel, dim3((N + 63) / 64), dim3(64), 0, stream, pred_corners, target_corners, N, iou);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_context_norm_forward(void *stream_, const float *x, float *y, float *inv, int rows, int K, float eps)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (rows == 0) return DCD_OK;
+    if (!x || !y || !inv || rows < 0 || K < 2) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(context_norm_fwd, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, inv, rows, K, eps);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_context_norm_backward(void *stream_, const float *grad_y, const float *y, const float *inv, float *grad_x, int rows, int K)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (rows == 0) return DCD_OK;
+    if (!grad_y || !y || !inv || !grad_x || rows < 0 || K < 2) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(context_norm_bwd, dim3((rows + 3) / 4), dim3(256), 0, stream, grad_y, y, inv, grad_x, rows, K);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -511,6 +511,38 @@ def conv_stem(x, weight):
     return _ConvStem.apply(x, weight)
 
 
+class _ContextNorm(torch.autograd.Function):
+    """GMW's `gcn` (per-row zero mean, unit unbiased variance + 1e-3) as one launch forward and one backward."""
+
+    @staticmethod
+    def forward(ctx, x, eps):
+        _lib.require_cuda(x)
+        x = _f32c(x)
+        K = x.shape[-1]
+        rows = x.numel() // K
+        y = torch.empty_like(x)
+        inv = torch.empty(rows, dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dcd_context_norm_forward(_lib.stream_of(x), x.data_ptr(), y.data_ptr(), inv.data_ptr(), rows, K, float(eps)),
+                   "dcd_context_norm_forward")
+        ctx.save_for_backward(y, inv)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        y, inv = ctx.saved_tensors
+        gy = _f32c(gy)
+        K = y.shape[-1]
+        gx = torch.empty_like(y)
+        _lib.check(_lib.lib().dcd_context_norm_backward(_lib.stream_of(y), gy.data_ptr(), y.data_ptr(), inv.data_ptr(), gx.data_ptr(),
+                                                        y.numel() // K, K), "dcd_context_norm_backward")
+        return gx, None
+
+
+def context_norm(x, eps=1e-3):
+    return _ContextNorm.apply(x, eps)
+
+
 class _FanOut(torch.autograd.Function):
     """n aliases of one tensor whose gradients are summed by ONE kernel (autograd would run n-1 pairwise additions, each
     a read-read-write pass over the map)."""

@@ -155,6 +155,11 @@ int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corne
  * head trunks (DGDE/model/head/detector_predictor.py:149-160 call every trunk on the same `features`). */
 int dcd_sum_tensors(void *stream, const float *const *srcs, int n, float *out, int64_t numel);
 
+/* Context normalisation of GMW's feature extractor (`gcn`, GMW/model/yi2018cvpr/ops.py:5-17): x (rows, K) -> y = (x - mean) /
+ * sqrt(var_unbiased + eps) per row, inv (rows) = the scale; backward from (grad_y, y, inv).  rows = batch * channels. */
+int dcd_context_norm_forward(void *stream, const float *x, float *y, float *inv, int rows, int K, float eps);
+int dcd_context_norm_backward(void *stream, const float *grad_y, const float *y, const float *inv, float *grad_x, int rows, int K);
+
 /* ------------------------------------------------------------------------------------------------
  * Batch normalisation fused with the residual add and ReLU that follow it.  Replaces the stock-op chains
  *   bn -> relu            DGDE/model/backbone/dla_dcn.py:91-93 (BasicBlock), :272-283 (conv levels), :403-410

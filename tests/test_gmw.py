@@ -99,3 +99,23 @@ def test_transport_backward_one_solve_equals_explicit_inverse():
         v = torch.randn(2, 1600, dtype=dtype)
         g0, g1 = T.gradient(P, 10.0, v, explicit_inverse=True), T.gradient(P, 10.0, v)
         assert (g0 - g1).abs().max().item() <= tol * g0.abs().max().item()
+
+
+@pytest.mark.gpu
+def test_context_norm_kernel_against_stock_formula(cuda):
+    """csrc/heads.hip context normalisation (forward + backward) against the reference's formula in fp64."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    for B, C, K in ((2, 128, 2628), (3, 5, 37)):
+        x = torch.randn(B, C, K, generator=g) * 2 + 0.5
+        gy = torch.randn(B, C, K, generator=g)
+        xd = x.double().requires_grad_()
+        m = torch.mean(xd, 2, keepdim=True)
+        v = torch.var(xd, 2, keepdim=True)
+        ref = (xd - m) * (1.0 / torch.sqrt(v + 1e-3))
+        ref.backward(gy.double())
+        xg = x.to(cuda).requires_grad_()
+        y = ops.context_norm(xg, 1e-3)
+        y.backward(gy.to(cuda))
+        assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-6 * ref.abs().max().item()
+        assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= 1e-5 * xd.grad.abs().max().item()
