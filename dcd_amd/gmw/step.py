@@ -40,3 +40,20 @@ def gmw_train_step(model, optimizer, kpts_2d, kpts_3d, pred_rot, gt_location, cl
         loss.backward()
     optimizer.step()
     return loss.detach(), cls_loss.detach(), reg_loss.detach(), pred_depth.detach()
+
+
+def gmw_val_step(model, kpts_2d, kpts_3d, pred_rot, raw_location, dim, cls_weight=1.0, reg_weight=0.0, compute_z=None):
+    """Validation step (GMW/main.py:524-548): the losses of the train step without gradients, and the detector's location
+    rescaled along its viewing ray to the weighted edge depth -- about the object CENTRE: y is moved up by h/2 (KITTI
+    locations are the bottom-face centre), scaled by pred_depth / raw_depth, and moved back.
+    Returns (loss, cls_loss, reg_loss, pred_depth, pred_location)."""
+    with torch.no_grad():
+        loss, cls_loss, reg_loss, pred_depth = gmw_losses(model, kpts_2d, kpts_3d, pred_rot, raw_location, cls_weight, reg_weight,
+                                                          compute_z)
+        loc = raw_location.clone()
+        scale = pred_depth / loc[:, 2]
+        h = dim[:, 0]
+        loc[:, 1] -= h / 2
+        pred_location = scale.unsqueeze(-1) * loc
+        pred_location[:, 1] += h / 2
+    return loss, cls_loss, reg_loss, pred_depth, pred_location

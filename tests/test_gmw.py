@@ -119,3 +119,19 @@ def test_context_norm_kernel_against_stock_formula(cuda):
         y.backward(gy.to(cuda))
         assert (y.detach().cpu().double() - ref.detach()).abs().max().item() <= 2e-6 * ref.abs().max().item()
         assert (xg.grad.cpu().double() - xd.grad).abs().max().item() <= 1e-5 * xd.grad.abs().max().item()
+
+
+def test_gmw_val_step_rescales_the_location_along_its_ray():
+    from oracle import torch_ops
+    from dcd_amd.gmw import GMW, gmw_val_step
+    torch.manual_seed(0)
+    model = GMW().eval()
+    k2, k3, rot, loc = (torch.from_numpy(a) for a in inputs())
+    dim = torch.tensor([[1.5, 1.6, 3.9], [1.4, 1.7, 4.1]])
+    fx = np.load(os.path.join(HERE, "golden", "gmw.npz"))
+    loss, cls, reg, z, ploc = gmw_val_step(model, k2, k3, rot, loc, dim, 0.1, 1.0, compute_z=torch_ops.compute_z)
+    assert abs(float(loss) - float(fx["loss"])) <= 2e-5 * abs(float(fx["loss"]))       # no train/eval difference: no BN, no dropout
+    assert torch.allclose(ploc[:, 2], z, rtol=1e-6)                                       # the new depth is the predicted one
+    centre_raw = loc.clone(); centre_raw[:, 1] -= dim[:, 0] / 2
+    centre_new = ploc.clone(); centre_new[:, 1] -= dim[:, 0] / 2
+    assert torch.allclose(centre_new / centre_new[:, 2:3], centre_raw / centre_raw[:, 2:3], rtol=1e-5, atol=1e-6)   # same ray
