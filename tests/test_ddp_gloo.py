@@ -127,3 +127,37 @@ def test_sync_bn_two_ranks_equal_full_batch(tmp_path):
     mp.spawn(_syncbn_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(os.path.join(str(tmp_path), "s%d.pt" % r))["ok"]
+
+
+def _gmw_worker(rank, world, port, out_dir):
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(3)
+    from make_golden_gmw import inputs
+    from oracle import torch_ops
+    from dcd_amd.gmw import GMW, gmw_losses
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    torch.manual_seed(0)
+    model = torch.nn.parallel.DistributedDataParallel(GMW().train())
+    k2, k3, rot, loc = (torch.from_numpy(a)[rank:rank + 1] for a in inputs())       # one of the fixture's two objects per rank
+    loss = gmw_losses(model, k2, k3, rot, loc, 0.1, 1.0, compute_z=torch_ops.compute_z)[0]
+    loss.backward()
+    torch.save({"loss": float(loss), "grads": [p.grad.clone() for p in model.parameters()]}, os.path.join(out_dir, "gmw_r%d.pt" % rank))
+    dist.destroy_process_group()
+
+
+def test_gmw_ddp_two_ranks_equal_the_reference_batch(tmp_path):
+    """GMW under DDP (GMW/main.py:250-253; BASELINE config 5 splits 64 objects over 8 ranks): with one of the fixture's two
+    objects per rank, the all-reduced gradient is the reference's two-object gradient (both losses are batch means)."""
+    import numpy as np
+    port = _free_port()
+    mp.spawn(_gmw_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    r0, r1 = (torch.load(os.path.join(str(tmp_path), "gmw_r%d.pt" % r)) for r in (0, 1))
+    for a, b in zip(r0["grads"], r1["grads"]):
+        assert torch.equal(a, b)                                             # every rank steps with the same gradient
+    fx = np.load(os.path.join(ROOT, "tests", "golden", "gmw.npz"))
+    assert abs(0.5 * (r0["loss"] + r1["loss"]) - float(fx["loss"])) <= 2e-5 * abs(float(fx["loss"]))
+    gn = np.array([float(g.double().norm()) for g in r0["grads"]])
+    scale = fx["grad_norms"].max()
+    assert np.all(np.abs(gn - fx["grad_norms"]) <= 1e-3 * fx["grad_norms"] + 1e-4 * scale)
