@@ -218,18 +218,136 @@ def cpu_baseline_child(args):
 
 def cpu_baseline(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-batch", str(args.cpu_batch),
-           "--objects", str(args.objects)]
+           "--objects", str(args.objects), "--workload", args.workload]
     env = dict(os.environ, CUDA_VISIBLE_DEVICES="", HIP_VISIBLE_DEVICES="")
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
         line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
         return json.loads(line)
     except Exception as e:  # a missing baseline must not kill the GPU number
-        return {"value": None, "unit": "images/s", "cores": None, "kind": "port", "sample": "failed: %r" % (e,)}
+        return {"value": None, "unit": "objects/s" if args.workload == "gmw" else "images/s", "cores": None, "kind": "port",
+                "sample": "failed: %r" % (e,)}
+
+
+# ------------------------------------------------------------------------------------------------
+# Secondary workload (BASELINE config 5): the GMW train step.  `--workload gmw`; never the default.
+# ------------------------------------------------------------------------------------------------
+GMW_EDGES = 2628
+
+
+def _gmw_inputs(B, seed, device=None):
+    """Seeded GMW batch (K-normalised 2-D keypoints of projected object-frame 3-D keypoints + 2e-3 noise, yaw, location)."""
+    import numpy as np
+    import torch
+    rng = np.random.default_rng(seed)
+    dims = np.array([3.9, 1.5, 1.6], dtype=np.float32)
+    k3 = ((rng.random((B, 73, 3)) - 0.5) * dims).astype(np.float32)
+    rot = (rng.random((B, 1)) * 2 * np.pi - np.pi).astype(np.float32)
+    loc = np.stack([(rng.random(B) - 0.5) * 10, np.full(B, 1.65), 8 + rng.random(B) * 40], 1).astype(np.float32)
+    c, s = np.cos(rot[:, 0]), np.sin(rot[:, 0])
+    zc = -k3[:, :, 0] * s[:, None] + k3[:, :, 2] * c[:, None] + loc[:, None, 2]
+    k2 = np.stack([(k3[:, :, 0] * c[:, None] + k3[:, :, 2] * s[:, None] + loc[:, None, 0]) / zc, (k3[:, :, 1] + loc[:, None, 1]) / zc], -1)
+    k2 = (k2 + rng.standard_normal(k2.shape) * 2e-3).astype(np.float32)
+    out = tuple(torch.from_numpy(a) for a in (k2, k3, rot, loc))
+    return tuple(t.to(device) for t in out) if device is not None else out
+
+
+def run_gmw(args):
+    import torch
+    import torch.distributed as dist
+    from dcd_amd.gmw import GMW, gmw_train_step
+    from dcd_amd.gmw.optimal_transport import RegularisedTransportFn
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1 or "RANK" in os.environ:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="nccl", device_id=device)
+    per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
+    torch.manual_seed(0)
+    model = GMW().to(device).train()
+    if world > 1:
+        model = torch.nn.parallel.DistributedDataParallel(model, device_ids=[local_rank])
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999))           # GMW/main.py:255-259
+    batch = _gmw_inputs(per_rank, 100 + rank, device)
+    # the transport layer's backward, timed with events around its own entry point (the step's dominant piece)
+    pairs, orig = [], RegularisedTransportFn.gradient
+    timing = {"on": False}
+
+    def timed_gradient(*a, **k):
+        if not timing["on"]:
+            return orig(*a, **k)
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        out = orig(*a, **k)
+        e1.record()
+        pairs.append((e0, e1))
+        return out
+    RegularisedTransportFn.gradient = staticmethod(timed_gradient)
+    for _ in range(args.warmup):
+        gmw_train_step(model, opt, *batch, 0.1, 1.0)
+
+    def fence():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize()
+    fence()
+    timing["on"] = True
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        gmw_train_step(model, opt, *batch, 0.1, 1.0)
+    fence()
+    elapsed = time.perf_counter() - t0
+    timing["on"] = False
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    tb_ms = sum(a.elapsed_time(b) for a, b in pairs) / max(args.steps, 1)
+    n = GMW_EDGES
+    flops = per_rank * (2.0 * n * (n - 1) * n + n ** 3 / 3.0 + n ** 3 / 3.0)       # S = D2 - B^T D1 B, potrf, inverse of the factor
+    out = None
+    if rank == 0:
+        out = {"metric": "objects/sec GMW train step (73 keypoints, 2628 edges)", "value": per_rank * world * args.steps / elapsed,
+               "unit": "objects/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": 1e3 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None,
+               "dtype": "f32", "data": "synthetic",
+               "config": {"workload": "GMW train step, %d objects (%d per GPU) x 2628 edges, cls 0.1 + reg 1.0 (GMW/main.py:313-315)" % (
+                   per_rank * world, per_rank), "global_batch": per_rank * world, "per_gpu_batch": per_rank, "parallelism": "dp%d" % world},
+               "roofline": {"bound": "mfma", "kernel": "transport-layer backward (S formation, Cholesky, inverse of the factor; library kernels)",
+                            "achieved": flops / 1e12 / (tb_ms / 1e3) if tb_ms > 0 else None, "peak": MFMA_PEAK_TFLOPS["f32"],
+                            "unit": "TFLOP/s", "frac": (flops / 1e12 / (tb_ms / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if tb_ms > 0 else None,
+                            "traffic": None, "flops": flops, "ms_per_step": tb_ms}}
+    if dist.is_initialized():
+        dist.barrier()
+        dist.destroy_process_group()
+    return out
+
+
+def gmw_cpu_baseline_child(args):
+    """The same GMW step on the host cores (our mirror with the oracle's compute_z; kind "port"), 2 objects."""
+    import torch
+    from dcd_amd.gmw import GMW, gmw_train_step
+    from oracle import torch_ops
+    torch.manual_seed(0)
+    model = GMW().train()
+    opt = torch.optim.AdamW(model.parameters(), lr=1e-4, betas=(0.9, 0.999))
+    batch = _gmw_inputs(2, 100)
+    gmw_train_step(model, opt, *batch, 0.1, 1.0, compute_z=torch_ops.compute_z)
+    t0 = time.perf_counter()
+    n = 3
+    for _ in range(n):
+        gmw_train_step(model, opt, *batch, 0.1, 1.0, compute_z=torch_ops.compute_z)
+    dt = (time.perf_counter() - t0) / n
+    print(json.dumps({"value": 2 / dt, "unit": "objects/s", "cores": torch.get_num_threads(), "kind": "port", "host_cpus": os.cpu_count(),
+                      "sample": "%d GMW train steps of 2 objects x 2628 edges on the host (PyTorch CPU ops, LAPACK Cholesky); %.1f s each" % (n, dt)}))
 
 
 def main():
     ap = argparse.ArgumentParser()
+    ap.add_argument("--workload", choices=("dgde", "gmw"), default="dgde", help="dgde: the headline metric (default); gmw: SURVEY 8(f) rank 1")
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
@@ -243,14 +361,14 @@ def main():
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
     args = ap.parse_args()
     if args.cpu_baseline_child:
-        cpu_baseline_child(args)
+        (gmw_cpu_baseline_child if args.workload == "gmw" else cpu_baseline_child)(args)
         return
     # RCCL prints its version banner on stdout when the first communicator is created; the contract is ONE JSON line on
     # stdout, so everything else written to fd 1 during the run goes to stderr.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    out = run_gpu(args)
+    out = run_gmw(args) if args.workload == "gmw" else run_gpu(args)
     sys.stdout.flush()
     if out is not None:
         if args.gpus == 1 and not args.no_cpu_baseline:
