@@ -508,7 +508,7 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
                                                         const float *__restrict__ msk, const float *__restrict__ wl,
                                                         const float *__restrict__ bias, float *__restrict__ out, Geom g,
                                                         int tiles_x, int nchunk, unsigned char *__restrict__ rescue_flags,
-                                                        const float *__restrict__ wf9)
+                                                        const float *__restrict__ wf9, int rescue_taps)
 {
     typedef TileCfg<TR> T;
     constexpr int TL_ROWS = TR, TL_WH = T::WH, TL_PLANE = T::PLANE, TL_IN_FLOATS = T::IN_FLOATS, TL_BUF = T::BUF,
@@ -611,7 +611,7 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
     __syncthreads();
     if (lane == 0) atomicMax(&far_worst, wave_far_taps);
     __syncthreads();
-    if (far_worst >= 5) {
+    if (far_worst >= rescue_taps) {
         if (tid == 0) rescue_flags[(size_t)b * gridDim.x + bx] = 1;      // dcn_fwd9_f32<2, true> computes this region
         return;
     }
@@ -1982,6 +1982,11 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                     return DCD_ERR_LAUNCH;
                 attr_set = true;
             }
+            static int rescue_taps = 0;
+            if (rescue_taps == 0) {
+                const char *e = getenv("DCD_FWD_RESCUE_TAPS");       // A/B: far taps in the worst wave that hand a region to the rescue kernel
+                rescue_taps = (e && atoi(e) >= 1 && atoi(e) <= 10) ? atoi(e) : 5;
+            }
             const int tiles_x = (g.Wo + 31) / 32;
             const bool rows8 = tile_rows == 8 && (int64_t)tiles_x * ((g.Ho + 7) / 8) * B * nz >= 512;
             const int TRr = rows8 ? 8 : 4;
@@ -1996,10 +2001,10 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                                    dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
                 if (rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9);
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps);
                 else
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(regions, B, nz), dim3(256), 2 * TileCfg<4>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9);
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps);
                 // rescue pass: register-gather kernel over the flagged regions only (usually none: its waves exit at once)
                 const int nb9 = g.Cop / 32, mb9 = nb9 >= 4 ? 4 : nb9 >= 2 ? 2 : 1;
                 dim3 gridr((tiles_x * g.Ho + 3) / 4, B, (nb9 + mb9 - 1) / mb9);
