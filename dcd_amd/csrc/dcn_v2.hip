@@ -503,12 +503,35 @@ __global__ void dcn_prep_weights_tile(const float *__restrict__ w, float *__rest
     }
 }
 
+// Per-call decision for large learned offsets (forward): counts the offset coordinates displaced by TL_NEAR_F px or more.
+// When they exceed 1/32 of all coordinates every workgroup of the tiled kernel hands its region to the rescue kernel at once
+// (no per-region mix of per-lane fallbacks and rescues, which is the slow regime: DESIGN.md section 4).
+constexpr float TL_NEAR_F = 3.f;
+__global__ __launch_bounds__(256) void dcn_fwd_far_count(const float *__restrict__ off, int64_t n, unsigned *__restrict__ counter)
+{
+    unsigned c = 0;
+    const int64_t n4 = ((uintptr_t)off & 15) == 0 ? n >> 2 : 0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+        const f32x4 v = *reinterpret_cast<const f32x4 *>(off + 4 * i);
+        c += (!(fabsf(v.x) < TL_NEAR_F)) + (!(fabsf(v.y) < TL_NEAR_F)) + (!(fabsf(v.z) < TL_NEAR_F)) + (!(fabsf(v.w) < TL_NEAR_F));
+    }
+    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+        c += !(fabsf(off[i]) < TL_NEAR_F);
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) c += __shfl_xor(c, o);
+    __shared__ unsigned part[4];
+    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = c;
+    __syncthreads();
+    if (threadIdx.x == 0 && part[0] + part[1] + part[2] + part[3]) atomicAdd(counter, part[0] + part[1] + part[2] + part[3]);
+}
+
 template <int TR>
 __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restrict__ in, const float *__restrict__ off,
                                                         const float *__restrict__ msk, const float *__restrict__ wl,
                                                         const float *__restrict__ bias, float *__restrict__ out, Geom g,
                                                         int tiles_x, int nchunk, unsigned char *__restrict__ rescue_flags,
-                                                        const float *__restrict__ wf9, int rescue_taps)
+                                                        const float *__restrict__ wf9, int rescue_taps,
+                                                        const unsigned *__restrict__ far_count, unsigned far_limit)
 {
     typedef TileCfg<TR> T;
     constexpr int TL_ROWS = TR, TL_WH = T::WH, TL_PLANE = T::PLANE, TL_IN_FLOATS = T::IN_FLOATS, TL_BUF = T::BUF,
@@ -519,6 +542,10 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
     const int p = lane & 31, h = lane >> 5;
     int bx = blockIdx.x, b = blockIdx.y;
     xcd_remap(bx, b);
+    if (*far_count > far_limit) {                              // far samples dominate this call: every region goes to the rescue kernel
+        if (tid == 0) rescue_flags[(size_t)b * gridDim.x + bx] = 1;
+        return;
+    }
     const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
     const int r0 = ty * TL_ROWS, c0 = tx * 32;
     const int ho = r0 + wave, wo = c0 + p;
@@ -1992,19 +2019,29 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             const int TRr = rows8 ? 8 : 4;
             const int regions = tiles_x * ((g.Ho + TRr - 1) / TRr);
             // region flags ("far samples dominate here: left to the rescue pass") live behind the weight area
-            const int nflag_words = (B * regions + 3) / 4;
+            const int nflag_words = (B * regions + 3) / 4 + 1;        // + the far-coordinate counter, zeroed with the flags
             unsigned char *flags = (unsigned char *)(wf + 2 * nw);
+            unsigned *far_count = (unsigned *)flags + (nflag_words - 1);
+            const int64_t ncoord = (int64_t)B * 18 * g.HoWo;
+            const unsigned far_limit = (unsigned)(ncoord / 32 < 0xffffffffll ? ncoord / 32 : 0xffffffffll);
             const size_t n9 = (size_t)Cin * 9 * g.Cop;
             if (nwl <= nw && n9 <= nw && workspace_bytes >= 2 * nw * sizeof(float) + (size_t)nflag_words * 4) {
                 float *wf9 = wf + nw;                         // [Wl | Wf9 | flags]
                 hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
                                    dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
+                {
+                    int gsz = (int)((ncoord + 4095) / 4096);
+                    if (gsz > 512) gsz = 512;
+                    hipLaunchKernelGGL(dcn_fwd_far_count, dim3(gsz), dim3(256), 0, stream, offset, ncoord, far_count);
+                }
                 if (rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps);
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps,
+                                       (const unsigned *)far_count, far_limit);
                 else
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(regions, B, nz), dim3(256), 2 * TileCfg<4>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps);
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps,
+                                       (const unsigned *)far_count, far_limit);
                 // rescue pass: register-gather kernel over the flagged regions only (usually none: its waves exit at once)
                 const int nb9 = g.Cop / 32, mb9 = nb9 >= 4 ? 4 : nb9 >= 2 ? 2 : 1;
                 dim3 gridr((tiles_x * g.Ho + 3) / 4, B, (nb9 + mb9 - 1) / mb9);
