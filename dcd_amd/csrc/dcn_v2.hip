@@ -791,9 +791,13 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
             const int64_t plane = i / HoWo;
             const int P = (int)(i - plane * HoWo), b = (int)(plane / ch_per_img);
             const int tid_ = b * tiles_per_img + (P >> 5);
-            unsigned *word = (unsigned *)(far_flag + (tid_ & ~3));
-            const unsigned bit = 1u << (8 * (tid_ & 3));
-            if ((atomicOr(word, bit) & bit) == 0u) far_list[atomicAdd(scal + 1, 1u)] = tid_;
+            // plain read first: with large learned offsets 10-25 % of all coordinates land here and nearly all of them find
+            // their tile already listed -- the atomics alone made this scan 0.2 ms (2 px) to 0.74 ms (4 px) on a 64-channel layer
+            if (__builtin_nontemporal_load(far_flag + tid_) == 0) {
+                unsigned *word = (unsigned *)(far_flag + (tid_ & ~3));
+                const unsigned bit = 1u << (8 * (tid_ & 3));
+                if ((atomicOr(word, bit) & bit) == 0u) far_list[atomicAdd(scal + 1, 1u)] = tid_;
+            }
         }
     };
     const int64_t n4 = ((uintptr_t)off & 15) == 0 ? n >> 2 : 0;     // 16-byte loads when the tensor allows it
