@@ -620,9 +620,8 @@ __global__ __launch_bounds__(256) void sum_tensors_kernel(SumSrcs srcs, int n, f
         }
         reinterpret_cast<float4 *>(out)[i] = a;
     }
-    // tail (numel % 4 elements)
-    const int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t < numel) {
+    // tail: numel % 4 elements -- or everything, when a pointer is not 16-byte aligned (n4 = 0)
+    for (int64_t t = n4 * 4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < numel; t += stride) {
         float a = srcs.p[0][t];
         for (int k = 1; k < n; ++k) a += srcs.p[k][t];
         out[t] = a;
@@ -789,13 +788,14 @@ int dcd_sum_tensors(void *stream_, const float *const *srcs, int n, float *out, 
     if (numel == 0) return DCD_OK;
     if (!srcs || !out || n < 1 || n > 16 || numel < 0) return DCD_ERR_BAD_ARG;
     SumSrcs a;
+    bool aligned = ((uintptr_t)out & 15) == 0;
     for (int k = 0; k < 16; ++k) {
         a.p[k] = srcs[k < n ? k : 0];
-        if (!a.p[k] || ((uintptr_t)a.p[k] & 15)) return DCD_ERR_BAD_ARG;
+        if (!a.p[k]) return DCD_ERR_BAD_ARG;
+        aligned = aligned && ((uintptr_t)a.p[k] & 15) == 0;
     }
-    if ((uintptr_t)out & 15) return DCD_ERR_BAD_ARG;
-    const int64_t n4 = numel / 4;
-    int64_t blocks = (n4 + 255) / 256;
+    const int64_t n4 = aligned ? numel / 4 : 0;           // views at odd offsets take the scalar loop
+    int64_t blocks = ((aligned ? n4 : numel) + 255) / 256;
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, n4, numel);

@@ -150,7 +150,7 @@ int dcd_poi_scatter_add(void *stream, const float *grad_out, const int64_t *inde
  * ---------------------------------------------------------------------------------------------- */
 int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corners, int N, float *iou);
 
-/* out = srcs[0] + ... + srcs[n-1] (n <= 16 device tensors of `numel` floats, 16-byte aligned; `srcs` is a HOST array of
+/* out = srcs[0] + ... + srcs[n-1] (n <= 16 device tensors of `numel` floats; `srcs` is a HOST array of
  * device pointers).  Replaces autograd's chain of n-1 pairwise gradient additions where one feature map feeds the twelve
  * head trunks (DGDE/model/head/detector_predictor.py:149-160 call every trunk on the same `features`). */
 int dcd_sum_tensors(void *stream, const float *const *srcs, int n, float *out, int64_t numel);

@@ -97,6 +97,14 @@ def test_fan_out_sums_gradients_in_one_pass(cuda):
     sum((o * w).sum() for o, w in zip(outs, ws)).backward()
     ref = torch.stack(ws).double().sum(0)
     assert (x.grad.double() - ref).abs().max().item() < 1e-5
+    from dcd_amd import _lib
+    import ctypes
+    base = torch.randn(3, 1003, device=cuda)
+    srcs = [base[i, 1:1001] for i in range(3)]              # contiguous rows starting 4 bytes past a 16-byte boundary
+    outp = torch.empty(1000, device=cuda)
+    arr = (ctypes.c_void_p * 3)(*[t.data_ptr() for t in srcs])
+    assert _lib.lib().dcd_sum_tensors(_lib.stream_of(outp), arr, 3, outp.data_ptr(), 1000) == 0
+    assert torch.allclose(outp, srcs[0] + srcs[1] + srcs[2], atol=1e-6)
     y = torch.randn(3, 4, device=cuda, requires_grad=True)
     a, b_, c = ops.fan_out(y, 3)
     (a.sum() * 2 + c.sum()).backward()                                    # one consumer unused
