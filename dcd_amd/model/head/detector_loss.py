@@ -346,7 +346,10 @@ class Loss_Computation():
             def core_flat(cls, pois, hm, *fl):
                 loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, dict(zip(names, fl)))
                 meta['loss_keys'], meta['log_names'] = list(loss_dict), log_names
-                return tuple(loss_dict.values()) + (sum(loss_dict.values()), packed)
+                stacked = torch.stack([v.reshape(()) for v in loss_dict.values()])
+                # three outputs instead of fifteen: the graphed backward copies one gradient per output into its static
+                # buffers before it replays, and those launches sit in the one gap where the GPU waits for the host
+                return stacked, stacked.sum(), packed
             sample = (pred_heatmap.detach().clone().requires_grad_(True), reg_pois.detach().clone().requires_grad_(True),
                       targets_heatmap.detach().clone()) + tuple(t.detach().clone() for t in flat)
             if len(self._graphs) >= 4:                       # a few input shapes at most (e.g. the last, smaller batch)
@@ -354,10 +357,10 @@ class Loss_Computation():
             entry = (torch.cuda.make_graphed_callables(core_flat, sample), meta)
             self._graphs[key] = entry
         graphed, meta = entry
-        outs = graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
-        loss_dict = LossDict(zip(meta['loss_keys'], outs[:-2]))
-        loss_dict.total = outs[-2]               # the sum, formed inside the graph: `total.backward()` needs no eager adds
-        return loss_dict, LazyLogDict(meta['log_names'], outs[-1].clone(), list(loss_dict))
+        stacked, total, packed = graphed(pred_heatmap, reg_pois, targets_heatmap, *flat)
+        loss_dict = LossDict(zip(meta['loss_keys'], stacked.unbind(0)))      # views: summing them back-propagates as well
+        loss_dict.total = total                  # the sum, formed inside the graph: `total.backward()` needs no eager adds
+        return loss_dict, LazyLogDict(meta['log_names'], packed.clone(), list(loss_dict))
 
     def _core(self, predictions, targets_heatmap, targets_variables):
         pred_heatmap = predictions['cls']
