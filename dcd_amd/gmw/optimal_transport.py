@@ -3,8 +3,8 @@
 forward: Sinkhorn iterations on K = exp(-lambda min(M, 5)) until every u of the batch moved < tolerance (max 100);
 backward: the declarative-node vector-Jacobian product of optimal_transport.py:77-128 (Gould et al. 2019, Lemma 4.4):
 one n x n Cholesky factorisation per object; the products are associated so that a single back-substitution replaces the
-explicit inverse and the two (m-1) x n x n products of the reference (see `gradient`), and `torch.cholesky` is spelled
-`torch.linalg.cholesky`.  Only the uniform-marginal case the GMW model uses (r, c > 0) is implemented.
+explicit inverse and the two dense blocks the reference builds (see `gradient`).  Only the uniform-marginal case the GMW model
+uses (r, c > 0) is implemented.
 """
 import torch
 
@@ -12,70 +12,62 @@ import torch
 class RegularisedTransportFn(torch.autograd.Function):
     @staticmethod
     def sinkhorn(M, r, c, lmbda=10.0, tolerance=1e-9, max_iterations=100, max_distance=5.0):
-        K = (-lmbda * M.clamp_max(max_distance)).exp()
-        Kt = K.transpose(-2, -1)
-        r = r.unsqueeze(-1)
-        c = c.unsqueeze(-1)
-        u = r.clone()
-        u_prev = torch.ones_like(u)
+        """Cuturi (2013) Algorithm 1 on the Gibbs kernel exp(-lmbda min(M, max_distance)): alternate scalings until no entry of
+        the row scaling of ANY object in the batch moved by more than `tolerance` (optimal_transport.py:52-75)."""
+        gibbs = torch.exp(-lmbda * M.clamp_max(max_distance))
+        gibbs_t = gibbs.transpose(-2, -1)
+        row_marg, col_marg = r.unsqueeze(-1), c.unsqueeze(-1)
+        scale_r, previous = row_marg.clone(), torch.ones_like(row_marg)
         for _ in range(max_iterations):
-            if torch.all(torch.isclose(u, u_prev, atol=tolerance, rtol=0.0)):
+            if torch.all(torch.isclose(scale_r, previous, atol=tolerance, rtol=0.0)):
                 break
-            u_prev = u
-            u = r / K.matmul(c / Kt.matmul(u))
-        v = c / Kt.matmul(u)
-        return (u * K) * v.transpose(-2, -1)
+            previous = scale_r
+            scale_r = row_marg / gibbs.matmul(col_marg / gibbs_t.matmul(scale_r))
+        scale_c = col_marg / gibbs_t.matmul(scale_r)
+        return (scale_r * gibbs) * scale_c.transpose(-2, -1)
 
     @staticmethod
-    def gradient(P, lmbda, v, explicit_inverse=False):
-        """DJ(M) = DJ(P) DP(M), v = DJ(P) flattened to (b, m n).
+    def gradient(P, lmbda, v):
+        """Vector-Jacobian product DJ(M) = DJ(P) DP(M) for v = DJ(P) flattened to (b, m n)  (optimal_transport.py:77-128).
 
-        With H^-1 = diag(lmbda vec(P)), B = lmbda P[1:], D1 = diag(1 / rowsum(lmbda P)[1:]), D2 = diag(colsum(lmbda P)) and
-        S = D2 - B^T D1 B, the reference builds S^-1, R = -D1 B S^-1 and Q = D1 - R B^T D1 explicitly (two more
-        (m-1) x n x n products and a triangular inverse per object: 126 GFLOP for 2628 edges) and then multiplies the row
-        vectors u1, u2 through them.  The same products associate the other way round into ONE solve:
-            y = (u2 - (u1 D1) B) S^-1,      u4 = u1 R + u2 S^-1 = y,      u3 = u1 Q + u2 R^T = u1 D1 - (y B^T) D1,
-        i.e. form S (36 GFLOP), factor it (6 GFLOP) and back-substitute one right-hand side (on the GPU: inverse of the
-        triangular factor + two mat-vecs, see below).  `explicit_inverse=True` keeps the reference's order of operations (the CPU
-        test compares the two)."""
+        The transport plan minimises f(M, P) = <M, P> + <P, log P - 1> / lmbda subject to the m + n - 1 independent marginal
+        constraints A vec(P) = const (first row constraint dropped).  With H^-1 = diag(lmbda vec(P)) the declarative-node
+        result is DP(M) = H^-1 A^T (A H^-1 A^T)^-1 A H^-1 - H^-1.  A H^-1 A^T = [[diag(rows), G], [G^T, diag(cols)]] with
+        G = lmbda P without its first row, rows = rowsum(G) (m-1), cols = colsum(lmbda P) (n); its Schur complement is
+            S = diag(cols) - G^T diag(1/rows) G                                   (n x n, symmetric positive definite).
+        The reference forms S^-1 and two dense (m-1) x n / (m-1) x (m-1) blocks of (A H^-1 A^T)^-1 (126 GFLOP per object
+        at 2628 edges) before multiplying the row vector through; everything the product needs is
+            w = v H^-1 (as an m x n field),  a = rowsum(w)[1:] / rows,  y = (colsum(w) - a G) S^-1,
+            multipliers: columns -> y,  rows -> a - (y G^T) / rows,
+        i.e. S (36 GFLOP), one factorisation and one right-hand side.  tests/test_gmw.py checks this against the generic
+        formula with an explicit A on small problems, and against finite differences of the fixed point."""
         with torch.no_grad():
             b, m, n = P.size()
-            B = lmbda * P
-            hinv = B.flatten(start_dim=-2)
-            d1inv = B.sum(-1)[:, 1:].reciprocal()
-            d2 = B.sum(-2)
-            B = B[:, 1:, :]
-            S = -B.transpose(-2, -1).matmul(d1inv.unsqueeze(-1) * B)
-            S.diagonal(dim1=-2, dim2=-1).add_(d2)
+            lamP = lmbda * P                                     # H^-1 as an m x n field
+            w = v.reshape(b, m, n) * lamP
+            G = lamP[:, 1:, :]
+            inv_rows = G.sum(-1).reciprocal()                    # b x (m-1)
+            cols = lamP.sum(-2)                                  # b x n
+            S = -G.transpose(-2, -1).matmul(inv_rows.unsqueeze(-1) * G)
+            S.diagonal(dim1=-2, dim2=-1).add_(cols)
             L = torch.linalg.cholesky(S)
-            vHinv = v * hinv
-            blocks = vHinv.reshape((-1, m, n))
-            u1 = blocks.sum(-1)[:, 1:].unsqueeze(-2)
-            u2 = blocks.sum(-2).unsqueeze(-2)
-            if explicit_inverse:
-                Sinv = torch.cholesky_inverse(L)
-                R = -B.matmul(Sinv) * d1inv.unsqueeze(-1)
-                Q = -R.matmul(B.transpose(-2, -1) * d1inv.unsqueeze(-2))
-                Q.diagonal(dim1=-2, dim2=-1).add_(d1inv)
-                u3 = u1.matmul(Q) + u2.matmul(R.transpose(-2, -1))
-                u4 = u1.matmul(R) + u2.matmul(Sinv)
+            a = (w.sum(-1)[:, 1:] * inv_rows).unsqueeze(-2)      # b x 1 x (m-1)
+            rhs = w.sum(-2).unsqueeze(-2) - a.matmul(G)          # b x 1 x n
+            if P.is_cuda:
+                # y = rhs S^-1 = (rhs L^-T) L^-1.  On this ROCm build batched potrs with one right-hand side faults
+                # (hipErrorLaunchFailure from torch.cholesky_solve on (b, 2628, 1)), two single-column trsm take 8.2 ms
+                # and potri 15.3 ms at b = 8; inverting the triangular factor against the identity takes 5.0 ms
+                # (tools/micro/chol_time.py), followed by two mat-vecs
+                eye = torch.eye(n, dtype=P.dtype, device=P.device).expand(b, n, n)
+                Linv = torch.linalg.solve_triangular(L, eye, upper=False)
+                y = rhs.matmul(Linv.transpose(-2, -1)).matmul(Linv)
             else:
-                a = u1 * d1inv.unsqueeze(-2)                                            # b x 1 x (m-1)
-                rhs = u2 - a.matmul(B)                                                  # b x 1 x n
-                if P.is_cuda:
-                    # y = rhs S^-1 = (rhs L^-T) L^-1.  On this ROCm build batched potrs with one right-hand side faults
-                    # (hipErrorLaunchFailure from torch.cholesky_solve on (b, 2628, 1)), two single-column trsm take 8.2 ms
-                    # and potri 15.3 ms at b = 8; inverting the triangular factor against the identity takes 5.0 ms
-                    # (tools/micro/chol_time.py), followed by two mat-vecs
-                    eye = torch.eye(n, dtype=P.dtype, device=P.device).expand(b, n, n)
-                    Linv = torch.linalg.solve_triangular(L, eye, upper=False)
-                    u4 = rhs.matmul(Linv.transpose(-2, -1)).matmul(Linv)                # y: b x 1 x n
-                else:
-                    u4 = torch.cholesky_solve(rhs.transpose(-2, -1), L).transpose(-2, -1)
-                u3 = a - u4.matmul(B.transpose(-2, -1)) * d1inv.unsqueeze(-2)
-            u5 = u3.expand(-1, n, -1).transpose(-2, -1) + u4.expand(-1, m - 1, -1)
-            uHinv = torch.cat((u4, u5), dim=-2).flatten(start_dim=-2) * hinv
-            return uHinv - vHinv
+                y = torch.cholesky_solve(rhs.transpose(-2, -1), L).transpose(-2, -1)
+            row_mult = a - y.matmul(G.transpose(-2, -1)) * inv_rows.unsqueeze(-2)     # b x 1 x (m-1)
+            # A^T [row multipliers; column multipliers] as an m x n field: entry (i, j) = row_mult[i-1] (i >= 1) + y[j]
+            field = y.expand(b, m, n).clone()
+            field[:, 1:, :] += row_mult.transpose(-2, -1)
+            return (field * lamP - w).flatten(start_dim=-2)
 
     @staticmethod
     def forward(ctx, M, r, c, lmbda, tolerance, max_iterations):

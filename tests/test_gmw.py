@@ -88,17 +88,28 @@ def test_gmw_step_matches_reference_fixture_gpu(cuda):
     assert np.isfinite(last) and last < before                       # the step optimises what it reports
 
 
-def test_transport_backward_one_solve_equals_explicit_inverse():
-    """The re-associated backward (one Cholesky solve) against the reference's order of operations (explicit S^-1, R, Q)."""
+def test_transport_backward_equals_generic_declarative_formula():
+    """The re-associated backward (one Cholesky solve) against Lemma 4.4 of Gould et al. evaluated literally on small
+    problems: DP(M) = H^-1 A^T (A H^-1 A^T)^-1 A H^-1 - H^-1 with the (m + n - 1) x mn constraint matrix A written out."""
     from dcd_amd.gmw.optimal_transport import RegularisedTransportFn as T
     torch.manual_seed(2)
-    for dtype, tol in ((torch.float64, 1e-10), (torch.float32, 2e-4)):
-        M = torch.rand(2, 40, 40, dtype=dtype)
-        r = torch.full((2, 40), 1 / 40, dtype=dtype)
-        P = T.sinkhorn(M, r, r, 10.0, 1e-9, 100)
-        v = torch.randn(2, 1600, dtype=dtype)
-        g0, g1 = T.gradient(P, 10.0, v, explicit_inverse=True), T.gradient(P, 10.0, v)
-        assert (g0 - g1).abs().max().item() <= tol * g0.abs().max().item()
+    for dtype, tol, (m, n) in ((torch.float64, 1e-9, (7, 5)), (torch.float64, 1e-9, (6, 6)), (torch.float32, 5e-4, (12, 12))):
+        M = torch.rand(2, m, n, dtype=dtype)
+        r = torch.full((2, m), 1.0 / m, dtype=dtype)
+        c = torch.full((2, n), 1.0 / n, dtype=dtype)
+        P = T.sinkhorn(M, r, c, 10.0, 1e-12, 1000)
+        v = torch.randn(2, m * n, dtype=dtype)
+        got = T.gradient(P, 10.0, v)
+        A = torch.zeros(m + n - 1, m * n, dtype=torch.float64)
+        for i in range(1, m):                       # row constraints, first row dropped
+            A[i - 1, i * n:(i + 1) * n] = 1
+        for j in range(n):                          # column constraints
+            A[m - 1 + j, j::n] = 1
+        for k in range(2):
+            Hinv = torch.diag(10.0 * P[k].double().flatten())
+            DP = Hinv @ A.T @ torch.linalg.inv(A @ Hinv @ A.T) @ A @ Hinv - Hinv
+            ref = v[k].double() @ DP
+            assert (got[k].double() - ref).abs().max().item() <= tol * ref.abs().max().item()
 
 
 @pytest.mark.gpu
