@@ -17,29 +17,23 @@ from dcd_amd.model.layers.conv import Conv2d
 
 
 class _DCNv2(Function):
+    """Python-side autograd node of the op: argument order (input, offset, mask, weight, bias, ...) as in the reference's
+    `_DCNv2` (dcn_v2.py:16-54); the extension takes (input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg)."""
+
     @staticmethod
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
-        ctx.stride = _pair(stride)
-        ctx.padding = _pair(padding)
-        ctx.dilation = _pair(dilation)
-        ctx.kernel_size = _pair(weight.shape[2:4])
-        ctx.deformable_groups = deformable_groups
-        output = _backend.dcn_v2_forward(input, weight, bias, offset, mask,
-                                         ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
-                                         ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1],
-                                         ctx.deformable_groups)
+        kernel = tuple(weight.shape[2:4])
+        ctx.geometry = (*kernel, *_pair(stride), *_pair(padding), *_pair(dilation), int(deformable_groups))
         ctx.save_for_backward(input, offset, mask, weight, bias)
-        return output
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geometry)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias = ctx.saved_tensors
-        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
-            input.contiguous(), weight.contiguous(), bias, offset, mask, grad_output,
-            ctx.kernel_size[0], ctx.kernel_size[1], ctx.stride[0], ctx.stride[1],
-            ctx.padding[0], ctx.padding[1], ctx.dilation[0], ctx.dilation[1], ctx.deformable_groups)
-        return grad_input, grad_offset, grad_mask, grad_weight, grad_bias, None, None, None, None
+        grads = _backend.dcn_v2_backward(input.contiguous(), weight.contiguous(), bias, offset, mask, grad_output, *ctx.geometry)
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = grads
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias) + (None,) * 4
 
 
 dcn_v2_conv = _DCNv2.apply

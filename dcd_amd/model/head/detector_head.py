@@ -1,30 +1,34 @@
-"""Head = predictor + (loss | post-processor)  (DGDE/model/head/detector_head.py:10-34)."""
+"""Head = predictor + (loss | post-processor)  (DGDE/model/head/detector_head.py:10-34).
+
+The three sub-module names (`predictor`, `loss_evaluator`, `post_processor`) are state-dict prefixes and therefore the
+reference's; `bulid_head` [sic] is its factory's spelling and part of the API."""
+import contextlib
+
 import torch
 from torch import nn
 
-from .detector_predictor import make_predictor
-from .detector_loss import make_loss_evaluator
-from .detector_infer import make_post_processor
+from . import detector_infer, detector_loss, detector_predictor
+
+
+def _maybe_autocast(enabled, tensor):
+    return torch.autocast(device_type=tensor.device.type) if enabled else contextlib.nullcontext()
 
 
 class Detect_Head(nn.Module):
     def __init__(self, cfg, in_channels):
         super().__init__()
-        self.predictor = make_predictor(cfg, in_channels)
-        self.loss_evaluator = make_loss_evaluator(cfg)
-        self.post_processor = make_post_processor(cfg)
-        self.fp16 = cfg.MODEL.FP16
+        self.fp16 = bool(cfg.MODEL.FP16)
+        self.predictor = detector_predictor.make_predictor(cfg, in_channels)
+        self.loss_evaluator = detector_loss.make_loss_evaluator(cfg)
+        self.post_processor = detector_infer.make_post_processor(cfg)
 
     def forward(self, features, targets=None, test=False):
-        if self.fp16:
-            with torch.autocast(device_type=features.device.type):
-                x = self.predictor(features, targets)
-        else:
-            x = self.predictor(features, targets)
-        if self.training:
-            return self.loss_evaluator(x, targets)
-        return self.post_processor(x, targets, test=test, features=features)
+        with _maybe_autocast(self.fp16, features):
+            predictions = self.predictor(features, targets)
+        if not self.training:
+            return self.post_processor(predictions, targets, test=test, features=features)
+        return self.loss_evaluator(predictions, targets)
 
 
-def bulid_head(cfg, in_channels):   # [sic] the reference's spelling is part of its API
+def bulid_head(cfg, in_channels):
     return Detect_Head(cfg, in_channels)
