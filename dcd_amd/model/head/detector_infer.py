@@ -19,135 +19,136 @@ def make_post_processor(cfg):
 
 
 class PostProcessor(nn.Module):
+    """Stages of the decode, each a method: `_detections` (NMS + top-K + threshold + POI gather), `_decode_heads` (per-head
+    decodes of the kept rows), `_fuse_depths` (uncertainty-weighted direct / keypoint depths), then the edge-constraint depth,
+    the final locations and the (N, 14) rows.  Outputs, dict keys and quirks are the reference's."""
+
     def __init__(self, cfg, anno_encoder, key2channel):
         super().__init__()
-        self.anno_encoder = anno_encoder
-        self.key2channel = key2channel
-        self.det_threshold = cfg.TEST.DETECTIONS_THRESHOLD
-        self.max_detection = cfg.TEST.DETECTIONS_PER_IMG
-        self.eval_dis_iou = cfg.TEST.EVAL_DIS_IOUS
-        self.eval_depth = cfg.TEST.EVAL_DEPTH
-        self.extra_kpts_num = cfg.MODEL.HEAD.EXTRA_KPTS_NUM
-        self.output_depth = cfg.MODEL.HEAD.OUTPUT_DEPTH
-        self.pred_2d = cfg.TEST.PRED_2D
-        self.pred_direct_depth = 'depth' in self.key2channel.keys
-        self.depth_with_uncertainty = 'depth_uncertainty' in self.key2channel.keys
-        self.regress_keypoints = 'corner_offset' in self.key2channel.keys
-        self.keypoint_depth_with_uncertainty = 'corner_uncertainty' in self.key2channel.keys
-        self.use_extra_kpts = 'extra_kpts_2d' in self.key2channel.keys
-        self.use_only_extra_kpts = cfg.TEST.USE_ONLY_EXTRA_KPTS
-        self.uncertainty_as_conf = cfg.TEST.UNCERTAINTY_AS_CONFIDENCE
-        self.generate_data = cfg.TEST.GENERATE_GMW
+        self.anno_encoder, self.key2channel = anno_encoder, key2channel
+        test, head = cfg.TEST, cfg.MODEL.HEAD
+        self.det_threshold, self.max_detection = test.DETECTIONS_THRESHOLD, test.DETECTIONS_PER_IMG
+        self.eval_dis_iou, self.eval_depth = test.EVAL_DIS_IOUS, test.EVAL_DEPTH
+        self.pred_2d, self.use_only_extra_kpts = test.PRED_2D, test.USE_ONLY_EXTRA_KPTS
+        self.uncertainty_as_conf, self.generate_data = test.UNCERTAINTY_AS_CONFIDENCE, test.GENERATE_GMW
+        self.extra_kpts_num, self.output_depth = head.EXTRA_KPTS_NUM, head.OUTPUT_DEPTH
         self.img_width = cfg.INPUT.WIDTH_TRAIN
+        heads = set(key2channel.keys)
+        self.pred_direct_depth = 'depth' in heads
+        self.depth_with_uncertainty = 'depth_uncertainty' in heads
+        self.regress_keypoints = 'corner_offset' in heads
+        self.keypoint_depth_with_uncertainty = 'corner_uncertainty' in heads
+        self.use_extra_kpts = 'extra_kpts_2d' in heads
         self.gen_infer_records = []
+
+    _OPTIONAL_FIELDS = ("cls_ids", "target_centers", "dimensions", "rotys", "locations", "offset_3D", "extra_kpts_2d",
+                        "extra_kpts_3d", "reg_mask", "Calib_P")
 
     def prepare_targets(self, targets, test):
         pad_size = torch.stack([t.get_field("pad_size") for t in targets])
-        calibs = [t.get_field("calib") for t in targets]
-        size = torch.stack([torch.as_tensor(t.size) for t in targets]).to(pad_size.device)
-        out = dict(calib=calibs, size=size, pad_size=pad_size)
-        if test:
-            return out
-        for name in ("cls_ids", "target_centers", "dimensions", "rotys", "locations", "offset_3D", "extra_kpts_2d",
-                     "extra_kpts_3d", "reg_mask", "Calib_P"):
-            if all(t.has_field(name) for t in targets):
-                out[name] = torch.stack([t.get_field(name) for t in targets])
+        out = {"calib": [t.get_field("calib") for t in targets], "pad_size": pad_size,
+               "size": torch.stack([torch.as_tensor(t.size) for t in targets]).to(pad_size.device)}
+        if not test:
+            for name in self._OPTIONAL_FIELDS:
+                if all(t.has_field(name) for t in targets):
+                    out[name] = torch.stack([t.get_field(name) for t in targets])
         return out
 
+    # ---- stage 1: which cells are detections ------------------------------------------------------------------------
+    def _detections(self, heat, reg):
+        """3x3 max-pool NMS + per-image top-K in one launch (nms_hm -> select_topk, detector_infer.py:101-106), score
+        threshold (the one host sync of the decode), regression vectors of the kept cells."""
+        scores, cell_idx, classes, ys, xs = select_topk(heat, K=self.max_detection, fuse_nms=True)
+        vectors = select_point_of_interest(heat.shape[0], cell_idx, reg).view(-1, reg.shape[1])
+        scores = scores.view(-1)
+        keep = (scores >= self.det_threshold).nonzero(as_tuple=True)[0]
+        if keep.numel() == 0:
+            return None
+        centres = torch.stack((xs.view(-1), ys.view(-1)), dim=1)
+        return {"scores": scores[keep], "classes": classes.view(-1)[keep], "centres": centres[keep], "vectors": vectors[keep]}
+
+    @staticmethod
+    def _nothing_detected(like, vis):
+        empty = like.new_zeros
+        vis['keypoints'], vis['proj_center'] = empty(0, 20), empty(0, 2)
+        info = {'dis_ious': None, 'depth_errors': None, 'vis_scores': empty(0), 'uncertainty_conf': empty(0),
+                'estimated_depth_error': empty(0)}
+        return empty(0, 14), info, vis
+
+    # ---- stage 2: per-head decodes -----------------------------------------------------------------------------------
+    def _decode_heads(self, det, ctx, reg, vis):
+        enc, sl, vec = self.anno_encoder, self.key2channel, det["vectors"]
+        out = {"offset_3d": vec[:, sl('3d_offset')]}
+        vis['proj_center'] = det["centres"] + out["offset_3d"]
+        out["box2d"] = enc.decode_box2d_fcos(det["centres"], F.relu(vec[:, sl('2d_dim')]), ctx["pad_size"], ctx["size"])
+        out["dims"] = enc.decode_dimension(det["classes"], vec[:, sl('3d_dim')])
+        out["orientation"] = torch.cat((vec[:, sl('ori_cls')], vec[:, sl('ori_offset')]), dim=1)
+        if self.pred_direct_depth:
+            out["direct_depth"] = enc.decode_depth(vec[:, sl('depth')].squeeze(-1))
+        if self.depth_with_uncertainty:
+            out["direct_sigma"] = vec[:, sl('depth_uncertainty')].exp()
+            vis['depth_uncertainty'] = reg[:, sl('depth_uncertainty'), ...].squeeze(1)
+        if self.regress_keypoints:
+            out["corner_offsets"] = vec[:, sl('corner_offset')].view(-1, 10, 2)
+            out["corner_depths"] = enc.decode_depth_from_keypoints_batch(out["corner_offsets"], out["dims"], ctx["calib"])
+            vis['keypoints'] = out["corner_offsets"]
+        if self.keypoint_depth_with_uncertainty:
+            out["corner_sigma"] = vec[:, sl('corner_uncertainty')].exp()
+        return out
+
+    # ---- stage 3: inverse-uncertainty weighted depth (detector_infer.py:150-170) -------------------------------------
+    def _fuse_depths(self, dec, vis):
+        if self.pred_direct_depth and self.depth_with_uncertainty:
+            depths = torch.cat((dec["direct_depth"].unsqueeze(1), dec["corner_depths"]), dim=1)
+            sigma = torch.cat((dec["direct_sigma"], dec["corner_sigma"]), dim=1)
+        else:
+            depths, sigma = dec["corner_depths"].clone(), dec["corner_sigma"].clone()
+        weights = 1 / sigma
+        vis['min_uncertainty'] = weights.argmax(dim=1)
+        weights = weights / weights.sum(dim=1, keepdim=True)
+        return (depths * weights).sum(dim=1), (weights * sigma).sum(dim=1)
+
     def forward(self, predictions, targets, features=None, test=False, refine_module=None):
-        pred_heatmap, pred_regression = predictions['cls'], predictions['reg']
-        batch = pred_heatmap.shape[0]
-        enc, k2c = self.anno_encoder, self.key2channel
-        tv = self.prepare_targets(targets, test=test)
-        calib, pad_size, img_size = tv['calib'], tv['pad_size'], tv['size']
         if self.eval_dis_iou or self.eval_depth:
             raise NotImplementedError("TEST.EVAL_DIS_IOUS / TEST.EVAL_DEPTH call functions the reference never defines "
                                       "(detector_infer.py:95,98)")
-        dis_ious = depth_errors = None
-        visualize_preds = {'heat_map': pred_heatmap.clone()}
+        heat, reg = predictions['cls'], predictions['reg']
+        enc = self.anno_encoder
+        ctx = self.prepare_targets(targets, test=test)
+        vis = {'heat_map': heat.clone()}
+        det = self._detections(heat, reg)
+        if det is None:
+            return self._nothing_detected(heat, vis)
+        dec = self._decode_heads(det, ctx, reg, vis)
+        fused_depth, depth_error = self._fuse_depths(dec, vis)
 
-        # 3x3 max-pool NMS + per-image top-K in one launch (nms_hm -> select_topk, detector_infer.py:101-106)
-        scores, indexs, clses, ys, xs = select_topk(pred_heatmap, K=self.max_detection, fuse_nms=True)
-        pred_bbox_points = torch.cat([xs.view(-1, 1), ys.view(-1, 1)], dim=1)
-        pois = select_point_of_interest(batch, indexs, pred_regression).view(-1, pred_regression.shape[1])
+        centres, offset = det["centres"], dec["offset_3d"]
+        image_of = fused_depth.new_zeros(fused_depth.shape[0]).long()          # batch size 1, like the reference (:173)
+        coarse = enc.decode_location_flatten(centres, offset, fused_depth, ctx["calib"], ctx["pad_size"], image_of)
+        rotys, alphas = enc.decode_axes_orientation(dec["orientation"], coarse)
+        rotys, alphas = rotys.view(-1, 1), alphas.view(-1, 1)
+        scores = det["scores"].view(-1, 1)
 
-        scores = scores.view(-1)
-        keep = (scores >= self.det_threshold).nonzero(as_tuple=True)[0]     # the host sync of the decode
-        if keep.numel() == 0:
-            z = scores.new_zeros
-            visualize_preds['keypoints'] = z(0, 20)
-            visualize_preds['proj_center'] = z(0, 2)
-            eval_utils = {'dis_ious': dis_ious, 'depth_errors': depth_errors, 'vis_scores': z(0),
-                          'uncertainty_conf': z(0), 'estimated_depth_error': z(0)}
-            return z(0, 14), eval_utils, visualize_preds
-
-        scores = scores.index_select(0, keep)
-        clses = clses.view(-1).index_select(0, keep)
-        pred_bbox_points = pred_bbox_points.index_select(0, keep)
-        pois = pois.index_select(0, keep)
-
-        pred_2d_reg = F.relu(pois[:, k2c('2d_dim')])
-        pred_offset_3D = pois[:, k2c('3d_offset')]
-        pred_dimensions_offsets = pois[:, k2c('3d_dim')]
-        pred_orientation = torch.cat((pois[:, k2c('ori_cls')], pois[:, k2c('ori_offset')]), dim=1)
-        visualize_preds['proj_center'] = pred_bbox_points + pred_offset_3D
-        pred_box2d = enc.decode_box2d_fcos(pred_bbox_points, pred_2d_reg, pad_size, img_size)
-        pred_dimensions = enc.decode_dimension(clses, pred_dimensions_offsets)
-
-        if self.pred_direct_depth:
-            pred_direct_depths = enc.decode_depth(pois[:, k2c('depth')].squeeze(-1))
-        if self.depth_with_uncertainty:
-            pred_direct_uncertainty = pois[:, k2c('depth_uncertainty')].exp()
-            visualize_preds['depth_uncertainty'] = pred_regression[:, k2c('depth_uncertainty'), ...].squeeze(1)
-        if self.regress_keypoints:
-            pred_keypoint_offset = pois[:, k2c('corner_offset')].view(-1, 10, 2)
-            pred_keypoints_depths = enc.decode_depth_from_keypoints_batch(pred_keypoint_offset, pred_dimensions, calib)
-            visualize_preds['keypoints'] = pred_keypoint_offset
-        if self.keypoint_depth_with_uncertainty:
-            pred_keypoint_uncertainty = pois[:, k2c('corner_uncertainty')].exp()
-
-        if self.pred_direct_depth and self.depth_with_uncertainty:
-            combined_depths = torch.cat((pred_direct_depths.unsqueeze(1), pred_keypoints_depths), dim=1)
-            combined_uncertainty = torch.cat((pred_direct_uncertainty, pred_keypoint_uncertainty), dim=1)
-        else:
-            combined_depths = pred_keypoints_depths.clone()
-            combined_uncertainty = pred_keypoint_uncertainty.clone()
-        depth_weights = 1 / combined_uncertainty
-        visualize_preds['min_uncertainty'] = depth_weights.argmax(dim=1)
-        depth_weights = depth_weights / depth_weights.sum(dim=1, keepdim=True)
-        pred_depths = torch.sum(combined_depths * depth_weights, dim=1)
-        estimated_depth_error = torch.sum(depth_weights * combined_uncertainty, dim=1)
-
-        batch_idxs = pred_depths.new_zeros(pred_depths.shape[0]).long()
-        coarse_loc = enc.decode_location_flatten(pred_bbox_points, pred_offset_3D, pred_depths, calib, pad_size, batch_idxs)
-        pred_rotys, pred_alphas = enc.decode_axes_orientation(pred_orientation, coarse_loc)
-        clses = clses.view(-1, 1)
-        pred_alphas = pred_alphas.view(-1, 1)
-        pred_rotys = pred_rotys.view(-1, 1)
-        scores = scores.view(-1, 1)
-
-        # depth from the dense edge constraints: mean over all keypoint pairs (detector_infer.py:183-184, :215-225)
-        pred_depths = self.compute_pairs_kpts_depth(tv, pois, pred_bbox_points, pred_offset_3D, pred_rotys, visualize_preds)
-        pred_locations = enc.decode_location_flatten(pred_bbox_points, pred_offset_3D, pred_depths, calib, pad_size, batch_idxs)
-        pred_locations = torch.cat((pred_locations[:, :1], pred_locations[:, 1:2] + pred_dimensions[:, 1:2] / 2,
-                                    pred_locations[:, 2:]), dim=1)
+        # the reported depth comes from the dense edge constraints: mean over all keypoint pairs (detector_infer.py:183-184)
+        edge_depth = self.compute_pairs_kpts_depth(ctx, det["vectors"], centres, offset, rotys, vis)
+        bottom = enc.decode_location_flatten(centres, offset, edge_depth, ctx["calib"], ctx["pad_size"], image_of)
+        locations = bottom.clone()
+        locations[:, 1] += dec["dims"][:, 1] / 2                               # object centre -> bottom-face centre (KITTI)
         if self.generate_data:
-            self.generate_infer_data(tv, pois, pred_bbox_points, pred_offset_3D, pred_keypoint_offset, pred_dimensions,
-                                     visualize_preds, pred_box2d, pred_rotys, pred_locations, scores)
+            self.generate_infer_data(ctx, det["vectors"], centres, offset, dec.get("corner_offsets"), dec["dims"], vis,
+                                     dec["box2d"], rotys, locations, scores)
 
-        pred_dimensions = pred_dimensions.roll(shifts=-1, dims=1)     # (l,h,w) -> (h,w,l)
-        vis_scores = scores.clone()
-        if self.uncertainty_as_conf and estimated_depth_error is not None:
-            uncertainty_conf = 1 - torch.clamp(estimated_depth_error, min=0.01, max=1)
-            scores = scores * uncertainty_conf.view(-1, 1)
-            scores = torch.where(torch.isnan(scores), torch.zeros_like(scores), scores)
+        dims_hwl = dec["dims"].roll(shifts=-1, dims=1)                          # (l, h, w) -> (h, w, l)
+        raw_scores = scores.clone()
+        if self.uncertainty_as_conf and depth_error is not None:
+            confidence = 1 - torch.clamp(depth_error, min=0.01, max=1)
+            scores = torch.nan_to_num(scores * confidence.view(-1, 1), nan=0.0, posinf=float("inf"), neginf=float("-inf"))
         else:
-            uncertainty_conf, estimated_depth_error = None, None
-
-        result = torch.cat([clses, pred_alphas, pred_box2d, pred_dimensions, pred_locations, pred_rotys, scores], dim=1)
-        eval_utils = {'dis_ious': dis_ious, 'depth_errors': depth_errors, 'uncertainty_conf': uncertainty_conf,
-                      'estimated_depth_error': estimated_depth_error, 'vis_scores': vis_scores}
-        return result, eval_utils, visualize_preds
+            confidence = depth_error = None
+        rows = torch.cat([det["classes"].view(-1, 1), alphas, dec["box2d"], dims_hwl, locations, rotys, scores], dim=1)
+        info = {'dis_ious': None, 'depth_errors': None, 'uncertainty_conf': confidence, 'estimated_depth_error': depth_error,
+                'vis_scores': raw_scores}
+        return rows, info, vis
 
     def _image_kpts(self, targets, pois, pred_bbox_points, pred_offset_3D):
         k2c = self.key2channel

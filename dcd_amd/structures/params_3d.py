@@ -1,19 +1,23 @@
-"""Per-image label container with the reference's interface (DGDE/structures/params_3d.py:6-57)."""
+"""Per-image label container with the reference's interface (DGDE/structures/params_3d.py:6-57): `ParamsList(image_size,
+is_train)`, `add_field / get_field / has_field / fields / to`, `len()` = number of regressed objects.  The attribute names
+`size`, `is_train` and `extra_fields` are read by callers and kept."""
 import torch
 
 
-class ParamsList:
-    """A bag of named fields for one image.  Tensors (and anything with `.to`) follow `.to(device)`;
-    strings and calibration objects are kept as they are; everything else goes through `torch.as_tensor`."""
+def _keep_as_is(value):
+    """Tensors, strings and calibration objects (anything that can project image points to the rectified frame) are stored
+    unchanged; numbers, lists and numpy arrays become tensors."""
+    return torch.is_tensor(value) or isinstance(value, str) or hasattr(value, "project_image_to_rect")
 
+
+class ParamsList:
     def __init__(self, image_size, is_train=True):
-        self.size = image_size
-        self.is_train = is_train
+        self.size, self.is_train = image_size, is_train
         self.extra_fields = {}
 
+    # ---- field access ------------------------------------------------------------------------------------------------
     def add_field(self, field, field_data):
-        keep = isinstance(field_data, (torch.Tensor, str)) or hasattr(field_data, "project_image_to_rect")
-        self.extra_fields[field] = field_data if keep else torch.as_tensor(field_data)
+        self.extra_fields[field] = field_data if _keep_as_is(field_data) else torch.as_tensor(field_data)
 
     def get_field(self, field):
         return self.extra_fields[field]
@@ -22,21 +26,20 @@ class ParamsList:
         return field in self.extra_fields
 
     def fields(self):
-        return list(self.extra_fields)
+        return [*self.extra_fields]
 
     def _copy_extra_fields(self, target):
         self.extra_fields.update(target.extra_fields)
 
+    # ---- device placement: every field that knows `.to` follows, the rest is shared ---------------------------------
     def to(self, device):
-        moved = ParamsList(self.size, self.is_train)
-        for name, value in self.extra_fields.items():
-            moved.add_field(name, value.to(device) if hasattr(value, "to") else value)
-        return moved
+        clone = type(self)(self.size, self.is_train)
+        clone.extra_fields = {k: (v.to(device) if hasattr(v, "to") else v) for k, v in self.extra_fields.items()}
+        return clone
 
     def __len__(self):
-        if not self.is_train:
-            return 0
-        return int(torch.count_nonzero(self.extra_fields["reg_mask"]))
+        return int(torch.count_nonzero(self.extra_fields["reg_mask"])) if self.is_train else 0
 
     def __repr__(self):
-        return "ParamsList(regress_number=%d, image_width=%s, image_height=%s)" % (len(self), self.size[0], self.size[1])
+        width, height = self.size[0], self.size[1]
+        return f"{type(self).__name__}(regress_number={len(self)}, image_width={width}, image_height={height})"
