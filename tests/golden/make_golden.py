@@ -269,6 +269,28 @@ def golden_solver():
          n_groups=np.array(len(opt.param_groups)))
 
 
+def golden_config():
+    """The reference's config tree (config/defaults.py merged with runs/DGDE.yaml) flattened to dotted keys -> cfg.json; pins
+    dcd_amd/config/{defaults,dgde_run}.py key by key."""
+    import json
+    from config import cfg
+    c = cfg.clone()
+    c.defrost()
+    c.merge_from_file(os.path.join(REF, "runs", "DGDE.yaml"))
+
+    def flat(node, prefix=""):
+        out = {}
+        for k, v in node.items():
+            if isinstance(v, dict):
+                out.update(flat(v, prefix + k + "."))
+            else:
+                out[prefix + k] = list(v) if isinstance(v, tuple) else v
+        return out
+    with open(os.path.join(HERE, "cfg.json"), "w") as f:
+        json.dump(flat(c), f, indent=0, sort_keys=True)
+    print("cfg.json: %d keys" % len(flat(c)))
+
+
 def golden_model():
     from model.detector import KeypointDetector
     cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
@@ -334,6 +356,7 @@ def main():
     golden_loss_computation()
     golden_gen_data()
     golden_solver()
+    golden_config()
     golden_model()
 
 

@@ -260,3 +260,27 @@ def test_product_ops_refuse_cpu_tensors():
     with pytest.raises(RuntimeError):
         _ext.dcn_v2_forward(x, torch.zeros(1, 1, 3, 3), torch.zeros(1), torch.zeros(1, 18, 4, 4), torch.zeros(1, 9, 4, 4),
                             3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+def test_config_tree_equals_the_reference(tmp_path=None):
+    """dcd_amd/config (defaults + the DGDE run tables of dgde_run.py) against the reference's merged tree, key by key
+    (tests/golden/cfg.json, written by make_golden.golden_config from config/defaults.py + runs/DGDE.yaml)."""
+    import json
+    import os
+    from dcd_amd.config import get_cfg
+    ref = json.load(open(os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden", "cfg.json")))
+
+    def flat(node, prefix=""):
+        out = {}
+        for k, v in node.items():
+            if isinstance(v, dict):
+                out.update(flat(v, prefix + k + "."))
+            else:
+                out[prefix + k] = list(v) if isinstance(v, tuple) else v
+        return out
+    def plain(v):                                    # JSON has no tuples
+        return [plain(x) for x in v] if isinstance(v, (list, tuple)) else v
+    ours = {k: plain(v) for k, v in flat(get_cfg()).items()}
+    assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref))[:10])
+    diff = {k: (ours[k], ref[k]) for k in ref if ours[k] != ref[k] and k != "PATHS_CATALOG"}      # a machine-specific path
+    assert not diff, diff
