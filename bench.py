@@ -1,7 +1,9 @@
 #!/usr/bin/env python3
 """DGDE train-step benchmark on MI355X:  images/sec at global batch 8, 384x1280, fp32 (BASELINE.json configs[1]).
 
-  python bench.py --gpus N --steps K --warmup W            (N > 1: launched by torch.distributed.run, one rank per GPU)
+  python bench.py --gpus N --steps K --warmup W
+      N > 1: one rank per GPU, either launched by torch.distributed.run (RANK/WORLD_SIZE in the environment) or, when
+      started bare, by bench.py itself (it spawns torch.distributed.run as a child before touching the GPU).
 
 A step = forward + 13-term loss + backward + gradient all-reduce (RCCL, N>1) + grad clip + AdamW, on a synthetic
 KITTI-shaped batch that is resident in HBM before the timed region.  The batch named by the metric (8 images) is
@@ -106,15 +108,14 @@ def run_gpu(args):
     rank = int(os.environ.get("RANK", 0))
     local_rank = int(os.environ.get("LOCAL_RANK", 0))
     if world != args.gpus:
-        raise SystemExit("--gpus %d but WORLD_SIZE=%d: launch with torch.distributed.run --nproc-per-node %d" % (
-            args.gpus, world, args.gpus))
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
     if world > 1 or "RANK" in os.environ:                               # launched by torch.distributed.run
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
     # MIOpen: its exhaustive find costs minutes on a fresh box, so by default its heuristics (immediate mode) pick the
-    # conv kernels.  DCD_MIOPEN_FIND=1 turns the search on (used once to fill dcd_amd/miopen_db/, see README).
+    # conv kernels.  DCD_MIOPEN_FIND=1 turns the search on (measured in round 1: no gain).
     torch.backends.cudnn.benchmark = os.environ.get("DCD_MIOPEN_FIND", "0") == "1"
 
     cfg, model, optimizer, images, targets, per_rank = build_everything(args, device, world, local_rank)
@@ -345,6 +346,64 @@ def gmw_cpu_baseline_child(args):
                       "sample": "%d GMW train steps of 2 objects x 2628 edges on the host (PyTorch CPU ops, LAPACK Cholesky); %.1f s each" % (n, dt)}))
 
 
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher around it: start the N ranks ourselves, the way the reference
+    spawns its own (DGDE/engine/launch.py:50-55).  This process has not touched the GPU (nothing is imported before this
+    point), it starts torch.distributed.run as a CHILD and exits with its code; rank 0's JSON line passes through."""
+    import socket
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    env.setdefault("OMP_NUM_THREADS", str(max(1, (os.cpu_count() or 8) // args.gpus)))
+    return subprocess.call(cmd, env=env)
+
+
+def run_dry(args):
+    """Launch / fence / max-over-ranks / one-JSON-line plumbing with no GPU in it (gloo on the host).  The step is a
+    gradient-sized all-reduce of zeros; tests/test_bench_launch.py runs this at world size 2.  Never a measurement."""
+    import torch
+    import torch.distributed as dist
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    rank = int(os.environ.get("RANK", 0))
+    if world != args.gpus:
+        raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        dist.init_process_group(backend="gloo")
+    per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
+    grad = torch.zeros(1 << 16)
+
+    def step():
+        if world > 1:
+            dist.all_reduce(grad)
+    for _ in range(args.warmup):
+        step()
+    if world > 1:
+        dist.barrier()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        step()
+    if world > 1:
+        dist.barrier()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+        dist.destroy_process_group()
+    if rank != 0:
+        return None
+    return {"metric": "images/sec DGDE train step (bs=8, 384x1280)", "value": None, "unit": "images/s", "n_gpus": world,
+            "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
+            "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
+            "dry": True, "config": {"workload": "DRY RUN of the launch path, no GPU work", "global_batch": per_rank * world,
+                                    "per_gpu_batch": per_rank, "parallelism": "dp%d" % world}}
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--workload", choices=("dgde", "gmw"), default="dgde", help="dgde: the headline metric (default); gmw: SURVEY 8(f) rank 1")
@@ -359,19 +418,22 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-timeout", type=int, default=420)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--dry", action="store_true", help="exercise the multi-rank launch path on the host (gloo), no GPU work")
     args = ap.parse_args()
     if args.cpu_baseline_child:
         (gmw_cpu_baseline_child if args.workload == "gmw" else cpu_baseline_child)(args)
         return
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        sys.exit(self_launch(args))
     # RCCL prints its version banner on stdout when the first communicator is created; the contract is ONE JSON line on
     # stdout, so everything else written to fd 1 during the run goes to stderr.
     sys.stdout.flush()
     real_stdout = os.dup(1)
     os.dup2(2, 1)
-    out = run_gmw(args) if args.workload == "gmw" else run_gpu(args)
+    out = run_dry(args) if args.dry else run_gmw(args) if args.workload == "gmw" else run_gpu(args)
     sys.stdout.flush()
     if out is not None:
-        if args.gpus == 1 and not args.no_cpu_baseline:
+        if args.gpus == 1 and not args.no_cpu_baseline and not args.dry:
             out["cpu_baseline"] = cpu_baseline(args)
         os.write(real_stdout, (json.dumps(out) + "\n").encode())
 

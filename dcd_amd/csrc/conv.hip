@@ -22,6 +22,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "lds_limit.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -524,13 +525,9 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *o
     const int nchunk = (Cc + WN_CH - 1) / WN_CH, nz = (Kk + WN_KS - 1) / WN_KS;
     if (workspace_bytes < (size_t)nchunk * nz * WN_U * sizeof(float)) return DCD_ERR_WORKSPACE;
     float *ul = (float *)workspace;
-    static bool attr_set = false;
+    static LdsLimit lds_limit;
     const size_t ldsb = (size_t)2 * WN_BUF * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wino_conv3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-            return DCD_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32)) return DCD_ERR_LAUNCH;
     const int nprep = nz * nchunk * WN_KS * WN_CH;
     // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
     hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
@@ -572,13 +569,9 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x);
     const int nblk = nog * ncg;
     if (workspace_bytes < (size_t)nblk * S * WW_PART * sizeof(float)) return DCD_ERR_WORKSPACE;
-    static bool attr_set = false;
+    static LdsLimit lds_limit;
     const size_t ldsb = (size_t)2 * WW_BUF * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)wino_wrw3x3_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-            return DCD_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32)) return DCD_ERR_LAUNCH;
     hipLaunchKernelGGL(wino_wrw3x3_f32, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout, B,
                        H, W, strips_x, S, ncg, nblk);
     hipLaunchKernelGGL(wino_wrw_reduce, dim3(nblk * 4096 / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout, S,

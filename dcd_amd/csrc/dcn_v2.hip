@@ -18,8 +18,11 @@
 //    computes IS its MFMA B operand, so the forward needs no LDS and no column buffer at all.
 //  * Weights are re-laid out once per call into Wf[k'][o] (forward A operand, coalesced over o)
 //    and Wb[o][k'] (backward-data A operand, coalesced over k') in the caller's workspace.
-//  * grad_input is scattered with hardware fp32 atomics (global_atomic_add_f32), like the
-//    reference's col2im; grad_weight / grad_bias are reduced across pixel splits with atomics.
+//  * grad_input is a GATHER, not the reference's col2im scatter: `dcn_build_inverse` lists, per input cell and tap, the
+//    output pixels whose sample touches the cell, and `dcn_bwd_input_*` contracts W with those dY values on the matrix
+//    pipe and stores plainly (atomics remain only as the fallback for samples beyond the list radius / overflowed cells).
+//    grad_weight leaves the tiled kernel as per-workgroup partials summed in a fixed order by `dcn_dw_reduce`;
+//    grad_bias is its own two-stage reduction.
 //
 // Sample validity follows the reference exactly: a tap contributes iff -1 < h < H and -1 < w < W
 // (cuda/dcn_v2_im2col_cuda.cu:180), each corner iff it lies inside the image (:38-48).
@@ -29,6 +32,7 @@
 #include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
+#include "lds_limit.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x32 __attribute__((ext_vector_type(32)));
@@ -2001,18 +2005,15 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
         const int nchunk = (Cin + TL_CH - 1) / TL_CH, nz = (Cout + TL_OB - 1) / TL_OB;
         const size_t nwl = (size_t)nz * nchunk * TL_W_FLOATS;
         if (nwl <= 2 * nw) {                                          // Wl lives in the [Wf | Wb] area
-            static bool attr_set = false;
+            static LdsLimit lds_limit8, lds_limit4;
             static int tile_rows = 0;
-            if (!attr_set) {
+            if (tile_rows == 0) {
                 const char *e = getenv("DCD_TILE_ROWS");
                 tile_rows = (e && atoi(e) == 4) ? 4 : 8;
-                if (hipFuncSetAttribute((const void *)dcn_fwd_tile_f32<8>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * TileCfg<8>::BUF * sizeof(float))) != hipSuccess ||
-                    hipFuncSetAttribute((const void *)dcn_fwd_tile_f32<4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                        (int)(2 * TileCfg<4>::BUF * sizeof(float))) != hipSuccess)
-                    return DCD_ERR_LAUNCH;
-                attr_set = true;
             }
+            if (!lds_limit8.raise((int)(2 * TileCfg<8>::BUF * sizeof(float)), dcn_fwd_tile_f32<8>) ||
+                !lds_limit4.raise((int)(2 * TileCfg<4>::BUF * sizeof(float)), dcn_fwd_tile_f32<4>))
+                return DCD_ERR_LAUNCH;
             static int rescue_taps = 0;
             if (rescue_taps == 0) {
                 const char *e = getenv("DCD_FWD_RESCUE_TAPS");       // A/B: far taps in the worst wave that hand a region to the rescue kernel
@@ -2168,13 +2169,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         bool bi_tiled = false;
 #ifndef DCN_NO_BWD_TILE
         if (bi_tile_ok) {
-            static bool attr_set = false;
+            static LdsLimit lds_limit;
             const size_t ldsb = (size_t)(BI_OC * BI_PLANE + (BI_OC / 2) * 9 * 2 * 2 * 32) * sizeof(float);
-            if (!attr_set) {
-                if (hipFuncSetAttribute((const void *)dcn_bwd_input_tile_f32<2>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-                    return DCD_ERR_LAUNCH;
-                attr_set = true;
-            }
+            if (!lds_limit.raise((int)ldsb, dcn_bwd_input_tile_f32<2>)) return DCD_ERR_LAUNCH;
             const int tiles_x = (W + 31) / 32, tiles_y = (H + BI_TR - 1) / BI_TR;
             hipLaunchKernelGGL(dcn_bwd_input_tile_f32<2>, dim3(tiles_x * tiles_y, B, (nblk + 1) / 2), dim3(BI_TR * 64), ldsb, stream,
                                grad_output, wb, inv, grad_input, g, tiles_x);
@@ -2206,14 +2203,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     bool bd_tiled = false;
 #ifndef DCN_NO_BWD_TILE
     if (bd_tile_ok) {
-        static bool attr_set = false;
+        static LdsLimit lds_limit;
         const size_t ldsb = (size_t)BD_CB * BD_PLANE * sizeof(float);
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)dcn_bwd_data_tile_f32<32>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess ||
-                hipFuncSetAttribute((const void *)dcn_bwd_data_tile_f32<64>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-                return DCD_ERR_LAUNCH;
-            attr_set = true;
-        }
+        if (!lds_limit.raise((int)ldsb, dcn_bwd_data_tile_f32<32>, dcn_bwd_data_tile_f32<64>)) return DCD_ERR_LAUNCH;
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + BD_TR - 1) / BD_TR;
         const int nsp = nblk;                 // one 32-channel block per workgroup
         dim3 gridt(tiles_x * tiles_y, B, nsp), blockt(BD_TR * 64);
@@ -2243,14 +2235,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     bool dw_tiled = false;
 #ifndef DCN_NO_BWD_TILE
     if (tile_shape) {
-        static bool attr_set = false;
+        static LdsLimit lds_limit;
         const size_t ldsb = (size_t)(DW_IN_FLOATS + DW_DY_FLOATS) * sizeof(float);
-        if (!attr_set) {
-            if (hipFuncSetAttribute((const void *)dcn_bwd_weight_tile_f32, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) !=
-                hipSuccess)
-                return DCD_ERR_LAUNCH;
-            attr_set = true;
-        }
+        if (!lds_limit.raise((int)ldsb, dcn_bwd_weight_tile_f32)) return DCD_ERR_LAUNCH;
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + DW_TR - 1) / DW_TR;
         const int ncb = (Cin + DW_CB - 1) / DW_CB, nzo = (Cout + TL_OB - 1) / TL_OB;
         const int total = B * tiles_x * tiles_y;

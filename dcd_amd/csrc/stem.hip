@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "lds_limit.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 
@@ -253,13 +254,9 @@ int launch_fwd(hipStream_t stream, const float *input, const float *weight, floa
                float *wp)
 {
     using C = StemCfg<CI, KS>;
-    static bool attr_set = false;
+    static LdsLimit lds_limit;
     const size_t ldsb = (size_t)CI * C::PLANE_F * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)stem_fwd_f32<CI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-            return DCD_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!lds_limit.raise((int)ldsb, stem_fwd_f32<CI, KS>)) return DCD_ERR_LAUNCH;
     hipLaunchKernelGGL((stem_prep_weights<CI, KS>), dim3((C::NSTEP * 64 + 255) / 256), dim3(256), 0, stream, weight, wp, backward_data);
     const int tiles_x = (W + ST_C - 1) / ST_C, tiles_y = (H + ST_R - 1) / ST_R;
     hipLaunchKernelGGL((stem_fwd_f32<CI, KS>), dim3(tiles_x * tiles_y, B), dim3(256), ldsb, stream, input, (const float *)wp, output, H, W,
@@ -273,13 +270,9 @@ template <int CI, int KS>
 int launch_wrw(hipStream_t stream, const float *input, const float *grad_output, float *grad_weight, int B, int H, int W, float *part)
 {
     using C = StemCfg<CI, KS>;
-    static bool attr_set = false;
+    static LdsLimit lds_limit;
     const size_t ldsb = (size_t)(CI * C::PLANE_W + 16 * ST_DPLANE) * sizeof(float);
-    if (!attr_set) {
-        if (hipFuncSetAttribute((const void *)stem_wrw_f32<CI, KS>, hipFuncAttributeMaxDynamicSharedMemorySize, (int)ldsb) != hipSuccess)
-            return DCD_ERR_LAUNCH;
-        attr_set = true;
-    }
+    if (!lds_limit.raise((int)ldsb, stem_wrw_f32<CI, KS>)) return DCD_ERR_LAUNCH;
     const int tiles_x = (W + ST_C - 1) / ST_C, tiles_y = (H + ST_R - 1) / ST_R;
     const int64_t total = (int64_t)B * tiles_x * tiles_y;
     const int nwg = total < ST_WRW_WGS ? (int)total : ST_WRW_WGS;

@@ -88,29 +88,116 @@ def step_schedulers(scheduler, warmup_scheduler, iteration, cfg):
         scheduler.step(iteration)
 
 
+def _reference_order(model, optimizer):
+    """For every trainable parameter in `named_parameters` order -- the order in which the reference creates its one-parameter
+    groups (DGDE/solver/__init__.py:10-25) -- (our group index, our flat state index).  Parameters that are frozen here but
+    trainable in the reference (the dead `Tree.project` convs under DDP) get None: they never receive a gradient there either,
+    so the reference keeps no optimizer state for them."""
+    m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
+    where, flat = {}, 0
+    for gi, g in enumerate(optimizer.param_groups):
+        for p in g["params"]:
+            where[id(p)] = (gi, flat)
+            flat += 1
+    frozen_here = {id(p) for mod in m.modules() if getattr(mod, "dead_project", False) for p in mod.project.parameters()}
+    order = []
+    for _, p in m.named_parameters():
+        if id(p) in where:
+            order.append(where[id(p)])
+        elif id(p) in frozen_here or p.requires_grad:
+            order.append(None)
+    return order
+
+
+def optimizer_state_to_reference(model, optimizer):
+    """Our pooled AdamW state (two groups: weights, biases) re-expressed in the reference's layout: one group per parameter in
+    `named_parameters` order, state keyed by that index -- what `utils/check_point.py:31-43` saves and
+    `SOLVER.LOAD_OPTIMIZER_SCHEDULER` loads."""
+    sd = optimizer.state_dict()
+    groups, state = [], {}
+    for ref_idx, loc in enumerate(_reference_order(model, optimizer)):
+        if loc is None:                                   # frozen here: hyper-parameters of a weight group, no state
+            g = {k: v for k, v in sd["param_groups"][0].items() if k != "params"}
+        else:
+            g = {k: v for k, v in sd["param_groups"][loc[0]].items() if k != "params"}
+            if loc[1] in sd["state"]:
+                state[ref_idx] = sd["state"][loc[1]]
+        g["params"] = [ref_idx]
+        g["fused"] = None                                  # the reference's optimizer is the plain for-loop AdamW
+        groups.append(g)
+    return {"state": state, "param_groups": groups}
+
+
+def optimizer_state_from_reference(ref_sd, model, optimizer):
+    """Inverse of optimizer_state_to_reference: a reference checkpoint's 'optimizer' entry -> a state dict this optimizer
+    loads.  Learning rates are taken per pooled group from the first member (all members share it by construction)."""
+    order = _reference_order(model, optimizer)
+    if len(ref_sd["param_groups"]) != len(order):
+        raise ValueError("optimizer state has %d parameter groups, the model has %d trainable parameters"
+                         % (len(ref_sd["param_groups"]), len(order)))
+    ours = optimizer.state_dict()
+    state, seen = {}, set()
+    for ref_idx, loc in enumerate(order):
+        if loc is None:
+            continue
+        rg = ref_sd["param_groups"][ref_idx]
+        if loc[0] not in seen:
+            seen.add(loc[0])
+            for k, v in rg.items():
+                if k not in ("params", "fused", "foreach"):
+                    ours["param_groups"][loc[0]][k] = v
+        if ref_idx in ref_sd["state"]:
+            state[loc[1]] = ref_sd["state"][ref_idx]
+    ours["state"] = state
+    return ours
+
+
+def _scheduler_state(sd, pick):
+    """Per-group lists of an LR scheduler's state (base_lrs, _last_lr, lr_lambdas) re-indexed by `pick`."""
+    out = dict(sd)
+    for k in ("base_lrs", "_last_lr", "lr_lambdas"):
+        if isinstance(out.get(k), (list, tuple)):
+            out[k] = [out[k][i] for i in pick]
+    return out
+
+
 def checkpoint_state(model, optimizer=None, scheduler=None, **extra):
     """Checkpoint dict in the reference's layout (DGDE/utils/check_point.py:31-43): {'model', 'optimizer', 'scheduler'} plus
-    the trainer's extras ('iteration', 'iter_per_epoch', DGDE/engine/trainer.py:167-171).  The model's state-dict keys equal the
-    reference's, so files written by either side load into the other."""
+    the trainer's extras ('iteration', 'iter_per_epoch', DGDE/engine/trainer.py:167-171).  State-dict keys of the model equal
+    the reference's; the optimizer and scheduler entries are converted to the reference's one-group-per-parameter layout, so a
+    file written here resumes there (SOLVER.LOAD_OPTIMIZER_SCHEDULER) and the other way round."""
     m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
     data = {"model": m.state_dict()}
     if optimizer is not None:
-        data["optimizer"] = optimizer.state_dict()
+        data["optimizer"] = optimizer_state_to_reference(model, optimizer)
     if scheduler is not None and hasattr(scheduler, "state_dict"):
-        data["scheduler"] = scheduler.state_dict()
+        sd = scheduler.state_dict()
+        if optimizer is not None:
+            order = _reference_order(model, optimizer)
+            sd = _scheduler_state(sd, [0 if loc is None else loc[0] for loc in order])
+        data["scheduler"] = sd
     data.update(extra)
     return data
 
 
 def load_checkpoint_state(data, model, optimizer=None, scheduler=None):
-    """Inverse of checkpoint_state; returns the extras (iteration, iter_per_epoch, ...)."""
+    """Inverse of checkpoint_state; accepts files written by the reference (per-parameter groups).  Returns the extras
+    (iteration, iter_per_epoch, ...)."""
     m = model.module if isinstance(model, nn.parallel.DistributedDataParallel) else model
     data = dict(data)
     m.load_state_dict(data.pop("model"))
     if optimizer is not None and "optimizer" in data:
-        optimizer.load_state_dict(data.pop("optimizer"))
+        optimizer.load_state_dict(optimizer_state_from_reference(data.pop("optimizer"), model, optimizer))
     if scheduler is not None and "scheduler" in data:
-        scheduler.load_state_dict(data.pop("scheduler"))
+        sd = data.pop("scheduler")
+        if optimizer is not None:
+            order = _reference_order(model, optimizer)
+            first = {}
+            for ref_idx, loc in enumerate(order):
+                if loc is not None:
+                    first.setdefault(loc[0], ref_idx)
+            sd = _scheduler_state(sd, [first[g] for g in range(len(optimizer.param_groups))])
+        scheduler.load_state_dict(sd)
     return data
 
 
@@ -158,6 +245,18 @@ def clip_grad_norm(params, max_norm):
     return total
 
 
+def guard_nonfinite_step(optimizer, total_norm):
+    """A batch without a single annotated object (or any other source of Inf/NaN) must not reach the weights; the reference
+    stops with an exception there (its num_reg_3D guard is followed by an UnboundLocalError).  On the GPU the fused AdamW
+    kernel takes a device flag (`found_inf`, the GradScaler hook) and skips the whole update when it is set -- no host sync,
+    no extra launch; the log dict still raises when somebody reads it.  On the host we simply raise."""
+    if total_norm.is_cuda:
+        if optimizer.defaults.get("fused"):
+            optimizer.found_inf = (~torch.isfinite(total_norm)).to(torch.float32).reshape(())
+    elif not bool(torch.isfinite(total_norm)):
+        raise FloatingPointError("non-finite gradient norm: %r" % float(total_norm))
+
+
 def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler=None, iteration=None):
     """One optimisation step; returns (loss_dict, log_loss_dict)."""
     optimizer.zero_grad(set_to_none=True)        # before the forward: nothing on the host between the loss and its backward
@@ -167,7 +266,7 @@ def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler
         losses = sum(loss_dict.values())
     losses.backward()
     if grad_norm_clip and grad_norm_clip > 0:
-        clip_grad_norm(_parameters_of(model), grad_norm_clip)
+        guard_nonfinite_step(optimizer, clip_grad_norm(_parameters_of(model), grad_norm_clip))
     optimizer.step()
     if scheduler is not None:
         scheduler.step(iteration) if iteration is not None else scheduler.step()

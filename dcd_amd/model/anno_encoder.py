@@ -16,38 +16,38 @@ from dcd_amd import ops
 PI = np.pi
 
 
+# attribute <- cfg path (the names anno_encoder.py:14-50 reads); tensors are listed separately below
+_CFG_ATTRS = {
+    "min_radius": "DATASETS.MIN_RADIUS", "max_radius": "DATASETS.MAX_RADIUS", "center_ratio": "DATASETS.CENTER_RADIUS_RATIO",
+    "target_center_mode": "INPUT.HEATMAP_CENTER", "orien_bin_size": "INPUT.ORIENTATION_BIN_SIZE",
+    "center_mode": "MODEL.HEAD.CENTER_MODE", "depth_mode": "MODEL.HEAD.DEPTH_MODE", "depth_range": "MODEL.HEAD.DEPTH_RANGE",
+    "scale_depth_by_focal_lengths_factor": "MODEL.HEAD.SCALE_DEPTH_BY_FOCAL_LENGTHS_FACTOR",
+    "dim_modes": "MODEL.HEAD.DIMENSION_REG", "down_ratio": "MODEL.BACKBONE.DOWN_RATIO", "fp16": "MODEL.FP16",
+}
+_CFG_TENSORS = {"depth_ref": "MODEL.HEAD.DEPTH_REFERENCE", "dim_mean": "MODEL.HEAD.DIMENSION_MEAN",
+                "dim_std": "MODEL.HEAD.DIMENSION_STD"}
+
+
+def _cfg_get(cfg, path):
+    for part in path.split("."):
+        cfg = getattr(cfg, part)
+    return cfg
+
+
 class Anno_Encoder():
+    INF = 100000000
+    EPS = 1e-3
+
     def __init__(self, cfg):
-        device = cfg.MODEL.DEVICE
-        self.device = device
-        self.INF = 100000000
-        self.EPS = 1e-3
-
+        self.device = device = cfg.MODEL.DEVICE
+        for attr, path in _CFG_ATTRS.items():
+            setattr(self, attr, _cfg_get(cfg, path))
+        for attr, path in _CFG_TENSORS.items():
+            setattr(self, attr, torch.as_tensor(_cfg_get(cfg, path)).to(device=device))
         self.num_cls = len(cfg.DATASETS.DETECT_CLASSES)
-        self.min_radius = cfg.DATASETS.MIN_RADIUS
-        self.max_radius = cfg.DATASETS.MAX_RADIUS
-        self.center_ratio = cfg.DATASETS.CENTER_RADIUS_RATIO
-        self.target_center_mode = cfg.INPUT.HEATMAP_CENTER
-        self.center_mode = cfg.MODEL.HEAD.CENTER_MODE
-
-        self.depth_mode = cfg.MODEL.HEAD.DEPTH_MODE
-        self.depth_range = cfg.MODEL.HEAD.DEPTH_RANGE
-        self.depth_ref = torch.as_tensor(cfg.MODEL.HEAD.DEPTH_REFERENCE).to(device=device)
-        self.scale_depth_by_focal_lengths_factor = cfg.MODEL.HEAD.SCALE_DEPTH_BY_FOCAL_LENGTHS_FACTOR
-
-        self.dim_mean = torch.as_tensor(cfg.MODEL.HEAD.DIMENSION_MEAN).to(device=device)
-        self.dim_std = torch.as_tensor(cfg.MODEL.HEAD.DIMENSION_STD).to(device=device)
-        self.dim_modes = cfg.MODEL.HEAD.DIMENSION_REG
-
+        self.multibin = cfg.INPUT.ORIENTATION == 'multi-bin'
+        self.offset_mean, self.offset_std = cfg.MODEL.HEAD.REGRESSION_OFFSET_STAT[:2]
         self.alpha_centers = torch.tensor([0, PI / 2, PI, - PI / 2]).to(device=device)
-        self.fp16 = cfg.MODEL.FP16
-        self.multibin = (cfg.INPUT.ORIENTATION == 'multi-bin')
-        self.orien_bin_size = cfg.INPUT.ORIENTATION_BIN_SIZE
-
-        self.offset_mean = cfg.MODEL.HEAD.REGRESSION_OFFSET_STAT[0]
-        self.offset_std = cfg.MODEL.HEAD.REGRESSION_OFFSET_STAT[1]
-        self.down_ratio = cfg.MODEL.BACKBONE.DOWN_RATIO
-
         # box corner signs: x uses l/2, y uses h/2, z uses w/2 (the gather table of anno_encoder.py:119-123)
         self._corner_sign = torch.tensor([[-1, -1, 1, 1, -1, -1, 1, 1],
                                           [1, 1, 1, 1, -1, -1, -1, -1],
@@ -56,12 +56,14 @@ class Anno_Encoder():
 
     # ------------------------------------------------------------------------------------------
     def _calib_table(self, calibs, device):
-        """(len(calibs), 6) float32 rows [c_u, c_v, f_u, f_v, b_x, b_y]; cached for the last list seen."""
+        """(len(calibs), 6) float32 rows [c_u, c_v, f_u, f_v, b_x, b_y]; cached for the last VALUES seen.  The key is the
+        intrinsics themselves, not object identity: a data loader builds new Calibration objects every batch and CPython
+        reuses freed addresses, so id()-keys would hand a stale table to the next batch."""
         if torch.is_tensor(calibs):                              # already a table (graph-captured loss)
             return calibs
-        key = (tuple(id(c) for c in calibs), str(device))      # the LIST is rebuilt every step, the Calibration objects are not
+        rows = tuple((float(c.c_u), float(c.c_v), float(c.f_u), float(c.f_v), float(c.b_x), float(c.b_y)) for c in calibs)
+        key = (rows, str(device))
         if self._calib_cache[0] != key:
-            rows = [[float(c.c_u), float(c.c_v), float(c.f_u), float(c.f_v), float(c.b_x), float(c.b_y)] for c in calibs]
             self._calib_cache = (key, torch.tensor(rows, dtype=torch.float32, device=device))
         return self._calib_cache[1]
 

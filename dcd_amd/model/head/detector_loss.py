@@ -12,6 +12,8 @@ What changed is how it executes on the GPU:
 Reference quirk kept on purpose: the pair mask comes from the top-1500 ordering of the TARGET 2-D keypoints while
 `pairs_kpt_depths_all` is ordered by the PREDICTED ones (:378 vs :381), and they are combined elementwise (:188-204).
 """
+import os
+
 import torch
 from torch.nn import functional as F
 
@@ -28,76 +30,63 @@ def make_loss_evaluator(cfg):
     return Loss_Computation(cfg=cfg)
 
 
+# Everything `Loss_Computation` reads from the config, as tables (the reference assigns them one by one,
+# detector_loss.py:24-98): attribute <- cfg path.
+_HEAD = "MODEL.HEAD."
+_CFG_ATTRS = {
+    "max_objs": "DATASETS.MAX_OBJECTS", "orien_bin_size": "INPUT.ORIENTATION_BIN_SIZE", "fp16": "MODEL.FP16",
+    "batch_weight_factor": "MODEL.BATCH_WEIGHT_FACTOR", "is_gen": "TEST.GENERATE_GMW",
+    "center_sample": _HEAD + "CENTER_SAMPLE", "regress_area": _HEAD + "REGRESSION_AREA", "heatmap_type": _HEAD + "HEATMAP_TYPE",
+    "corner_depth_sp": _HEAD + "SUPERVISE_CORNER_DEPTH", "loss_keys": _HEAD + "LOSS_NAMES",
+    "uncertainty_range": _HEAD + "UNCERTAINTY_RANGE", "trunc_offset_loss_type": _HEAD + "TRUNCATION_OFFSET_LOSS",
+    "uncertainty_weight": _HEAD + "UNCERTAINTY_WEIGHT", "keypoint_xy_weights": _HEAD + "KEYPOINT_XY_WEIGHT",
+    "keypoint_norm_factor": _HEAD + "KEYPOINT_NORM_FACTOR", "extra_kpts_num": _HEAD + "EXTRA_KPTS_NUM",
+    "modify_invalid_keypoint_depths": _HEAD + "MODIFY_INVALID_KEYPOINT_DEPTH", "corner_loss_depth": _HEAD + "CORNER_LOSS_DEPTH",
+}
+# flag <- name that must appear in MODEL.HEAD.LOSS_NAMES / in the regression-head channel map
+_LOSS_FLAGS = {"compute_direct_depth_loss": "depth_loss", "compute_keypoint_depth_loss": "keypoint_depth_loss",
+               "compute_pairs_kpts_depth_loss": "pairs_kpts_depth_loss", "compute_weighted_depth_loss": "weighted_avg_depth_loss",
+               "compute_corner_loss": "corner_loss", "separate_trunc_offset": "trunc_offset_loss"}
+_HEAD_FLAGS = {"pred_direct_depth": "depth", "depth_with_uncertainty": "depth_uncertainty", "compute_keypoint_corner": "corner_offset",
+               "compute_extra_kpts_corner": "extra_kpts_2d", "corner_with_uncertainty": "corner_uncertainty"}
+_DEPTH_LOSSES = {"berhu": Berhu_Loss, "inv_sig": Inverse_Sigmoid_Loss, "log": Log_L1_Loss, "L1": lambda: F.l1_loss}
+
+
 class Loss_Computation():
+    eps = 1e-5
+
     def __init__(self, cfg):
+        head = cfg.MODEL.HEAD
+        for attr, path in _CFG_ATTRS.items():
+            node = cfg
+            for part in path.split("."):
+                node = getattr(node, part)
+            setattr(self, attr, node)
         self.anno_encoder = Anno_Encoder(cfg)
-        self.key2channel = Converter_key2channel(keys=cfg.MODEL.HEAD.REGRESSION_HEADS,
-                                                 channels=cfg.MODEL.HEAD.REGRESSION_CHANNELS)
-        self.max_objs = cfg.DATASETS.MAX_OBJECTS
-        self.center_sample = cfg.MODEL.HEAD.CENTER_SAMPLE
-        self.regress_area = cfg.MODEL.HEAD.REGRESSION_AREA
-        self.heatmap_type = cfg.MODEL.HEAD.HEATMAP_TYPE
-        self.corner_depth_sp = cfg.MODEL.HEAD.SUPERVISE_CORNER_DEPTH
-        self.loss_keys = cfg.MODEL.HEAD.LOSS_NAMES
+        self.key2channel = Converter_key2channel(keys=head.REGRESSION_HEADS, channels=head.REGRESSION_CHANNELS)
+        for flag, name in _LOSS_FLAGS.items():
+            setattr(self, flag, name in self.loss_keys)
+        for flag, name in _HEAD_FLAGS.items():
+            setattr(self, flag, name in self.key2channel.keys)
         self.world_size = get_world_size()
-        self.dim_weight = torch.as_tensor(cfg.MODEL.HEAD.DIMENSION_WEIGHT).view(1, 3)
-        self.uncertainty_range = cfg.MODEL.HEAD.UNCERTAINTY_RANGE
+        self.multibin = cfg.INPUT.ORIENTATION == 'multi-bin'
+        self.dim_weight = torch.as_tensor(head.DIMENSION_WEIGHT).view(1, 3)
+        self.loss_weights = dict(zip(head.LOSS_NAMES, head.INIT_LOSS_WEIGHT))
 
-        loss_types = cfg.MODEL.HEAD.LOSS_TYPE
-        self.cls_loss_fnc = FocalLoss(cfg.MODEL.HEAD.LOSS_PENALTY_ALPHA, cfg.MODEL.HEAD.LOSS_BETA, cfg=cfg)
-        self.iou_loss = IOULoss(loss_type=loss_types[2])
-        if loss_types[3] == 'berhu':
-            self.depth_loss = Berhu_Loss()
-        elif loss_types[3] == 'inv_sig':
-            self.depth_loss = Inverse_Sigmoid_Loss()
-        elif loss_types[3] == 'log':
-            self.depth_loss = Log_L1_Loss()
-        elif loss_types[3] == 'L1':
-            self.depth_loss = F.l1_loss
-        else:
-            raise ValueError
-
-        self.reg_loss = loss_types[1]
-        self.reg_loss_fnc = F.l1_loss if loss_types[1] == 'L1' else F.smooth_l1_loss
-        self.keypoint_loss_fnc = F.l1_loss
+        # LOSS_TYPE = [heat-map, regression, 2-D box, depth]
+        _, self.reg_loss, box_loss, depth_loss = head.LOSS_TYPE[:4]
+        if depth_loss not in _DEPTH_LOSSES:
+            raise ValueError("MODEL.HEAD.LOSS_TYPE[3] = %r" % (depth_loss,))
+        self.cls_loss_fnc = FocalLoss(head.LOSS_PENALTY_ALPHA, head.LOSS_BETA, cfg=cfg)
+        self.iou_loss = IOULoss(loss_type=box_loss)
+        self.depth_loss = _DEPTH_LOSSES[depth_loss]()
+        self.reg_loss_fnc = F.l1_loss if self.reg_loss == 'L1' else F.smooth_l1_loss
+        self.keypoint_loss_fnc = self.extra_kpts_3d_loss_fnc = F.l1_loss
         self.extra_kpts_2d_loss_fnc = RegWeightedL1Loss()
-        self.extra_kpts_3d_loss_fnc = F.l1_loss
 
-        self.multibin = (cfg.INPUT.ORIENTATION == 'multi-bin')
-        self.orien_bin_size = cfg.INPUT.ORIENTATION_BIN_SIZE
-        self.trunc_offset_loss_type = cfg.MODEL.HEAD.TRUNCATION_OFFSET_LOSS
-
-        self.loss_weights = dict(zip(cfg.MODEL.HEAD.LOSS_NAMES, cfg.MODEL.HEAD.INIT_LOSS_WEIGHT))
-
-        self.compute_direct_depth_loss = 'depth_loss' in self.loss_keys
-        self.compute_keypoint_depth_loss = 'keypoint_depth_loss' in self.loss_keys
-        self.compute_pairs_kpts_depth_loss = 'pairs_kpts_depth_loss' in self.loss_keys
-        self.compute_weighted_depth_loss = 'weighted_avg_depth_loss' in self.loss_keys
-        self.compute_corner_loss = 'corner_loss' in self.loss_keys
-        self.separate_trunc_offset = 'trunc_offset_loss' in self.loss_keys
-
-        self.pred_direct_depth = 'depth' in self.key2channel.keys
-        self.depth_with_uncertainty = 'depth_uncertainty' in self.key2channel.keys
-        self.compute_keypoint_corner = 'corner_offset' in self.key2channel.keys
-        self.compute_extra_kpts_corner = 'extra_kpts_2d' in self.key2channel.keys
-        self.corner_with_uncertainty = 'corner_uncertainty' in self.key2channel.keys
-
-        self.uncertainty_weight = cfg.MODEL.HEAD.UNCERTAINTY_WEIGHT
-        self.keypoint_xy_weights = cfg.MODEL.HEAD.KEYPOINT_XY_WEIGHT
-        self.keypoint_norm_factor = cfg.MODEL.HEAD.KEYPOINT_NORM_FACTOR
-        self.modify_invalid_keypoint_depths = cfg.MODEL.HEAD.MODIFY_INVALID_KEYPOINT_DEPTH
-        self.extra_kpts_num = cfg.MODEL.HEAD.EXTRA_KPTS_NUM
-
-        self.fp16 = cfg.MODEL.FP16
-        self.batch_weight_factor = cfg.MODEL.BATCH_WEIGHT_FACTOR
-        self.corner_loss_depth = cfg.MODEL.HEAD.CORNER_LOSS_DEPTH
-        self.eps = 1e-5
-        self.is_gen = cfg.TEST.GENERATE_GMW
-        import os
         self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
         self._graphs = {}                      # input-shape key -> (graphed callable, {'loss_keys', 'log_names'})
-        self.gen_data = {'kpts_2d': [], 'kpts_3d': [], 'pred_rot': [], 'gt_location': [], 'pred_location': [],
-                         'weight_img': [], 'img_idx': []}
+        self.gen_data = {k: [] for k in ('kpts_2d', 'kpts_3d', 'pred_rot', 'gt_location', 'pred_location', 'weight_img', 'img_idx')}
 
     # ------------------------------------------------------------------------------------------
     def prepare_targets(self, targets):

@@ -5,8 +5,9 @@ DGDE/model/backbone/dla_dcn.py:17-18), so checkpoints are interchangeable.  `for
 `act(bn(x) + residual)` with `act` = ReLU when `fuse_relu` is set.  Where the reference has `[BN, ReLU]` inside an
 `nn.Sequential`, the ReLU slot is kept as `nn.Identity()` so module indices (and therefore keys) do not move.
 
-Device tensors always take the HIP kernels (and raise if libdcd_hip.so is missing).  CPU tensors -- the CPU test
-suite and the gloo DDP tests -- run the stock torch ops the reference itself uses.
+Device tensors always take the HIP kernels (and raise if libdcd_hip.so is missing).  CPU tensors (the host-logic tests)
+run `torch.nn.BatchNorm2d.forward`, the very op the reference calls; synchronised statistics exist on the device only --
+the world-size-2 gloo tests plug their own torch restatement into `BatchNorm2d.host_sync_stats` (tests/cpu_syncbn.py).
 `sync_group`: set by `engine.trainer.wrap_distributed` when MODEL.USE_SYNC_BN; statistics are then all-reduced.
 """
 import torch
@@ -14,42 +15,6 @@ from torch import nn
 from torch.nn import functional as F
 
 from dcd_amd import ops
-
-
-class _SyncStatsCPU(torch.autograd.Function):
-    """SyncBN on CPU tensors over gloo (torch's SyncBatchNorm is GPU-only): the same two-phase scheme as the HIP path,
-    written with torch ops.  Test infrastructure for the world-size-2 CPU tests."""
-
-    @staticmethod
-    def forward(ctx, x, weight, bias, eps, group):
-        import torch.distributed as dist
-        dims = [0] + list(range(2, x.dim()))
-        xd = x.double()
-        stats = torch.stack((xd.sum(dims), (xd * xd).sum(dims)), 1)
-        dist.all_reduce(stats, group=group)
-        count = x.numel() // x.shape[1] * dist.get_world_size(group)
-        mean = stats[:, 0] / count
-        var = (stats[:, 1] / count - mean * mean).clamp_min(0)
-        invstd = (var + eps).rsqrt()
-        shape = [1, -1] + [1] * (x.dim() - 2)
-        xhat = ((xd - mean.view(shape)) * invstd.view(shape)).float()
-        ctx.save_for_backward(xhat, weight, invstd.float())
-        ctx.group, ctx.count = group, count
-        ctx.mark_non_differentiable(mean, var)
-        return xhat * weight.view(shape) + bias.view(shape), mean, var
-
-    @staticmethod
-    def backward(ctx, gy, _gm, _gv):
-        import torch.distributed as dist
-        xhat, weight, invstd = ctx.saved_tensors
-        dims = [0] + list(range(2, gy.dim()))
-        shape = [1, -1] + [1] * (gy.dim() - 2)
-        sums = torch.stack((gy.double().sum(dims), (gy.double() * xhat.double()).sum(dims)), 1)
-        gw, gb = sums[:, 1].float(), sums[:, 0].float()
-        dist.all_reduce(sums, group=ctx.group)
-        m = (sums / ctx.count).float()
-        gx = (gy - m[:, 0].view(shape) - xhat * m[:, 1].view(shape)) * (invstd * weight).view(shape)
-        return gx, gw, gb, None, None
 
 
 class BatchNorm2d(nn.BatchNorm2d):
@@ -61,9 +26,13 @@ class BatchNorm2d(nn.BatchNorm2d):
     def extra_repr(self):
         return super().extra_repr() + ", fuse_relu={}".format(self.fuse_relu)
 
+    host_sync_stats = None      # test hook: f(x, weight, bias, eps, group) -> (y, mean, var); never set by product code
+
     def _stock(self, x, residual):
         if self.training and self.sync_group is not None:
-            y, mean, var = _SyncStatsCPU.apply(x, self.weight, self.bias, self.eps, self.sync_group)
+            if self.host_sync_stats is None:
+                raise RuntimeError("synchronised BatchNorm2d needs device tensors (the statistics exchange is a HIP + RCCL path)")
+            y, mean, var = self.host_sync_stats(x, self.weight, self.bias, self.eps, self.sync_group)
             with torch.no_grad():
                 n = x.numel() // x.shape[1] * torch.distributed.get_world_size(self.sync_group)
                 self.running_mean.mul_(1 - self.momentum).add_(mean.float(), alpha=self.momentum)

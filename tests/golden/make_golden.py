@@ -253,20 +253,37 @@ def golden_solver():
     sched, warm = build_scheduler(opt, 100, cfg.SOLVER)
     x = torch.linspace(-1, 1, 24).reshape(4, 6)
     lrs_w, lrs_b = [], []
+    import copy
+    snap = {}
     for it in range(3000):
-        if it < 3:
+        if it < 4:
+            if it == 3:       # the state a checkpoint written after iteration 2 holds (utils/check_point.py:31-43)
+                snap = {"opt": copy.deepcopy(opt.state_dict()), "sched": {k: v for k, v in sched.state_dict().items() if k != "lr_lambdas"},
+                        "p3": np.concatenate([p.detach().numpy().ravel() for p in net.parameters()])}
             opt.zero_grad()
             net(x).square().sum().backward()
             opt.step()
+            if it == 3:
+                snap["p4"] = np.concatenate([p.detach().numpy().ravel() for p in net.parameters()])
         if it < cfg.SOLVER.WARMUP_STEPS:
             warm.step(it)
         else:
             sched.step(it)
         lrs_w.append(opt.param_groups[0]["lr"])      # first parameter is a weight, second a bias
         lrs_b.append(opt.param_groups[1]["lr"])
+    osd = snap["opt"]
+    n = len(osd["param_groups"])
     save("solver", lr_weight=np.array(lrs_w), lr_bias=np.array(lrs_b),
-         params_after_3_steps=np.concatenate([p.detach().numpy().ravel() for p in net.parameters()]),
-         n_groups=np.array(len(opt.param_groups)))
+         params_after_3_steps=snap["p3"], params_after_4_steps=snap["p4"], n_groups=np.array(n),
+         ckpt_group_lr=np.array([g["lr"] for g in osd["param_groups"]]),
+         ckpt_group_initial_lr=np.array([g["initial_lr"] for g in osd["param_groups"]]),
+         ckpt_group_params=np.array([g["params"] for g in osd["param_groups"]]),
+         ckpt_group_wd=np.array([g["weight_decay"] for g in osd["param_groups"]]),
+         ckpt_step=np.array([float(osd["state"][i]["step"]) for i in range(n)]),
+         ckpt_sched_base_lrs=np.array(snap["sched"]["base_lrs"]), ckpt_sched_last_lr=np.array(snap["sched"]["_last_lr"]),
+         ckpt_sched_last_epoch=np.array(snap["sched"]["last_epoch"]),
+         **{"ckpt_exp_avg_%d" % i: osd["state"][i]["exp_avg"].numpy() for i in range(n)},
+         **{"ckpt_exp_avg_sq_%d" % i: osd["state"][i]["exp_avg_sq"].numpy() for i in range(n)})
 
 
 def golden_config():

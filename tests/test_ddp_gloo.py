@@ -88,7 +88,10 @@ def _syncbn_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
     torch.set_num_threads(2)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    import cpu_syncbn
     from dcd_amd.model.layers.norm import BatchNorm2d
+    cpu_syncbn.install()
     dist.init_process_group("gloo", rank=rank, world_size=world)
     g = torch.Generator().manual_seed(5)
     x = torch.randn(4, 6, 5, 7, generator=g) * 2 + 1

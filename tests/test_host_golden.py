@@ -245,6 +245,93 @@ def test_solver_schedule_and_step_match_reference(tmp_path):
     assert opt2.param_groups[0]["lr"] == opt.param_groups[0]["lr"]
 
 
+def _reference_checkpoint_from_fixture(g, net):
+    """The 'optimizer' / 'scheduler' entries a reference checkpoint holds after iteration 2 (one group per parameter), rebuilt
+    from tests/golden/solver.npz -- the values were saved by the reference's own solver package (make_golden.golden_solver)."""
+    n = int(g["n_groups"])
+    groups = [{"lr": float(g["ckpt_group_lr"][i]), "betas": (0.9, 0.99), "eps": 1e-8, "weight_decay": float(g["ckpt_group_wd"][i]),
+               "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False, "fused": None,
+               "decoupled_weight_decay": True, "initial_lr": float(g["ckpt_group_initial_lr"][i]),
+               "params": [int(v) for v in g["ckpt_group_params"][i]]} for i in range(n)]
+    state = {i: {"step": torch.tensor(float(g["ckpt_step"][i])), "exp_avg": torch.from_numpy(g["ckpt_exp_avg_%d" % i].copy()),
+                 "exp_avg_sq": torch.from_numpy(g["ckpt_exp_avg_sq_%d" % i].copy())} for i in range(n)}
+    sched = {"base_lrs": list(map(float, g["ckpt_sched_base_lrs"])), "last_epoch": int(g["ckpt_sched_last_epoch"]),
+             "_last_lr": list(map(float, g["ckpt_sched_last_lr"])), "_step_count": 1, "_is_initial": False, "lr_lambdas": [None] * n}
+    flat = torch.from_numpy(g["params_after_3_steps"].copy())
+    model_sd, o = {}, 0
+    for k, v in net.state_dict().items():
+        model_sd[k] = flat[o:o + v.numel()].reshape(v.shape).clone()
+        o += v.numel()
+    return {"model": model_sd, "optimizer": {"state": state, "param_groups": groups}, "scheduler": sched, "iteration": 2,
+            "iter_per_epoch": 100}
+
+
+def test_reference_checkpoint_resumes_here_and_ours_resumes_there():
+    """the reference saves one optimizer group per parameter (solver/__init__.py:10-25); ours pools weights and
+    biases.  A reference checkpoint must load (SOLVER.LOAD_OPTIMIZER_SCHEDULER path of utils/check_point.py) and continue to
+    the same weights, and what we write must have the reference's layout, value for value."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.engine.trainer import build_optimizer, build_scheduler, checkpoint_state, load_checkpoint_state
+    g = load("solver")
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "SOLVER.LR_WARMUP", True, "SOLVER.WARMUP_STEPS", 200,
+                        "SOLVER.MAX_ITERATION", 3000, "SOLVER.STEPS", (2000, 2600)])
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    opt = build_optimizer(net, cfg)
+    sched, _ = build_scheduler(opt, cfg)
+    ref_ckpt = _reference_checkpoint_from_fixture(g, net)
+    extra = load_checkpoint_state(ref_ckpt, net, opt, sched)
+    assert extra == {"iteration": 2, "iter_per_epoch": 100}
+    assert len(opt.param_groups) == 2 and [len(gr["params"]) for gr in opt.param_groups] == [2, 2]
+    assert opt.param_groups[0]["lr"] == float(g["ckpt_group_lr"][0]) and opt.param_groups[1]["lr"] == float(g["ckpt_group_lr"][1])
+    # (a) the reference's 4th step, taken by our optimizer from the loaded state
+    x = torch.linspace(-1, 1, 24).reshape(4, 6)
+    opt.zero_grad()
+    net(x).square().sum().backward()
+    opt.step()
+    got = np.concatenate([p.detach().numpy().ravel() for p in net.parameters()])
+    np.testing.assert_allclose(got, g["params_after_4_steps"], rtol=2e-6, atol=1e-7)
+    # (b) what we write has the reference's layout: reload the fixture state, write it back out, compare entry by entry
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
+    opt2 = build_optimizer(net2, cfg)
+    sched2, _ = build_scheduler(opt2, cfg)
+    load_checkpoint_state(_reference_checkpoint_from_fixture(g, net2), net2, opt2, sched2)
+    out = checkpoint_state(net2, opt2, sched2, iteration=2, iter_per_epoch=100)
+    n = int(g["n_groups"])
+    assert len(out["optimizer"]["param_groups"]) == n
+    for i, gr in enumerate(out["optimizer"]["param_groups"]):
+        assert gr["params"] == [int(v) for v in g["ckpt_group_params"][i]]
+        assert gr["lr"] == float(g["ckpt_group_lr"][i]) and gr["initial_lr"] == float(g["ckpt_group_initial_lr"][i])
+        assert gr["weight_decay"] == float(g["ckpt_group_wd"][i]) and tuple(gr["betas"]) == (0.9, 0.99)
+        st = out["optimizer"]["state"][i]
+        assert float(st["step"]) == float(g["ckpt_step"][i])
+        np.testing.assert_array_equal(st["exp_avg"].numpy(), g["ckpt_exp_avg_%d" % i])
+        np.testing.assert_array_equal(st["exp_avg_sq"].numpy(), g["ckpt_exp_avg_sq_%d" % i])
+    assert out["scheduler"]["base_lrs"] == list(map(float, g["ckpt_sched_base_lrs"]))
+    assert out["scheduler"]["_last_lr"] == list(map(float, g["ckpt_sched_last_lr"]))
+    # (c) a stock per-parameter AdamW (the reference's construction) loads our 'optimizer' entry as it is
+    ref_like = torch.optim.AdamW([{"params": [p], "lr": 1.0} for p in net2.parameters()], betas=(0.9, 0.99))
+    ref_like.load_state_dict(out["optimizer"])
+    assert [gr["lr"] for gr in ref_like.param_groups] == [float(v) for v in g["ckpt_group_lr"]]
+
+
+def test_calibration_table_follows_values_not_object_identity():
+    """a loader builds new Calibration objects per batch and CPython recycles their addresses; the cached device
+    table must follow the intrinsics."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.model.anno_encoder import Anno_Encoder
+
+    class Calib:
+        def __init__(self, f):
+            self.c_u, self.c_v, self.f_u, self.f_v, self.b_x, self.b_y = 600.0, 170.0, f, f, 0.06, 0.0003
+    enc = Anno_Encoder(get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu"]))
+    seen = []
+    for f in (700.0, 710.0, 720.0, 730.0):
+        batch = [Calib(f)]
+        seen.append(float(enc._calib_table(batch, torch.device("cpu"))[0, 2]))
+        del batch
+    assert seen == [700.0, 710.0, 720.0, 730.0]
+
+
 def test_whole_model_matches_reference(cpu_backend):
     check_model(torch.device("cpu"), 2e-4, 2e-3)
 
