@@ -85,7 +85,8 @@ def build_everything(args, device, world, local_rank):
 
     _ext.set_precision(args.precision)
     force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
-    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1 or force_ddp])
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1 or force_ddp,
+                        "MODEL.FP16", bool(args.amp)])
     torch.manual_seed(0)
     model = KeypointDetector(cfg)
     init_like_trained(model, std=0.01, seed=0)
@@ -144,6 +145,7 @@ def run_gpu(args):
         elapsed = float(t.item())
 
     global_batch = per_rank * world
+    prec = "bf16x3" if args.amp else args.precision          # MODEL.FP16 routes every DCN call to the split kernels
     dcn_ms = timer.total_ms() / max(args.steps, 1)                      # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
     out = None
@@ -152,18 +154,19 @@ def run_gpu(args):
             "metric": "images/sec DGDE train step (bs=8, 384x1280)", "value": global_batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-            "config": {"workload": "DGDE train bs=%d fp32 on %dxMI355X, synthetic KITTI 384x1280 + random kpts_ann "
-                                   "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (global_batch, world, args.objects),
+            "vs_baseline": None, "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
+            "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI 384x1280 + random kpts_ann "
+                                   "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
+                                       global_batch, "bf16 autocast (MODEL.FP16)" if args.amp else "fp32", world, args.objects),
                        "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
-                       "parallelism": "dp%d" % world, "dcn_precision": args.precision,
+                       "parallelism": "dp%d" % world, "dcn_precision": prec,
                        "sync_bn": bool(world > 1)},
             # The fused op has 196 FLOP per algorithmic byte (ridge of the part: 157.3 TF / 8 TB/s = 19.7), so the matrix pipe
             # is the bound that applies; the HBM view north_star also asks for is kept beside it.
             "roofline": {"bound": "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers, batch %d per GPU" % per_rank,
                          "achieved": fl / 1e12 / (dcn_ms / 1e3) if dcn_ms > 0 else None,
-                         "peak": MFMA_PEAK_TFLOPS[args.precision], "unit": "TFLOP/s",
-                         "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[args.precision] if dcn_ms > 0 else None,
+                         "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
+                         "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
                          "traffic": load_traffic(per_rank), "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
                          "calls_per_step": len(timer.pairs) // max(args.steps, 1)},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
@@ -413,7 +416,10 @@ def main():
     ap.add_argument("--batch", type=int, default=8, help="global batch (strong) or per-GPU batch (weak)")
     ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
     ap.add_argument("--objects", type=int, default=6)
-    ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32")
+    ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
+                    help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")
+    ap.add_argument("--amp", action="store_true", help="MODEL.FP16: bf16 autocast around the backbone + split-bf16 DCN "
+                                                        "(BASELINE config 3: --gpus 4 --batch 32 --amp)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-timeout", type=int, default=420)

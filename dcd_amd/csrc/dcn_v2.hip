@@ -1956,6 +1956,8 @@ inline int pick_mb(int nb, int tiles_total)
     return 1;
 }
 
+#include "dcn_v2_bf16x3.inc"
+
 }  // namespace
 
 extern "C" {
@@ -1989,7 +1991,10 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     Geom g;
     if (!input || !weight || !bias || !offset || !mask || !output || !workspace) return DCD_ERR_BAD_ARG;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
-    if (precision != DCD_PREC_F32) return DCD_ERR_BAD_ARG;
+    // DCD_PREC_BF16X3 permits (does not oblige) the split-bf16 contraction: the workgroup-tiled kernels have it, every other
+    // geometry runs the exact fp32 kernels, which are inside any tolerance the split form is
+    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3) return DCD_ERR_BAD_ARG;
+    const bool split = precision == DCD_PREC_BF16X3;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
     float *wf = (float *)workspace, *wb = wf + nw;
@@ -2002,10 +2007,11 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     // workgroup-tiled LDS kernel: the DLA-34 shape (3x3, stride 1, pad 1, dil 1, dg 1); maps of at least 16 rows
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
         H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr) {
-        const int nchunk = (Cin + TL_CH - 1) / TL_CH, nz = (Cout + TL_OB - 1) / TL_OB;
-        const size_t nwl = (size_t)nz * nchunk * TL_W_FLOATS;
+        const int nz = (Cout + TL_OB - 1) / TL_OB;
+        const int nchunk = split ? (Cin + TB_CH - 1) / TB_CH : (Cin + TL_CH - 1) / TL_CH;
+        const size_t nwl = (size_t)nz * nchunk * (split ? TB_W_FLOATS : TL_W_FLOATS);
         if (nwl <= 2 * nw) {                                          // Wl lives in the [Wf | Wb] area
-            static LdsLimit lds_limit8, lds_limit4;
+            static LdsLimit lds_limit8, lds_limit4, lds_limit8b, lds_limit4b;
             static int tile_rows = 0;
             if (tile_rows == 0) {
                 const char *e = getenv("DCD_TILE_ROWS");
@@ -2013,6 +2019,9 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             }
             if (!lds_limit8.raise((int)(2 * TileCfg<8>::BUF * sizeof(float)), dcn_fwd_tile_f32<8>) ||
                 !lds_limit4.raise((int)(2 * TileCfg<4>::BUF * sizeof(float)), dcn_fwd_tile_f32<4>))
+                return DCD_ERR_LAUNCH;
+            if (split && (!lds_limit8b.raise((int)(TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<8>) ||
+                          !lds_limit4b.raise((int)(TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<4>)))
                 return DCD_ERR_LAUNCH;
             static int rescue_taps = 0;
             if (rescue_taps == 0) {
@@ -2032,14 +2041,28 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             const size_t n9 = (size_t)Cin * 9 * g.Cop;
             if (nwl <= nw && n9 <= nw && workspace_bytes >= 2 * nw * sizeof(float) + (size_t)nflag_words * 4) {
                 float *wf9 = wf + nw;                         // [Wl | Wf9 | flags]
-                hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
-                                   dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
+                if (split)
+                    hipLaunchKernelGGL(dcn_prep_weights_tile_bf16, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
+                                       dim3(256), 0, stream, weight, (unsigned short *)wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
+                else
+                    hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
+                                       dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
                 {
                     int gsz = (int)((ncoord + 4095) / 4096);
                     if (gsz > 512) gsz = 512;
                     hipLaunchKernelGGL(dcn_fwd_far_count, dim3(gsz), dim3(256), 0, stream, offset, ncoord, far_count);
                 }
-                if (rows8)
+                if (split && rows8)
+                    hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<8>, dim3(regions, B, nz), dim3(512),
+                                       TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
+                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps, (const unsigned *)far_count,
+                                       far_limit);
+                else if (split)
+                    hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<4>, dim3(regions, B, nz), dim3(256),
+                                       TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
+                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps, (const unsigned *)far_count,
+                                       far_limit);
+                else if (rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
                                        input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps,
                                        (const unsigned *)far_count, far_limit);
@@ -2104,7 +2127,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         !grad_weight || !grad_bias || !workspace)
         return DCD_ERR_BAD_ARG;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
-    if (precision != DCD_PREC_F32) return DCD_ERR_BAD_ARG;
+    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3) return DCD_ERR_BAD_ARG;
+    const bool split = precision == DCD_PREC_BF16X3;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes + 256 < dcd_dcn_v2_workspace_bytes(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg))
         return DCD_ERR_WORKSPACE;
@@ -2235,17 +2259,39 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     bool dw_tiled = false;
 #ifndef DCN_NO_BWD_TILE
     if (tile_shape) {
-        static LdsLimit lds_limit;
+        static LdsLimit lds_limit, lds_limit2, lds_limit2b;
         const size_t ldsb = (size_t)(DW_IN_FLOATS + DW_DY_FLOATS) * sizeof(float);
-        if (!lds_limit.raise((int)ldsb, dcn_bwd_weight_tile_f32)) return DCD_ERR_LAUNCH;
+        if (!lds_limit.raise((int)ldsb, dcn_bwd_weight_tile_f32) ||
+            !lds_limit2.raise((int)(Dw2Cfg<DCD_PREC_F32>::FLOATS * sizeof(float)), dcn_bwd_weight_tile_v2<DCD_PREC_F32>) ||
+            !lds_limit2b.raise((int)(Dw2Cfg<DCD_PREC_BF16X3>::FLOATS * sizeof(float)), dcn_bwd_weight_tile_v2<DCD_PREC_BF16X3>))
+            return DCD_ERR_LAUNCH;
+        static int dw_gen = 0;                                 // A/B: DCD_DW_GEN=1 keeps the first-generation f32 kernel
+        if (dw_gen == 0) {
+            const char *e = getenv("DCD_DW_GEN");
+            dw_gen = (e && atoi(e) == 1) ? 1 : 2;
+        }
+        static int dw_colmajor = -1;                           // A/B: DCD_DW_ORDER=0 walks the tiles row by row
+        if (dw_colmajor < 0) {
+            const char *e = getenv("DCD_DW_ORDER");
+            dw_colmajor = (e && atoi(e) == 0) ? 0 : 1;
+        }
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + DW_TR - 1) / DW_TR;
         const int ncb = (Cin + DW_CB - 1) / DW_CB, nzo = (Cout + TL_OB - 1) / TL_OB;
         const int total = B * tiles_x * tiles_y;
         int S = 512 / (ncb * nzo);
         if (S < 1) S = 1;
         if (S > total) S = total;
-        hipLaunchKernelGGL(dcn_bwd_weight_tile_f32, dim3(ncb, S, nzo), dim3(DW_NT), ldsb, stream, input, offset, mask, grad_output,
-                           dw_part, g, tiles_x, tiles_y, S, (const unsigned *)absmax);
+        if (split)
+            hipLaunchKernelGGL(dcn_bwd_weight_tile_v2<DCD_PREC_BF16X3>, dim3(ncb, S, nzo), dim3(DW_NT),
+                               Dw2Cfg<DCD_PREC_BF16X3>::FLOATS * sizeof(float), stream, input, offset, mask, grad_output, dw_part, g,
+                               tiles_x, tiles_y, S, (const unsigned *)absmax, dw_colmajor);
+        else if (dw_gen == 2)
+            hipLaunchKernelGGL(dcn_bwd_weight_tile_v2<DCD_PREC_F32>, dim3(ncb, S, nzo), dim3(DW_NT),
+                               Dw2Cfg<DCD_PREC_F32>::FLOATS * sizeof(float), stream, input, offset, mask, grad_output, dw_part, g,
+                               tiles_x, tiles_y, S, (const unsigned *)absmax, dw_colmajor);
+        else
+            hipLaunchKernelGGL(dcn_bwd_weight_tile_f32, dim3(ncb, S, nzo), dim3(DW_NT), ldsb, stream, input, offset, mask, grad_output,
+                               dw_part, g, tiles_x, tiles_y, S, (const unsigned *)absmax);
         const int nred = ncb * nzo * 2 * 32 * DW_CB * 9;
         const int rgroups = S >= 16 ? 16 : S;
         hipLaunchKernelGGL(dcn_dw_reduce, dim3((nred + 255) / 256, rgroups), dim3(256), 0, stream, dw_part, grad_weight, g, ncb, nzo, S,

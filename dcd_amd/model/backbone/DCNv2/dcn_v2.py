@@ -21,22 +21,33 @@ class _DCNv2(Function):
     `_DCNv2` (dcn_v2.py:16-54); the extension takes (input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg)."""
 
     @staticmethod
-    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, precision=None):
         kernel = tuple(weight.shape[2:4])
         ctx.geometry = (*kernel, *_pair(stride), *_pair(padding), *_pair(dilation), int(deformable_groups))
+        ctx.precision = {} if precision is None else {"precision": precision}      # None: the backend's default (exact fp32)
         ctx.save_for_backward(input, offset, mask, weight, bias)
-        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geometry)
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geometry, **ctx.precision)
 
     @staticmethod
     @once_differentiable
     def backward(ctx, grad_output):
         input, offset, mask, weight, bias = ctx.saved_tensors
-        grads = _backend.dcn_v2_backward(input.contiguous(), weight.contiguous(), bias, offset, mask, grad_output, *ctx.geometry)
+        grads = _backend.dcn_v2_backward(input.contiguous(), weight.contiguous(), bias, offset, mask, grad_output.contiguous(),
+                                         *ctx.geometry, **ctx.precision)
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = grads
-        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias) + (None,) * 4
+        return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias) + (None,) * 5
 
 
-dcn_v2_conv = _DCNv2.apply
+def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
+    """`_DCNv2.apply` with the reference's arguments.  Inside an autocast region (MODEL.FP16, DGDE/model/detector.py:34-36)
+    the op itself stays an fp32 op like the reference's (its extension reads `.data<float>()`, cuda/dcn_v2_cuda.cu:58):
+    half-precision activations are cast back to fp32 at its boundary, and the weight contraction may then take the split-bf16
+    matrix path (DCD_PREC_BF16X3: fp32 in, fp32 out, ~2^-16 per product), which is what a reduced-precision run is for."""
+    if input.is_cuda and torch.is_autocast_enabled():
+        with torch.autocast(device_type="cuda", enabled=False):
+            return _DCNv2.apply(input.float(), offset.float(), mask.float(), weight.float(), bias.float(), stride, padding,
+                                dilation, deformable_groups, "bf16x3")
+    return _DCNv2.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)
 
 
 class DCNv2(nn.Module):

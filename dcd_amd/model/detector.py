@@ -25,8 +25,10 @@ class KeypointDetector(nn.Module):
         if training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         pixels = to_image_list(images).tensors
-        # under autocast the DCN op still computes in fp32 like the reference's (cuda/dcn_v2_cuda.cu:58): its inputs are cast back
-        amp = torch.autocast(device_type=pixels.device.type) if (training and self.fp16) else contextlib.nullcontext()
+        # MODEL.FP16 (detector.py:34-36): autocast around the backbone.  bfloat16 on MI355X (no loss scaling needed; BASELINE
+        # config 3); the DCN op stays an fp32 op at its boundary and takes the split-bf16 matrix path (DCNv2/dcn_v2.py).
+        amp = (torch.autocast(device_type=pixels.device.type, dtype=torch.bfloat16) if (training and self.fp16)
+               else contextlib.nullcontext())
         with amp:
             features = self.backbone(pixels)
         return self.heads(features, targets) if training else self.heads(features, targets, test=self.test)

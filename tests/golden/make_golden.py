@@ -239,6 +239,33 @@ def golden_gen_data():
          keys=np.array(list(gd.keys())))
 
 
+def golden_post_processor():
+    """PostProcessor.forward (detector_infer.py:86-213) on PINNED predictor outputs: image 0 of the `loss_inputs()` maps, at the
+    configured threshold (TEST.DETECTIONS_THRESHOLD) and once more with TEST.GENERATE_GMW.  `select_topk` asserts CUDA tensors
+    (layers/utils.py:83-84,93), so torch.cuda.FloatTensor is aliased to torch.FloatTensor while it runs."""
+    from model.head.detector_infer import make_post_processor
+    cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    preds, targets = gi.loss_inputs()
+    ref_targets = to_ref_targets(targets)[:1]
+    pp = make_post_processor(cfg)
+    cls, reg = torch.from_numpy(preds["cls"][:1]), torch.from_numpy(preds["reg"][:1])
+    orig = torch.cuda.FloatTensor
+    torch.cuda.FloatTensor = torch.FloatTensor
+    try:
+        with torch.no_grad():
+            result, info, vis = pp({"cls": cls, "reg": reg}, ref_targets)
+            pp.generate_data = True
+            result_g, _, vis_g = pp({"cls": cls, "reg": reg}, ref_targets)
+    finally:
+        torch.cuda.FloatTensor = orig
+    assert torch.equal(result, result_g)
+    save("post_processor", result=T(result), vis_scores=T(info["vis_scores"]), uncertainty_conf=T(info["uncertainty_conf"]),
+         estimated_depth_error=T(info["estimated_depth_error"]), keypoints=T(vis["keypoints"]), proj_center=T(vis["proj_center"]),
+         min_uncertainty=T(vis["min_uncertainty"]), pred_extra_kpts_2d=T(vis["pred_extra_kpts_2d"]),
+         pred_extra_kpts_3d=T(vis["pred_extra_kpts_3d"]), gen_kpts_2d=T(vis_g["gen_pred_extra_kpts_2d"]),
+         gen_kpts_3d=T(vis_g["gen_pred_extra_kpts_3d"]), threshold=np.float64(pp.det_threshold))
+
+
 def golden_solver():
     """Trainer harness: per-parameter learning rates, the warm-up / step-decay schedule driven exactly as
     DGDE/engine/trainer.py:152-155 drives it, and one AdamW step -- from the reference's own solver package.
@@ -361,6 +388,34 @@ def golden_model():
     save("model_96x320", **out)
 
 
+def golden_model_f64():
+    """Ground truth for the whole-model tolerance: the SAME reference model and inputs as golden_model, run
+    in float64 -- backbone (stock convs + the f64 build of the C oracle as `_ext`) and predictor in double; the predictor
+    returns float32 maps by construction (detector_predictor.py:203), so the loss arithmetic stays float32 on f64-accurate
+    inputs.  Lets the tests measure how far each fp32 run (the reference's, ours on the GPU) sits from the exact result."""
+    from model.detector import KeypointDetector
+    cfg = ref_cfg(["INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg)
+    gi.name_hashed_init(model)
+    model = model.double().train()
+    images, targets = gi.model_inputs()
+    images = images.double()
+    ref_targets = to_ref_targets(targets)
+    feats = model.backbone(images)
+    pred = model.heads.predictor(feats, ref_targets)
+    out = dict(feat_slice=T(feats[:, :4, ::6, ::16]), cls_slice=T(pred["cls"][:, :, ::4, ::8]),
+               reg_slice=T(pred["reg"][:, ::25, ::6, ::16]), reg_abs=T(pred["reg"].double().abs().mean((0, 2, 3))))
+    gi.name_hashed_init(model)
+    model.zero_grad()
+    loss_dict, _ = model(images, ref_targets)
+    sum(loss_dict.values()).backward()
+    out.update({"loss_" + k: T(v) for k, v in loss_dict.items()})
+    out["param_names"] = np.array([n for n, _ in model.named_parameters()])
+    out["grad_norms"] = np.array([0.0 if p.grad is None else float(p.grad.norm()) for _, p in model.named_parameters()])
+    save("model_96x320_f64", **out)
+
+
 def main():
     install_stubs()
     sys.path.insert(0, REF)
@@ -372,9 +427,11 @@ def main():
     golden_decode()
     golden_loss_computation()
     golden_gen_data()
+    golden_post_processor()
     golden_solver()
     golden_config()
     golden_model()
+    golden_model_f64()
 
 
 if __name__ == "__main__":

@@ -69,6 +69,70 @@ def test_backward_matches_oracle(cuda, oracle_dcn, case):
         close(g_, r_, 5e-5, "%s %s" % (name, case))
 
 
+# ---- DCD_PREC_BF16X3: split-bf16 contraction (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32 accumulate).
+# north_star's bound is 1e-3 relative; the split form loses ~2^-16 per product, so it is held to 1e-4 of the output scale
+# (1e-3 / 10) against the SAME fp32 oracle.  Geometries without a split kernel run the exact fp32 kernels (allowed by the ABI).
+BF16X3_TOL = 1e-4
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_matches_oracle_bf16x3(cuda, oracle_dcn, case):
+    from dcd_amd import _ext
+    B, C, Co, H, W, dg, osc = case
+    x, w, b, off, m, _ = make_case(B, C, Co, H, W, dg, off_scale=osc)
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    got = _ext.dcn_v2_forward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), 3, 3, 1, 1, 1, 1, 1, 1, dg,
+                              precision="bf16x3")
+    close(got, ref, BF16X3_TOL, "bf16x3 forward %s" % (case,))
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_backward_matches_oracle_bf16x3(cuda, oracle_dcn, case):
+    from dcd_amd import _ext
+    B, C, Co, H, W, dg, osc = case
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, dg, off_scale=osc, seed=1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, 3, 3, 1, 1, 1, 1, 1, 1, dg)
+    got = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda),
+                               3, 3, 1, 1, 1, 1, 1, 1, dg, precision="bf16x3")
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, BF16X3_TOL, "bf16x3 %s %s" % (name, case))
+
+
+def test_bf16x3_path_is_the_split_kernel(cuda, oracle_dcn):
+    """On a tiled geometry the split kernels must be what runs: the result differs from the exact-fp32 path in the low bits
+    (it is not the f32 kernel under another name) yet stays ~2^-16-close; forward and grad_weight (the two split kernels)."""
+    from dcd_amd import _ext
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 64, 64, 24, 64, off_scale=0.5, seed=9))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    y32 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="f32")
+    y16 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="bf16x3")
+    assert not torch.equal(y32, y16)
+    rel = (y32 - y16).abs().max().item() / y32.abs().max().item()
+    assert 1e-8 < rel < 3e-5, rel
+    g32 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="f32")
+    g16 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="bf16x3")
+    assert not torch.equal(g32[3], g16[3])
+    rel = (g32[3] - g16[3]).abs().max().item() / g32[3].abs().max().item()
+    assert 1e-8 < rel < 3e-5, rel
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 96, 320), (128, 64, 48, 160), (256, 256, 24, 80)])
+def test_full_size_bf16x3(cuda, oracle_dcn, geom):
+    """BASELINE batch (8) in split precision: image 0 against the fp32 oracle, forward and all five gradients."""
+    from dcd_amd import _ext
+    C, Co, H, W = geom
+    x, w, b, off, m, gy = make_case(8, C, Co, H, W, seed=7, off_scale=0.5)
+    xd, wd, bd, od, md, gd = (t.to(cuda) for t in (x, w, b, off, m, gy))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    y = _ext.dcn_v2_forward(xd, wd, bd, od, md, *a, precision="bf16x3")
+    close(y[:1], oracle_dcn.dcn_v2_forward(x[:1], w, b, off[:1], m[:1], *a), BF16X3_TOL, "bf16x3 image 0 forward")
+    g1 = _ext.dcn_v2_backward(xd[:1].contiguous(), wd, bd, od[:1].contiguous(), md[:1].contiguous(), gd[:1].contiguous(), *a,
+                              precision="bf16x3")
+    refg = oracle_dcn.dcn_v2_backward(x[:1], w, b, off[:1], m[:1], gy[:1], *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), g1, refg):
+        close(g_, r_, BF16X3_TOL, "bf16x3 full-size image 0 " + name)
+
+
 @pytest.mark.parametrize("geom", [(3, 3, 2, 2, 1, 1, 1, 1), (3, 3, 1, 1, 2, 2, 2, 2), (1, 1, 1, 1, 0, 0, 1, 1),
                                   (3, 1, 1, 2, 1, 0, 1, 1)])
 def test_general_geometry(cuda, oracle_dcn, geom):
@@ -164,13 +228,25 @@ def test_backward_is_deterministic_without_fallback(cuda):
     assert torch.equal(g1, g2)
 
 
-def test_full_size_layer_properties(cuda, oracle_dcn):
-    """BASELINE size (64->64 @ 96x320, bs 8): size-independent properties instead of a full oracle run.
-    (1) linearity in the weights, (2) image 0 of the batch equals a batch-1 run compared with the oracle,
-    (3) <dY, dcn(x)> adjoint identity between forward and grad_weight/grad_bias."""
+# the seven distinct DCN geometries of DLA-34 at 384x1280 (bench.py::DCN_LAYERS), at the BASELINE batch
+DGDE_GEOMETRIES = [(512, 256, 12, 40), (256, 256, 24, 80), (256, 128, 24, 80), (128, 128, 48, 160), (128, 64, 48, 160),
+                   (64, 64, 96, 320), (256, 64, 24, 80)]
+
+
+@pytest.mark.parametrize("off_scale", [0.5, 2.0])
+@pytest.mark.parametrize("geom", DGDE_GEOMETRIES)
+def test_full_size_layer_properties(cuda, oracle_dcn, geom, off_scale):
+    """BASELINE size (every DGDE layer geometry, bs 8): size-independent properties instead of a full oracle run.
+    The kernel dispatch depends on the size (tiled kernels need H >= 16, W >= 32; Cin <= 64 / Cout <= 64 pick other
+    variants; the deep layers run the generic kernels and the far-only passes), so each geometry is its own case, at
+    sub-pixel offsets (0.5 px: everything from the staged windows) and at 2 px (far samples, list fallbacks).
+    (1) linearity in the weights, (2) image 0 of the batch equals the oracle, forward and all five gradients,
+    (3) <dY, dcn(x)> adjoint identity between forward and grad_weight/grad_bias, (4) the batched run's per-image
+    gradients equal the batch-1 run's (images are independent; grad_weight sums over them)."""
     from dcd_amd import _ext
-    B, C, Co, H, W = 8, 64, 64, 96, 320
-    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=7)
+    C, Co, H, W = geom
+    B = 8
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=7, off_scale=off_scale)
     xd, wd, bd, od, md, gd = (t.to(cuda) for t in (x, w, b, off, m, gy))
     a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
     y = _ext.dcn_v2_forward(xd, wd, bd, od, md, *a)
@@ -188,6 +264,13 @@ def test_full_size_layer_properties(cuda, oracle_dcn):
                               gd[:1].contiguous(), *a)
     for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), g1, refg):
         close(g_, r_, 1e-4, "full-size image 0 " + name)
+    for i, name in enumerate(("grad_input", "grad_offset", "grad_mask")):
+        close(grads[i][:1], g1[i], 2e-5, "batched vs single image " + name)
+    # grad_weight of the batch = sum over images: check against the last image's own contribution added to the rest
+    g7 = _ext.dcn_v2_backward(xd[7:].contiguous(), wd, bd, od[7:].contiguous(), md[7:].contiguous(), gd[7:].contiguous(), *a)
+    g07 = _ext.dcn_v2_backward(xd[:7].contiguous(), wd, bd, od[:7].contiguous(), md[:7].contiguous(), gd[:7].contiguous(), *a)
+    close(grads[3], g07[3] + g7[3], 2e-5, "grad_weight additivity over images")
+    close(grads[4], g07[4] + g7[4], 2e-5, "grad_bias additivity over images")
 
 
 def test_errors_raise(cuda):

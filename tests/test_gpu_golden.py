@@ -97,18 +97,28 @@ def test_gen_data_for_gmw_matches_reference(cuda):
     H.check_gen_data(cuda, 2e-3)      # the normalised keypoints pass through the solver's mean depth: 2e-3 of the value range
 
 
-def test_whole_model_matches_reference(cuda):
-    """KeypointDetector on the GPU (MIOpen convs + HIP DCNv2 + HIP losses) vs the reference on CPU:
-    features, predictions, all 13 losses, per-parameter gradient norms, BN statistics and the eval decode.
+def test_post_processor_matches_reference(cuda):
+    """The eval decode on the GPU path (fused NMS + top-K kernel, POI gather, HIP edge-depth solve, device sin/cos/atan2) on
+    pinned predictor maps vs the reference's output: exact row order, every column within 1e-4 of its range."""
+    H.check_post_processor(cuda, 1e-4)
 
-    Tolerance: this compares TWO stock convolution back ends (MIOpen on the GPU, oneDNN on the CPU) through ~90
-    layers, 16 of which are deformable: a 1e-4 difference in a predicted sampling offset moves every later sample, so
-    the end-to-end deviation (measured layer by layer with tools/diag_layers.py: <2e-4 after the encoder, growing
-    ~2x per deformable stage) is set by the conv back ends, not by our kernels.  Our kernels are held to <=1e-4
-    against the oracle in tests/test_gpu_dcn.py / test_gpu_heads.py, and the host logic to 2e-4 against the reference
-    on identical back ends in tests/test_host_golden.py.  Here: 1e-2 on activations / losses, 3e-2 on gradient norms."""
+
+def test_whole_model_matches_reference(cuda):
+    """KeypointDetector on the GPU (HIP DCNv2 / Winograd / BN / heads kernels + MIOpen for the remaining convs) against the
+    EXACT result: the reference model run in float64 (tests/golden/model_96x320_f64.npz; our shell reproduces that run bit for
+    bit on the host, test_float64_model_equals_reference_float64).  Measured on MI355X (tools/model_dist_f64.py): activations
+    1.2-1.6e-5 from exact (the reference's own fp32 CPU run: 1.0-1.5e-5), losses <= 6.3e-5 (reference fp32: <= 4.9e-6),
+    per-parameter gradient norms <= 2.6e-3 (reference fp32: 1.25e-2 on the same yardstick).  Bars: 1e-4 on activations,
+    3e-4 on the 13 losses (north_star: 1e-3), 6e-3 on gradient norms -- i.e. the GPU run must stay as close to the exact
+    result as the reference's fp32 run is, not merely close to that run."""
     torch.backends.cudnn.benchmark = False
-    H.check_model(cuda, 1e-2, 3e-2)
+    H.check_model(cuda, 1e-4, 6e-3, truth="model_96x320_f64", loss_tol=3e-4)
+
+
+def test_whole_model_close_to_reference_fp32_run(cuda):
+    """Same model against the reference's fp32 CPU run: two fp32 runs each ~1.5e-5 from exact."""
+    torch.backends.cudnn.benchmark = False
+    H.check_model(cuda, 1e-4, 2e-2, loss_tol=3e-4)
 
 
 def test_iou3d_kernel(cuda):
@@ -163,3 +173,114 @@ def test_graphed_loss_equals_eager_loss_on_changing_targets(cuda):
         assert (gp0 - gp1).abs().max().item() <= 1e-5 * max(gp0.abs().max().item(), 1e-6)
         assert set(log0) == set(log1)
     assert len(lc._graphs) == 1          # one capture served all three batches
+
+
+def test_solver_fused_adamw_and_clip_match_reference(cuda):
+    """SURVEY 8(f)-3 on the device path: the GPU step uses FUSED AdamW over two pooled groups and our own clip_grad_norm
+    (engine/trainer.py), not the reference's per-parameter for-loop AdamW + torch.nn.utils.clip_grad_norm_
+    (DGDE/solver/__init__.py:10-62, DGDE/engine/trainer.py:139-148).  Same fixture as the CPU test (three AdamW steps and a
+    fourth from a loaded reference checkpoint, produced by the reference's solver package), now with everything on the GPU."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.engine.trainer import (build_optimizer, build_scheduler, clip_grad_norm, guard_nonfinite_step,
+                                        load_checkpoint_state, step_schedulers)
+    g = H.load("solver")
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "SOLVER.LR_WARMUP", True, "SOLVER.WARMUP_STEPS", 200,
+                        "SOLVER.MAX_ITERATION", 3000, "SOLVER.STEPS", (2000, 2600)])
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3)).to(cuda)
+    opt = build_optimizer(net, cfg)
+    assert opt.defaults["fused"] is True
+    sched, warm = build_scheduler(opt, cfg)
+    x = torch.linspace(-1, 1, 24).reshape(4, 6).to(cuda)
+    for it in range(3):
+        opt.zero_grad()
+        net(x).square().sum().backward()
+        opt.step()
+        step_schedulers(sched, warm, it, cfg)
+    got = np.concatenate([p.detach().cpu().numpy().ravel() for p in net.parameters()])
+    np.testing.assert_allclose(got, g["params_after_3_steps"], rtol=5e-6, atol=2e-7)
+    # resume from the reference's checkpoint (per-parameter groups) and take its 4th step with the fused optimizer
+    net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3)).to(cuda)
+    opt2 = build_optimizer(net2, cfg)
+    sched2, _ = build_scheduler(opt2, cfg)
+    load_checkpoint_state(H._reference_checkpoint_from_fixture(g, net2), net2, opt2, sched2)
+    opt2.zero_grad()
+    net2(x).square().sum().backward()
+    opt2.step()
+    got = np.concatenate([p.detach().cpu().numpy().ravel() for p in net2.parameters()])
+    np.testing.assert_allclose(got, g["params_after_4_steps"], rtol=5e-6, atol=2e-7)
+
+    # clip_grad_norm == torch.nn.utils.clip_grad_norm_ (the reference's call), clipping and non-clipping cases
+    gen = torch.Generator().manual_seed(3)
+    shapes = [(64, 16, 3, 3), (64,), (27, 64, 3, 3), (5, 7), (1,)]
+    for scale, max_norm in ((10.0, 15.0), (0.01, 15.0)):
+        ps = [torch.nn.Parameter(torch.zeros(s)) for s in shapes]
+        for p in ps:
+            p.grad = torch.randn(p.shape, generator=gen) * scale
+        qs = [torch.nn.Parameter(torch.zeros(s, device=cuda)) for s in shapes]
+        for p, q in zip(ps, qs):
+            q.grad = p.grad.to(cuda)
+        ref_total = torch.nn.utils.clip_grad_norm_(ps, max_norm)
+        total = clip_grad_norm(qs, max_norm)
+        assert abs(float(total) - float(ref_total)) <= 2e-6 * float(ref_total)
+        for p, q in zip(ps, qs):
+            assert (q.grad.cpu() - p.grad).abs().max().item() <= 2e-6 * p.grad.abs().max().item()
+
+    # a non-finite gradient must not reach the weights (fused kernel's found_inf flag, no host sync)
+    before = [p.detach().clone() for p in net.parameters()]
+    opt.zero_grad()
+    (net(x).square().sum() * float("nan")).backward()
+    guard_nonfinite_step(opt, clip_grad_norm(list(net.parameters()), 15.0))
+    opt.step()
+    assert all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+    opt.zero_grad()
+    net(x).square().sum().backward()
+    guard_nonfinite_step(opt, clip_grad_norm(list(net.parameters()), 15.0))
+    opt.step()
+    assert not all(torch.equal(a, b) for a, b in zip(before, net.parameters()))
+
+
+def test_model_fp16_flag_trains_in_bf16_autocast(cuda):
+    """BASELINE config 3 (bs 8 per rank, bf16): MODEL.FP16 puts the backbone under autocast like the reference
+    (DGDE/model/detector.py:34-36) -- bfloat16 here -- with the DCN op an fp32 op at its boundary on the split-bf16 matrix
+    path.  One train step at 8 images per rank must (a) really run the DCN calls in split precision, (b) give the fp32 run's
+    losses to bf16 accuracy (15 % each, 3 % in total), (c) produce finite gradients for every parameter the fp32 run has gradients for, and step."""
+    from dcd_amd import _ext
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step
+    from dcd_amd.model.detector import KeypointDetector
+    images, targets = make_batch(8, seed=5, n_objects=3, input_size=(320, 96), device=cuda)
+    seen = []
+    fwd = _ext.dcn_v2_forward
+
+    def spy(*a, **k):
+        seen.append(k.get("precision"))
+        return fwd(*a, **k)
+    results = {}
+    for fp16 in (False, True):
+        cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "MODEL.USE_SYNC_BN", False, "MODEL.FP16", fp16,
+                            "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+        torch.manual_seed(0)
+        model = KeypointDetector(cfg).to(cuda).train()
+        init_like_trained(model)
+        opt = build_optimizer(model, cfg)
+        before = [p.detach().clone() for p in model.parameters()]
+        del seen[:]
+        _ext.dcn_v2_forward = spy
+        try:
+            loss_dict, _ = train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+        finally:
+            _ext.dcn_v2_forward = fwd
+        assert len(seen) == 16 and all(p == ("bf16x3" if fp16 else None) for p in seen), seen
+        results[fp16] = ({k: float(v) for k, v in loss_dict.items()},
+                         [None if p.grad is None else bool(torch.isfinite(p.grad).all()) for p in model.parameters()],
+                         sum(int(not torch.equal(a, b)) for a, b in zip(before, model.parameters())))
+    (l32, g32, moved32), (l16, g16, moved16) = results[False], results[True]
+    assert g32 == g16 and all(v is not False for v in g16), "non-finite or missing gradients under MODEL.FP16"
+    assert moved16 == moved32 > 0
+    # bf16 carries 8 mantissa bits through ~90 layers: the individual regression losses of a randomly initialised net move by
+    # up to ~10 % (measured: dims_loss 9 %), their sum by much less
+    for k in l32:
+        assert abs(l16[k] - l32[k]) <= 0.15 * max(abs(l32[k]), 1e-2), (k, l16[k], l32[k])
+    assert abs(sum(l16.values()) - sum(l32.values())) <= 0.03 * sum(l32.values())

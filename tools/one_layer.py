@@ -14,7 +14,8 @@ w = torch.randn(Co, C, 3, 3, device=dev) / (C * 9) ** 0.5
 b = torch.zeros(Co, device=dev)
 gy = torch.randn(B, Co, H, W, device=dev)
 a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+prec = os.environ.get("DCD_PREC", "f32")
 for _ in range(4):
-    _ext.dcn_v2_forward(x, w, b, off, m, *a)
-    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    _ext.dcn_v2_forward(x, w, b, off, m, *a, precision=prec)
+    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=prec)
 torch.cuda.synchronize()
