@@ -39,6 +39,10 @@ typedef float f32x32 __attribute__((ext_vector_type(32)));
 
 namespace {
 
+template <int N> struct IntC {
+    static constexpr int value = N;
+};
+
 struct Geom {
     int B, C, H, W, Co, kh, kw, sh, sw, ph, pw, dh, dw, dg;
     int Ho, Wo, HoWo, KK, cpg, cpgp, Kp, Cop;  // cpgp: channels/group padded to 32; Kp = dg*KK*cpgp; Cop: Co padded to 32
@@ -864,6 +868,9 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             }
         }
     inv.cnt[((size_t)b * S + seg) * HW + q] = (unsigned char)(cnt > INV_CAP ? INV_OVERFLOW : cnt);
+    // scal[2] = number of overflowed (cell, tap) lists of the call.  Normally zero: the data kernels then skip their per-corner
+    // look-ups of `cnt` altogether (four dependent byte loads per pixel and tap, each waited for before the MFMA block)
+    if (cnt > INV_CAP) atomicAdd(const_cast<unsigned *>(inv.absmax_bits) + 2, 1u);
 }
 
 // grid = (ceil(in_tiles/4), B, ceil(total_channel_blocks/MB)); lane = (input cell l&31, output-channel parity l>>5)
@@ -908,14 +915,17 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
         unsigned eoff[INV_CAP];
         float ew[INV_CAP];
         const size_t base = ((size_t)b * S + seg) * INV_CAP * HW + Qc;
+        const int mu = __builtin_amdgcn_readfirstlane(maxc);      // wave-uniform: the loads below sit behind SCALAR branches
 #pragma unroll
         for (int e = 0; e < INV_CAP; ++e) {
-            eoff[e] = 0u;
-            ew[e] = 0.f;
-            if (e < maxc && e < cnt) {
-                eoff[e] = (unsigned)inv.idx[base + (size_t)e * HW] * 4u;
-                ew[e] = inv.w[base + (size_t)e * HW];
+            int ri = 0;
+            float rw_ = 0.f;
+            if (e < mu) {                                          // slots past this cell's cnt hold stale words: masked below
+                ri = inv.idx[base + (size_t)e * HW];
+                rw_ = inv.w[base + (size_t)e * HW];
             }
+            eoff[e] = e < cnt ? (unsigned)ri * 4u : 0u;
+            ew[e] = e < cnt ? rw_ : 0.f;
         }
         const unsigned wlane = ((unsigned)h * (unsigned)g.Kp + (unsigned)(seg * g.cpgp) + (unsigned)p) * 4u;
         const unsigned Kp8 = (unsigned)g.Kp * 8u;           // two weight rows per step
@@ -924,43 +934,50 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
         // stage = the raw dY samples and weight operands of ONE output-channel pair; two stages alternate so that the
         // next pair's loads are in flight while the current pair runs on the matrix pipe
         float ga[INV_CAP], gb_[INV_CAP], wa[MB], wbx[MB];
-        auto issue = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
-            const int o = 2 * st + h;
-            const float *gp = gy_b + (size_t)(o < g.Co ? o : last_o) * g.HoWo;
+        // NE: entries gathered per cell, a compile-time count picked from the wave-uniform maximum; unused slots read element
+        // 0 of the row with weight 0 (no per-entry branches: those serialised the gathers)
+        auto run = [&](auto ne_tag) {
+            constexpr int NE = decltype(ne_tag)::value;
+            auto issue = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
+                const int o = 2 * st + h;
+                const float *gp = gy_b + (size_t)(o < g.Co ? o : last_o) * g.HoWo;
 #pragma unroll
-            for (int e = 0; e < INV_CAP; ++e)
+                for (int e = 0; e < NE; ++e)
 #ifdef K3_ABL_NOGATHER
-                if (e < maxc) gv[e] = ew[e] + (float)st;
+                    gv[e] = ew[e] + (float)st;
 #else
-                if (e < maxc) gv[e] = ldg(gp, eoff[e]);
+                    gv[e] = ldg(gp, eoff[e]);
 #endif
-            const float *wp = (const float *)((const char *)wb + (size_t)st * Kp8);
+                const float *wp = (const float *)((const char *)wb + (size_t)st * Kp8);
 #pragma unroll
-            for (int mb = 0; mb < MB; ++mb) {
-                const int gbk = gb0 + mb;
-                if (gbk / nblk == grp) wv[mb] = ldg(wp, wlane + (unsigned)((gbk - grp * nblk) * 32) * 4u);
+                for (int mb = 0; mb < MB; ++mb) {
+                    const int gbk = gb0 + mb;
+                    if (gbk / nblk == grp) wv[mb] = ldg(wp, wlane + (unsigned)((gbk - grp * nblk) * 32) * 4u);
+                }
+            };
+            auto compute = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
+                float val = 0.f;
+#pragma unroll
+                for (int e = 0; e < NE; ++e) val += ew[e] * gv[e];
+                val = (2 * st + h < g.Co) ? val : 0.f;
+#pragma unroll
+                for (int mb = 0; mb < MB; ++mb)
+                    if ((gb0 + mb) / nblk == grp) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[mb], val, acc[mb], 0, 0, 0);
+            };
+            issue(ga, wa, 0);
+            int st = 0;
+            for (; st + 1 < nsteps; st += 2) {
+                issue(gb_, wbx, st + 1);
+                compute(ga, wa, st);
+                if (st + 2 < nsteps) issue(ga, wa, st + 2);
+                compute(gb_, wbx, st + 1);
             }
-        };
-        auto compute = [&](float (&gv)[INV_CAP], float (&wv)[MB], int st) {
-            float val = 0.f;
-#pragma unroll
-            for (int e = 0; e < INV_CAP; ++e)
-                if (e < maxc) val += ew[e] * gv[e];
-            val = (2 * st + h < g.Co) ? val : 0.f;
-#pragma unroll
-            for (int mb = 0; mb < MB; ++mb)
-                if ((gb0 + mb) / nblk == grp) acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wv[mb], val, acc[mb], 0, 0, 0);
+            if (st < nsteps) compute(ga, wa, st);
         };
         (void)row2;
-        issue(ga, wa, 0);
-        int st = 0;
-        for (; st + 1 < nsteps; st += 2) {
-            issue(gb_, wbx, st + 1);
-            compute(ga, wa, st);
-            if (st + 2 < nsteps) issue(ga, wa, st + 2);
-            compute(gb_, wbx, st + 1);
-        }
-        if (st < nsteps) compute(ga, wa, st);
+        if (mu <= 4) run(IntC<4>{});
+        else if (mu <= 6) run(IntC<6>{});
+        else run(IntC<INV_CAP>{});
     }
 
     float *gin_b = gin + (size_t)b * g.C * HW;
@@ -1026,16 +1043,20 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
     const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 
     // list entries (raw, undecoded) of the next tap to run: cnt is capped at 6 loads in flight per array to bound registers
-    int ncnt = 0, neo[INV_CAP];
-    float new_[INV_CAP];
+    // The two lane halves serve the same cell, so each loads HALF of the list (half 0 the even slots, half 1 the odd ones) and
+    // one v_permlane32_swap per register hands both halves the pair: 10 loads per lane and tap instead of 20 (the list loads
+    // -- duplicate addresses in the two halves, i.e. the slow address path -- were the largest piece of the kernel's non-MFMA time)
+    static_assert(INV_CAP % 2 == 0, "list slots are loaded in (even, odd) pairs");
+    int ncnt = 0, neo[INV_CAP / 2];
+    float new_[INV_CAP / 2];
     auto fetch_list = [&](int t) {
         int c = qv ? (int)inv.cnt[((size_t)b * 9 + t) * HW + Qc] : 0;
         ncnt = c == INV_OVERFLOW ? 0 : c;
         const size_t base = ((size_t)b * 9 + t) * INV_CAP * HW + Qc;
 #pragma unroll
-        for (int e = 0; e < INV_CAP; ++e) {       // unconditional: slots past cnt hold stale data of the workspace, masked on use
-            neo[e] = inv.idx[base + (size_t)e * HW];
-            new_[e] = inv.w[base + (size_t)e * HW];
+        for (int e2 = 0; e2 < INV_CAP / 2; ++e2) {       // unconditional: slots past cnt hold stale data of the workspace, masked on use
+            neo[e2] = inv.idx[base + (size_t)(2 * e2 + h) * HW];
+            new_[e2] = inv.w[base + (size_t)(2 * e2 + h) * HW];
         }
     };
     fetch_list(0);
@@ -1097,7 +1118,14 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
             int eo[INV_CAP];
             float ew[INV_CAP];
 #pragma unroll
-            for (int e = 0; e < INV_CAP; ++e) { eo[e] = neo[e]; ew[e] = new_[e]; }
+            for (int e2 = 0; e2 < INV_CAP / 2; ++e2) {
+                // V_PERMLANE32_SWAP: lanes 32-63 of the first operand <-> lanes 0-31 of the second: [0] = half 0's value in
+                // every lane (the even slot), [1] = half 1's (the odd slot)
+                const auto pi = __builtin_amdgcn_permlane32_swap((unsigned)neo[e2], (unsigned)neo[e2], false, false);
+                const auto pw = __builtin_amdgcn_permlane32_swap(__float_as_uint(new_[e2]), __float_as_uint(new_[e2]), false, false);
+                eo[2 * e2] = (int)pi[0]; eo[2 * e2 + 1] = (int)pi[1];
+                ew[2 * e2] = __uint_as_float(pw[0]); ew[2 * e2 + 1] = __uint_as_float(pw[1]);
+            }
             fetch_list(t == 8 ? 0 : t + 1);
             int maxc = cnt;
 #pragma unroll
@@ -1110,25 +1138,35 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
                 ew[e] = e < cnt ? ew[e] : 0.f;
             }
             const float *wrow = wsl + (t * MB * 2 + h) * 32 + p;
+            // NE = entries evaluated per cell: a compile-time count picked from the wave-uniform maximum, every read
+            // unconditional (unused slots point at window cell 0 with weight 0).  With a run-time bound the compiler guarded each
+            // ds_read with its own exec branch and waited for it at once -- ten serialised LDS latencies per output pair.
+            auto run = [&](auto ne_tag) {
+                constexpr int NE = decltype(ne_tag)::value;
 #pragma unroll
-            for (int s = 0; s < BI_OC / 2; ++s) {
-                const float *pl = lds + 2 * s * BI_PLANE;
-                float val = 0.f;
+                for (int s = 0; s < BI_OC / 2; ++s) {
+                    const float *pl = lds + 2 * s * BI_PLANE;
+                    float val = 0.f;
 #pragma unroll
-                for (int e = 0; e < INV_CAP; ++e)
+                    for (int e = 0; e < NE; ++e)
 #ifdef BIT_ABL_NOLDS
-                    if (e < maxc) val += ew[e] * (float)eo[e];
+                        val += ew[e] * (float)eo[e];
 #else
-                    if (e < maxc) val += ew[e] * pl[eo[e]];
+                        val += ew[e] * pl[eo[e]];
 #endif
 #pragma unroll
-                for (int mb = 0; mb < MB; ++mb)
+                    for (int mb = 0; mb < MB; ++mb)
 #ifdef BIT_ABL_NOMFMA
-                    acc[mb][s] += val;
+                        acc[mb][s] += val;
 #else
-                    acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(s * 9 * MB + mb) * 64], val, acc[mb], 0, 0, 0);
+                        acc[mb] = __builtin_amdgcn_mfma_f32_32x32x2f32(wrow[(s * 9 * MB + mb) * 64], val, acc[mb], 0, 0, 0);
 #endif
-            }
+                }
+            };
+            const int mu = __builtin_amdgcn_readfirstlane(maxc);
+            if (mu <= 4) run(IntC<4>{});
+            else if (mu <= 6) run(IntC<6>{});
+            else run(IntC<INV_CAP>{});
         }
     }
 
@@ -1204,6 +1242,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
     if (tile * 32 >= g.HoWo) return;
     const int z = blockIdx.z;
     const float rlim = (float)inv_radius(inv.absmax_bits);
+    const bool any_overflow = inv.absmax_bits[2] != 0u;
     const int S_all = g.dg * g.KK;
     const int P = tile * 32 + p;
     const bool pv = P < g.HoWo;
@@ -1245,8 +1284,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
             const bool mine = !far_mode || !(fabsf(s.oh) < TL_NEAR && fabsf(s.ow) < TL_NEAR);   // sample owned by this launch
             if (far_mode && !__any(mine)) continue;
             const unsigned char *cnt_p = inv.cnt + ((size_t)b * S_all + seg) * HW;
-            const bool a1 = mine && s.c1 && (far || cnt_p[s.i1] == INV_OVERFLOW), a2 = mine && s.c2 && (far || cnt_p[s.i2] == INV_OVERFLOW);
-            const bool a3 = mine && s.c3 && (far || cnt_p[s.i3] == INV_OVERFLOW), a4 = mine && s.c4 && (far || cnt_p[s.i4] == INV_OVERFLOW);
+            bool o1 = false, o2 = false, o3 = false, o4 = false;
+            if (any_overflow) {                                  // uniform, normally false: no look-ups at all
+                o1 = cnt_p[s.i1] == INV_OVERFLOW; o2 = cnt_p[s.i2] == INV_OVERFLOW;
+                o3 = cnt_p[s.i3] == INV_OVERFLOW; o4 = cnt_p[s.i4] == INV_OVERFLOW;
+            }
+            const bool a1 = mine && s.c1 && (far || o1), a2 = mine && s.c2 && (far || o2);
+            const bool a3 = mine && s.c3 && (far || o3), a4 = mine && s.c4 && (far || o4);
             for (int blk = blk0; blk < blk1; ++blk) {
                 f32x16 acc;
 #pragma unroll
@@ -1345,7 +1389,8 @@ __global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const flo
                                                                    const unsigned *__restrict__ far_scal)
 {
     if (far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32))) return;      // the generic kernel does the whole job instead
-    extern __shared__ __attribute__((aligned(16))) float lds[];       // [32][BD_PLANE]
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [32][BD_PLANE] window | 2 x [2 NS][32] weights of a tap
+    float *wsl = lds + BD_CB * BD_PLANE;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -1411,16 +1456,38 @@ __global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const flo
         }
         __syncthreads();
 
-        float wcur[NS];
-        {
-            const float *wp0 = wb + (size_t)blk * 32 + p + (size_t)h * g.Kp;
+        // A operands (weights of one tap: [2 NS outputs][32 channels] = NS x 256 B) travel through LDS, double-buffered per tap:
+        // fetched as coalesced dwordx4 (2 NS / 64 per thread) instead of NS dword loads per LANE and tap -- with eight waves per
+        // CU those loads (two 128-byte runs each, the slow address path) kept the CU's vector-memory unit busy for ~4 k cycles
+        // per tap, twice the MFMA block they feed (ablation: r02_abl_64.txt).
+        constexpr int NWQ = (2 * NS * 8 + BD_TR * 64 - 1) / (BD_TR * 64);          // dwordx4 per thread and tap
+        f32x4 wreg[NWQ];
+        auto w_issue = [&](int t) {
 #pragma unroll
-            for (int k = 0; k < NS; ++k) wcur[k] = wp0[(size_t)(2 * k) * g.Kp];
-        }
+            for (int k = 0; k < NWQ; ++k) {
+                const int e = tid + BD_TR * 64 * k;
+                const int o = e >> 3, q = e & 7;
+                if (e < 2 * NS * 8) wreg[k] = *reinterpret_cast<const f32x4 *>(wb + (size_t)o * g.Kp + (size_t)t * g.cpgp + blk * 32 + 4 * q);
+            }
+        };
+        auto w_commit = [&](int buf) {
+#pragma unroll
+            for (int k = 0; k < NWQ; ++k) {
+                const int e = tid + BD_TR * 64 * k;
+                if (e < 2 * NS * 8) *reinterpret_cast<f32x4 *>(wsl + buf * (2 * NS * 32) + e * 4) = wreg[k];
+            }
+        };
+        w_issue(0);
+        w_commit(0);
+        __syncthreads();
+        const bool any_overflow = far_scal[2] != 0u;           // uniform, normally false
+        TapRaw raw_next = load_tap_raw(off_b, msk_b, g, 0, P);
 #pragma unroll 1
         for (int t = 0; t < 9; ++t) {
-            // sampling state of (pixel, tap): recomputed per channel block (3 loads + ~40 VALU against 2*NS MFMAs)
-            const TapRaw raw = load_tap_raw(off_b, msk_b, g, t, P);
+            // sampling state of (pixel, tap): recomputed per channel block (3 loads + ~40 VALU against 2*NS MFMAs); the raw
+            // offsets / mask of the NEXT tap are requested here so their latency hides behind this tap's MFMA block
+            const TapRaw raw = raw_next;
+            if (t + 1 < 9) raw_next = load_tap_raw(off_b, msk_b, g, t + 1, P);
             const int ky = t / 3, kx = t - ky * 3;
             const float hf = (float)(ho - 1 + ky) + raw.oh, wf_ = (float)(wo - 1 + kx) + raw.ow;
             const bool sv = pv && hf > -1.f && wf_ > -1.f && hf < (float)g.H && wf_ < (float)g.W &&
@@ -1441,36 +1508,31 @@ __global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const flo
 #ifdef BDT_ABL_NOCNT
             const bool a1 = false, a2 = false, a3 = false, a4 = false; (void)cnt_p;
 #else
-            const bool a1 = c1 && cnt_p[i1] == INV_OVERFLOW, a2 = c2 && cnt_p[i2] == INV_OVERFLOW;
-            const bool a3 = c3 && cnt_p[i3] == INV_OVERFLOW, a4 = c4 && cnt_p[i4] == INV_OVERFLOW;
+            bool a1 = false, a2 = false, a3 = false, a4 = false;
+            if (any_overflow) {                                  // rare: some (cell, tap) list of this call overflowed
+                a1 = c1 && cnt_p[i1] == INV_OVERFLOW; a2 = c2 && cnt_p[i2] == INV_OVERFLOW;
+                a3 = c3 && cnt_p[i3] == INV_OVERFLOW; a4 = c4 && cnt_p[i4] == INV_OVERFLOW;
+            }
 #endif
 
             // dcol block on the matrix pipe: the A operands (weights of this tap) were fetched during the previous tap, the
             // next tap's are requested now; two accumulator chains keep dependent MFMAs from serialising the wave
-            float wnext[NS];
-            if (t + 1 < 9) {
-                const float *wpn = wb + (size_t)(t + 1) * g.cpgp + blk * 32 + p + (size_t)h * g.Kp;
-#pragma unroll
-                for (int k = 0; k < NS; ++k) wnext[k] = wpn[(size_t)(2 * k) * g.Kp];
-            }
+            if (t + 1 < 9) w_issue(t + 1);
+            const float *wa = wsl + (t & 1) * (2 * NS * 32) + h * 32 + p;      // A of k-step k: wa[k * 64] = Wb[2k + h][tap, channel p]
             f32x16 acc, acc2;
 #pragma unroll
             for (int r = 0; r < 16; ++r) { acc[r] = 0.f; acc2[r] = 0.f; }
 #ifndef BDT_ABL_NOMFMA
 #pragma unroll
             for (int k = 0; k < NS; k += 2) {
-                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[k], dy[k], acc, 0, 0, 0);
-                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wcur[k + 1], dy[k + 1], acc2, 0, 0, 0);
+                acc = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[k * 64], dy[k], acc, 0, 0, 0);
+                acc2 = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[(k + 1) * 64], dy[k + 1], acc2, 0, 0, 0);
             }
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[r] += acc2[r];
 #else
-            acc[0] = wcur[0] + dy[t]; acc[5] = dy[t + 1];
+            acc[0] = wa[0] + dy[t]; acc[5] = dy[t + 1];
 #endif
-            if (t + 1 < 9) {
-#pragma unroll
-                for (int k = 0; k < NS; ++k) wcur[k] = wnext[k];
-            }
 
             const float *cp0 = lds + pos + 4 * h * BD_PLANE;
             float s_m = 0.f, s_h = 0.f, s_w = 0.f;
@@ -1521,6 +1583,8 @@ __global__ __launch_bounds__(BD_TR * 64, 2) void dcn_bwd_data_tile_f32(const flo
                     }
                 }
             }
+            if (t + 1 < 9) w_commit((t + 1) & 1);     // that buffer was last read in tap t-1, which every wave has left
+            __syncthreads();
         }
     }
 }
@@ -2161,7 +2225,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     {
         ZeroRanges z;
         for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
-        z.p[0] = absmax; z.n[0] = 2;
+        z.p[0] = absmax; z.n[0] = 4;                         // max |offset| bits, far-tile count, overflowed-list count
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
         z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
@@ -2228,8 +2292,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 #ifndef DCN_NO_BWD_TILE
     if (bd_tile_ok) {
         static LdsLimit lds_limit;
-        const size_t ldsb = (size_t)BD_CB * BD_PLANE * sizeof(float);
-        if (!lds_limit.raise((int)ldsb, dcn_bwd_data_tile_f32<32>, dcn_bwd_data_tile_f32<64>)) return DCD_ERR_LAUNCH;
+        const size_t ldsb = (size_t)(BD_CB * BD_PLANE + 2 * g.Cop * 32) * sizeof(float);
+        if (!lds_limit.raise((int)((BD_CB * BD_PLANE + 2 * 128 * 32) * sizeof(float)), dcn_bwd_data_tile_f32<32>, dcn_bwd_data_tile_f32<64>))
+            return DCD_ERR_LAUNCH;
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + BD_TR - 1) / BD_TR;
         const int nsp = nblk;                 // one 32-channel block per workgroup
         dim3 gridt(tiles_x * tiles_y, B, nsp), blockt(BD_TR * 64);

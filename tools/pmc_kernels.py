@@ -1,0 +1,94 @@
+"""Hardware counters per kernel, one `rocprofv3 --pmc` pass per counter group (the program goes directly after `--`: no shell,
+no wrapper).  Aggregates the rocpd databases into one JSON: counter sums and dispatch counts per kernel short name.
+
+  python3 tools/pmc_kernels.py <out.json> <name-filter> -- python3 tools/one_layer.py 64 64 96 320
+
+Derived per kernel (MI355X_MICROARCH.md "rocprofv3 PMC slots" / per-instruction constants):
+  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   fraction of SIMD-cycles the matrix pipe is busy
+  wait_frac = SQ_WAIT_ANY / SQ_WAVE_CYCLES, issue_stall = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES, active = SQ_ACTIVE_INST_ANY / SQ_WAVE_CYCLES
+  lds_conflict = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
+  hbm bytes = (2 x FETCH_SIZE + WRITE_SIZE) KiB  (gfx950: FETCH_SIZE counts 128-B requests as 64 B; WRITE_SIZE uncalibrated)"""
+import glob
+import json
+import os
+import re
+import shutil
+import sqlite3
+import subprocess
+import sys
+
+GROUPS = [
+    ["SQ_WAVE_CYCLES", "SQ_BUSY_CU_CYCLES", "SQ_WAIT_ANY", "SQ_WAIT_INST_ANY", "SQ_ACTIVE_INST_ANY", "SQ_VALU_MFMA_BUSY_CYCLES",
+     "SQ_WAIT_INST_LDS", "SQ_WAVES"],
+    ["SQ_ACTIVE_INST_VALU", "SQ_ACTIVE_INST_LDS", "SQ_ACTIVE_INST_VMEM", "SQ_LDS_BANK_CONFLICT", "SQ_LDS_IDX_ACTIVE", "SQ_INSTS_LDS",
+     "SQ_INSTS_VMEM_RD", "SQ_INSTS_VALU_MFMA_MOPS_F32"],
+    ["SQ_INSTS_VALU", "SQ_INSTS_SALU", "SQ_INST_CYCLES_VMEM_RD", "SQ_INSTS_VALU_MFMA_MOPS_BF16", "SQ_BUSY_CYCLES", "GRBM_GUI_ACTIVE"],
+    ["FETCH_SIZE"],
+    ["WRITE_SIZE"],
+    ["TCC_HIT_sum", "TCC_MISS_sum"],
+]
+
+
+def short(name):
+    name = re.sub(r"\(anonymous namespace\)::", "", name)
+    name = re.sub(r"^void\s+", "", name)
+    return name.split("(")[0].strip()
+
+
+def main():
+    out, flt = sys.argv[1], sys.argv[2]
+    cmd = sys.argv[sys.argv.index("--") + 1:]
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    cmd = [os.path.join(root, c) if c.endswith(".py") and not os.path.isabs(c) else c for c in cmd]    # rocprofv3 runs in /tmp
+    res = {}
+    for gi, grp in enumerate(GROUPS):
+        d = "/tmp/pmck_%d" % gi
+        shutil.rmtree(d, ignore_errors=True)
+        env = dict(os.environ, TMPDIR="/tmp")
+        r = subprocess.run(["rocprofv3", "--kernel-trace", "--pmc"] + grp + ["-d", d, "--"] + cmd, cwd="/tmp", env=env,
+                           stdout=subprocess.DEVNULL, stderr=subprocess.PIPE, text=True)
+        dbs = glob.glob(d + "/**/*.db", recursive=True)
+        if not dbs:
+            print("pass %d failed: %s" % (gi, r.stderr[-400:]))
+            continue
+        cur = sqlite3.connect(dbs[0]).cursor()
+        for name, counter, val, n in cur.execute("select name, counter_name, sum(counter_value), count(*) from pmc_events "
+                                                 "group by name, counter_name"):
+            k = short(name)
+            if flt not in k:
+                continue
+            e = res.setdefault(k, {"dispatches": 0})
+            e[counter] = val
+            e["dispatches"] = max(e["dispatches"], n)
+        # mean duration per dispatch from the kernel trace of this pass
+        for name, dur, n in cur.execute("select name, sum(end-start), count(*) from kernels group by name"):
+            k = short(name)
+            if k in res:
+                res[k].setdefault("avg_us_profiled", []).append(dur / n / 1e3)
+    for k, e in res.items():
+        if "avg_us_profiled" in e:
+            e["avg_us_profiled"] = sum(e["avg_us_profiled"]) / len(e["avg_us_profiled"])
+        g = e.get
+        if g("SQ_BUSY_CU_CYCLES"):
+            e["mfma_busy"] = g("SQ_VALU_MFMA_BUSY_CYCLES", 0) / (4.0 * e["SQ_BUSY_CU_CYCLES"])
+        if g("SQ_WAVE_CYCLES"):
+            e["wait_frac"] = g("SQ_WAIT_ANY", 0) / e["SQ_WAVE_CYCLES"]
+            e["issue_stall_frac"] = g("SQ_WAIT_INST_ANY", 0) / e["SQ_WAVE_CYCLES"]
+            e["active_frac"] = g("SQ_ACTIVE_INST_ANY", 0) / e["SQ_WAVE_CYCLES"]
+            e["lds_issue_stall_frac"] = g("SQ_WAIT_INST_LDS", 0) / e["SQ_WAVE_CYCLES"]
+        if g("SQ_LDS_IDX_ACTIVE"):
+            e["lds_conflict_frac"] = g("SQ_LDS_BANK_CONFLICT", 0) / e["SQ_LDS_IDX_ACTIVE"]
+        if g("FETCH_SIZE") is not None and g("WRITE_SIZE") is not None:
+            e["hbm_bytes_per_dispatch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024 / max(e["dispatches"], 1)
+        if g("TCC_HIT_sum") is not None:
+            e["l2_hit"] = e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + g("TCC_MISS_sum", 0), 1)
+    json.dump({"command": " ".join(cmd), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
+        print("%-34s us %7.1f mfma %.3f wait %.2f stall %.2f (lds %.2f) active %.2f ldsconf %.2f l2hit %.2f hbmMB %.1f" % (
+            k[:34], e.get("avg_us_profiled", 0), e.get("mfma_busy", 0), e.get("wait_frac", 0), e.get("issue_stall_frac", 0),
+            e.get("lds_issue_stall_frac", 0), e.get("active_frac", 0), e.get("lds_conflict_frac", 0), e.get("l2_hit", 0),
+            e.get("hbm_bytes_per_dispatch", 0) / 1e6))
+
+
+if __name__ == "__main__":
+    main()
