@@ -123,8 +123,29 @@ def run_gpu(args):
     timer = DcnTimer(torch, _ext)
     clip = cfg.SOLVER.GRAD_NORM_CLIP
 
-    for _ in range(args.warmup):
-        train_step(model, optimizer, images, targets, clip)
+    # DCD_STEP_GRAPH=1 (one process only): the whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep).
+    # EXPERIMENTAL and off by default: on this ROCm stack memset nodes inside a captured graph are not reliably ordered before
+    # the kernel that follows (profiles/r02_graph_memset_hazard.txt); our own kernels no longer use them, but ATen's multi-block
+    # reductions and library kernels in the backward do, and at 384x1280 the second replay faults.  The loss section's own
+    # graph (free of such nodes since round 2) stays on.
+    force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
+    use_graph = world == 1 and not force_ddp and os.environ.get("DCD_STEP_GRAPH", "0") == "1"
+    if use_graph:
+        from dcd_amd.engine.trainer import GraphedTrainStep
+        graphed = GraphedTrainStep(model, optimizer, clip)
+
+        def step():
+            graphed(images, targets)
+    else:
+        def step():
+            train_step(model, optimizer, images, targets, clip)
+    trace = (lambda m: (sys.stderr.write("[bench] %s\n" % m), sys.stderr.flush())) if os.environ.get("DCD_BENCH_TRACE") else (lambda m: None)
+    for i in range(args.warmup):
+        step()
+        if i == 0:
+            torch.cuda.synchronize()
+            trace("first warm-up step done (graph captured and replayed once)" if use_graph else "first warm-up step done")
+    trace("warm-up done")
 
     def fence():
         if world > 1:
@@ -132,13 +153,24 @@ def run_gpu(args):
         torch.cuda.synchronize()
 
     fence()
-    timer.enabled = True
+    timer.enabled = not use_graph
     t0 = time.perf_counter()
     for _ in range(args.steps):
-        train_step(model, optimizer, images, targets, clip)
+        step()
     fence()
     elapsed = time.perf_counter() - t0
+    trace("timed region done")
     timer.enabled = False
+    dcn_source = "event pairs around every DCN call inside the timed steps"
+    if use_graph:
+        # kernels inside a graph replay cannot be bracketed by events: the DCN time comes from eager steps of the same model
+        # and batch, run right after the timed region (same process, same clocks)
+        timer.enabled = True
+        for _ in range(args.dcn_steps):
+            train_step(model, optimizer, images, targets, clip)
+        torch.cuda.synchronize()
+        timer.enabled = False
+        dcn_source = "event pairs around every DCN call in %d eager steps run right after the timed (graph-replayed) region" % args.dcn_steps
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -146,7 +178,8 @@ def run_gpu(args):
 
     global_batch = per_rank * world
     prec = "bf16x3" if args.amp else args.precision          # MODEL.FP16 routes every DCN call to the split kernels
-    dcn_ms = timer.total_ms() / max(args.steps, 1)                      # per step, this rank's share of the batch
+    dcn_count = args.dcn_steps if use_graph else args.steps
+    dcn_ms = timer.total_ms() / max(dcn_count, 1)                       # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
     out = None
     if rank == 0:
@@ -159,7 +192,7 @@ def run_gpu(args):
                                    "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
                                        global_batch, "bf16 autocast (MODEL.FP16)" if args.amp else "fp32", world, args.objects),
                        "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
-                       "parallelism": "dp%d" % world, "dcn_precision": prec,
+                       "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": "one HIP graph per step" if use_graph else "eager",
                        "sync_bn": bool(world > 1)},
             # The fused op has 196 FLOP per algorithmic byte (ridge of the part: 157.3 TF / 8 TB/s = 19.7), so the matrix pipe
             # is the bound that applies; the HBM view north_star also asks for is kept beside it.
@@ -168,7 +201,7 @@ def run_gpu(args):
                          "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                          "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
                          "traffic": load_traffic(per_rank), "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
-                         "calls_per_step": len(timer.pairs) // max(args.steps, 1)},
+                         "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
                              "algorithmic_bytes": by},
@@ -420,6 +453,7 @@ def main():
                     help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")
     ap.add_argument("--amp", action="store_true", help="MODEL.FP16: bf16 autocast around the backbone + split-bf16 DCN "
                                                         "(BASELINE config 3: --gpus 4 --batch 32 --amp)")
+    ap.add_argument("--dcn-steps", type=int, default=5, help="eager steps used to time the DCN calls when the timed steps are graph replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-timeout", type=int, default=420)

@@ -12,6 +12,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -674,7 +675,7 @@ int dcd_focal_loss(void *stream_, const float *pred, const float *target, int64_
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (!pred || !target || !out || n < 0) return DCD_ERR_BAD_ARG;
-    if (hipMemsetAsync(out, 0, 2 * sizeof(float), stream) != hipSuccess) return DCD_ERR_LAUNCH;
+    if (!dcd_zero_fill(stream, out, 2)) return DCD_ERR_LAUNCH;          // a launch, not a memset node: zero_fill.h
     if (n == 0) return DCD_OK;
     const int grid = grid_for(n, 256 * 4);
     hipLaunchKernelGGL(focal_loss_kernel, dim3(grid), dim3(256), 0, stream, pred, target, n, alpha, beta, out, grad_pred);

@@ -17,6 +17,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "zero_fill.h"
 #include "lds_limit.h"
 
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -276,7 +277,7 @@ int launch_wrw(hipStream_t stream, const float *input, const float *grad_output,
     const int tiles_x = (W + ST_C - 1) / ST_C, tiles_y = (H + ST_R - 1) / ST_R;
     const int64_t total = (int64_t)B * tiles_x * tiles_y;
     const int nwg = total < ST_WRW_WGS ? (int)total : ST_WRW_WGS;
-    if (hipMemsetAsync(grad_weight, 0, (size_t)16 * C::NJ * sizeof(float), stream) != hipSuccess) return DCD_ERR_LAUNCH;
+    if (!dcd_zero_fill(stream, grad_weight, (size_t)16 * C::NJ)) return DCD_ERR_LAUNCH;      // a launch, not a memset node: zero_fill.h
     hipLaunchKernelGGL((stem_wrw_f32<CI, KS>), dim3(nwg), dim3(256), ldsb, stream, input, grad_output, part, B, H, W, tiles_x, tiles_y);
     hipLaunchKernelGGL((stem_wrw_reduce<CI, KS>), dim3(C::NB, 32), dim3(256), 0, stream, (const float *)part, nwg * 4, grad_weight);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;

@@ -11,6 +11,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "zero_fill.h"
 
 namespace {
 
@@ -119,7 +120,7 @@ int dcd_upsample_dw_backward(void *stream_, const float *x, const float *weight,
     if (!x || !weight || !grad_y || !grad_x || !grad_weight || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535)
         return DCD_ERR_BAD_ARG;
     if (f != 2 && f != 4 && f != 8) return DCD_ERR_BAD_ARG;
-    if (hipMemsetAsync(grad_weight, 0, sizeof(float) * (size_t)C * 4 * f * f, stream) != hipSuccess) return DCD_ERR_LAUNCH;
+    if (!dcd_zero_fill(stream, grad_weight, (size_t)C * 4 * f * f)) return DCD_ERR_LAUNCH;   // a launch, not a memset node: zero_fill.h
     dim3 grid((H * W + 255) / 256, B * C), block(256);
     if (f == 2) hipLaunchKernelGGL(up_dw_bwd<2>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
     else if (f == 4) hipLaunchKernelGGL(up_dw_bwd<4>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);

@@ -61,6 +61,8 @@ class Anno_Encoder():
         reuses freed addresses, so id()-keys would hand a stale table to the next batch."""
         if torch.is_tensor(calibs):                              # already a table (graph-captured loss)
             return calibs
+        if len(calibs) and torch.is_tensor(calibs[0]):           # per-image (6,) rows (GraphedTrainStep's static targets)
+            return torch.stack(list(calibs)).to(device)
         rows = tuple((float(c.c_u), float(c.c_v), float(c.f_u), float(c.f_v), float(c.b_x), float(c.b_y)) for c in calibs)
         key = (rows, str(device))
         if self._calib_cache[0] != key:

@@ -26,6 +26,16 @@ from dcd_amd.model.layers.utils import Converter_key2channel, select_point_of_in
 from dcd_amd.utils.comm import get_world_size
 
 
+def _total(x):
+    """Sum of every element, as a row reduction followed by a sum of the rows.  A flat `.sum()` of a large tensor is a
+    multi-block reduction in ATen: partials in a scratch buffer plus a semaphore cleared by hipMemsetAsync.  Inside a captured
+    HIP graph that memset node is not reliably ordered before the kernel on this ROCm stack (csrc/zero_fill.h): from the second
+    replay on, the flat sums of the (slots, 1500) pair-depth tensors came back as 0, 2x, or another reduction's value while all
+    inputs were bit-identical to the eager evaluation (tools/debug_step_graph5.py).  Row reductions and single-block sums use
+    neither the scratch buffer nor the semaphore."""
+    return x.reshape(x.shape[0], -1).sum(dim=1).sum() if x.dim() > 1 else x.sum()
+
+
 def make_loss_evaluator(cfg):
     return Loss_Computation(cfg=cfg)
 
@@ -137,8 +147,8 @@ class Loss_Computation():
             preds['extra_kpts_2d'], pred_targets['extra_kpts_2d'], pred_targets['depth_3D']) * m2d
         l3d = self.loss_weights['extra_kpts_3d_loss'] * self.extra_kpts_3d_loss_fnc(
             preds['extra_kpts_3d'], pred_targets['extra_kpts_3d'], reduction='none').sum(dim=2) * m3d
-        extra_kpts_2d_loss = l2d.sum() / torch.clamp(m2d.sum(), min=1) * scale
-        extra_kpts_3d_loss = l3d.sum() / torch.clamp(m3d.sum(), min=1) * scale
+        extra_kpts_2d_loss = _total(l2d) / torch.clamp(_total(m2d), min=1) * scale
+        extra_kpts_3d_loss = _total(l3d) / torch.clamp(_total(m3d), min=1) * scale
 
         pred = preds['pairs_kpt_depths_all']
         pmask = preds['pairs_kpt_depths_mask'] > 0
@@ -149,14 +159,14 @@ class Loss_Computation():
         w = self.loss_weights['pairs_kpts_depth_loss']
         valid_l = w * self.reg_loss_fnc(pred, target, reduction='none') * valid
         invalid_l = w * self.reg_loss_fnc(pred.detach(), target, reduction='none') * invalid
-        n_valid, n_invalid = valid.sum(), invalid.sum()
-        log_valid = valid_l.detach().sum() / n_valid          # mean over the valid set (nan if empty, as the reference)
-        valid_total = valid_l.sum() / torch.clamp(n_valid, min=1) * scale
-        invalid_total = invalid_l.sum() / torch.clamp(n_invalid, min=1) * scale
+        n_valid, n_invalid = _total(valid), _total(invalid)
+        log_valid = _total(valid_l.detach()) / n_valid          # mean over the valid set (nan if empty, as the reference)
+        valid_total = _total(valid_l) / torch.clamp(n_valid, min=1) * scale
+        invalid_total = _total(invalid_l) / torch.clamp(n_invalid, min=1) * scale
         pairs_loss = valid_total + invalid_total if self.modify_invalid_keypoint_depths else valid_total
 
         pairs_mae = ((pred.detach() - target).abs() / target) * valid
-        pairs_all_mae = pairs_mae.sum() / torch.clamp(n_valid, min=1)
+        pairs_all_mae = _total(pairs_mae) / torch.clamp(n_valid, min=1)
         return extra_kpts_2d_loss, extra_kpts_3d_loss, pairs_loss, pairs_mae, pairs_all_mae, log_valid
 
     # ------------------------------------------------------------------------------------------
@@ -248,7 +258,7 @@ class Loss_Computation():
             kp = pick(tv["keypoints"], tv["keypoints"].shape[2], 3)
             targets['keypoints'] = kp[..., :2]
             targets['keypoints_mask'] = kp[..., -1]
-            reg_nums['keypoints'] = targets['keypoints_mask'].sum()
+            reg_nums['keypoints'] = _total(targets['keypoints_mask'])
             targets['keypoints_depth_mask'] = pick(tv["keypoints_depth_mask"], 3)
             pred_keypoints_3D = pois[:, k2c('corner_offset')].reshape(max(n_obj, 1), -1, 2)
             preds['keypoints'] = pred_keypoints_3D
@@ -268,8 +278,8 @@ class Loss_Computation():
             found = targets['find_pcl'].unsqueeze(-1).expand_as(ek[..., 2])
             targets['extra_kpts_2d_mask'] = (ek[..., 2] != 0) & found
             targets['extra_kpts_3d_mask'] = found
-            reg_nums['extra_kpts_2d'] = targets['extra_kpts_2d_mask'].sum()
-            reg_nums['extra_kpts_3d'] = targets['extra_kpts_3d_mask'].sum()
+            reg_nums['extra_kpts_2d'] = _total(targets['extra_kpts_2d_mask'])
+            reg_nums['extra_kpts_3d'] = _total(targets['extra_kpts_3d_mask'])
 
             pred_extra_kpts_2D = pois[:, k2c('extra_kpts_2d')].reshape(n_obj, -1, 2)
             pred_extra_kpts_3D = pois[:, k2c('extra_kpts_3d')].reshape(n_obj, -1, 3)
@@ -313,7 +323,7 @@ class Loss_Computation():
         pred_heatmap = predictions['cls']
         reg_pois = predictions.get('reg_pois')
         if (self.use_graph and reg_pois is not None and not self.is_gen and pred_heatmap.is_cuda and torch.is_grad_enabled()
-                and pred_heatmap.requires_grad and reg_pois.requires_grad):
+                and pred_heatmap.requires_grad and reg_pois.requires_grad and not torch.cuda.is_current_stream_capturing()):
             return self._call_graphed(pred_heatmap, reg_pois, targets_heatmap, targets_variables)
         loss_dict, names, packed = self._core(predictions, targets_heatmap, targets_variables)
         return loss_dict, LazyLogDict(names, packed, list(loss_dict))
@@ -419,7 +429,7 @@ class Loss_Computation():
         if self.compute_keypoint_corner:
             kl = lw['keypoint_loss'] * self.keypoint_loss_fnc(preds['keypoints'], pt['keypoints'],
                                                               reduction='none').sum(dim=2) * pt['keypoints_mask'] * ov[:, None]
-            loss_dict['keypoint_loss'] = kl.sum() / batch_weight
+            loss_dict['keypoint_loss'] = _total(kl) / batch_weight
 
         if self.compute_extra_kpts_corner:
             e2d, e3d, edepth, _mae, all_mae, log_edepth = self.compute_pairs_kpts_loss(preds, pt, batch_weight)
@@ -436,13 +446,13 @@ class Loss_Computation():
             w = lw['keypoint_depth_loss']
             v_l = w * self.reg_loss_fnc(kd, tgt, reduction='none')
             i_l = w * self.reg_loss_fnc(kd.detach(), tgt, reduction='none')
-            log_tensors['keypoint_depth_loss'] = (v_l.detach() * km * ovk).sum() / batch_weight
+            log_tensors['keypoint_depth_loss'] = _total(v_l.detach() * km * ovk) / batch_weight
             if self.corner_with_uncertainty:
                 cu = preds['corner_offset_uncertainty']
                 v_l = v_l * torch.exp(-cu) + w * cu
                 i_l = i_l * torch.exp(-cu)
-            v_sum = (v_l * km * ovk).sum() / batch_weight
-            i_sum = (i_l * (1 - km) * ovk).sum() / batch_weight
+            v_sum = _total(v_l * km * ovk) / batch_weight
+            i_sum = _total(i_l * (1 - km) * ovk) / batch_weight
             loss_dict['keypoint_depth_loss'] = v_sum + i_sum if self.modify_invalid_keypoint_depths else v_sum
 
         # ---- logging: one device->host copy for every scalar, made only when somebody reads the log dict (the reference
