@@ -181,6 +181,7 @@ def run_gpu(args):
     dcn_count = args.dcn_steps if use_graph else args.steps
     dcn_ms = timer.total_ms() / max(dcn_count, 1)                       # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
+    traffic, mfma_busy, pmc_source = load_pmc(per_rank)
     out = None
     if rank == 0:
         out = {
@@ -200,7 +201,7 @@ def run_gpu(args):
                          "achieved": fl / 1e12 / (dcn_ms / 1e3) if dcn_ms > 0 else None,
                          "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                          "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
-                         "traffic": load_traffic(per_rank), "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
+                         "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
                          "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
@@ -212,16 +213,20 @@ def run_gpu(args):
     return out
 
 
-def load_traffic(per_rank):
-    """HBM bytes per step of the DCN kernels from the PMC pass (profiles/dcn_traffic.json, written by
-    tools/pmc_traffic.py after a separate `rocprofv3 --pmc` run), or None when that pass has not been made."""
-    path = os.path.join(ROOT, "profiles", "dcn_traffic.json")
+def load_pmc(per_rank):
+    """Counter evidence for the DCN kernels, from separate `rocprofv3 --pmc` passes over THIS command (tools/pmc_kernels.py ->
+    profiles/dcn_pmc_r02.json): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) and the
+    time-weighted matrix-pipe busy fraction.  (None, None, "absent") when the passes have not been made for this batch."""
+    path = os.path.join(ROOT, "profiles", "dcn_pmc_r02.json")
     try:
         with open(path) as f:
             d = json.load(f)
-        return d.get("bytes_per_step_batch%d" % per_rank)
-    except (OSError, ValueError):
-        return None
+        if "--batch" in d.get("command", "") or per_rank != 8:      # the committed passes are the default bs-8 single-GPU step
+            return None, None, "absent for this batch"
+        s_ = d["summary"]
+        return int(s_["hbm_bytes_per_step"]), float(s_["mfma_busy_time_weighted"]), "profiles/dcn_pmc_r02.json"
+    except (OSError, ValueError, KeyError):
+        return None, None, "absent"
 
 
 def cpu_baseline_child(args):

@@ -2221,7 +2221,14 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 
     const bool tile_shape = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 &&
                             (W & 3) == 0 && H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr;
-    const bool bd_tile_ok = tile_shape && g.Cop == 64;   // Cout 128 (64 dY registers per lane) spills at two waves per SIMD
+    // Cout <= 64: always.  Cout 128 (64 dY registers per lane): possible since the tap weights travel through LDS (no spills,
+    // 191 VGPRs) but LDS then allows one workgroup per CU; A/B switch DCD_BD_TILE128=1.
+    static int bd128 = -1;
+    if (bd128 < 0) {
+        const char *e = getenv("DCD_BD_TILE128");
+        bd128 = (e && atoi(e) == 1) ? 1 : 0;
+    }
+    const bool bd_tile_ok = tile_shape && (g.Cop == 64 || (g.Cop == 128 && bd128));
     {
         ZeroRanges z;
         for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }

@@ -52,18 +52,17 @@ def main():
             print("pass %d failed: %s" % (gi, r.stderr[-400:]))
             continue
         cur = sqlite3.connect(dbs[0]).cursor()
-        for name, counter, val, n in cur.execute("select name, counter_name, sum(counter_value), count(*) from pmc_events "
-                                                 "group by name, counter_name"):
+        # pmc_events holds one row per dispatch, counter AND hardware instance (shader engine / XCD): values are summed over
+        # the instances; the number of dispatches comes from the kernel trace of the same pass
+        for name, counter, val in cur.execute("select name, counter_name, sum(counter_value) from pmc_events group by name, counter_name"):
             k = short(name)
             if flt not in k:
                 continue
-            e = res.setdefault(k, {"dispatches": 0})
-            e[counter] = val
-            e["dispatches"] = max(e["dispatches"], n)
-        # mean duration per dispatch from the kernel trace of this pass
+            res.setdefault(k, {"dispatches": 0})[counter] = val
         for name, dur, n in cur.execute("select name, sum(end-start), count(*) from kernels group by name"):
             k = short(name)
             if k in res:
+                res[k]["dispatches"] = n
                 res[k].setdefault("avg_us_profiled", []).append(dur / n / 1e3)
     for k, e in res.items():
         if "avg_us_profiled" in e:
@@ -82,7 +81,19 @@ def main():
             e["hbm_bytes_per_dispatch"] = (2.0 * e["FETCH_SIZE"] + e["WRITE_SIZE"]) * 1024 / max(e["dispatches"], 1)
         if g("TCC_HIT_sum") is not None:
             e["l2_hit"] = e["TCC_HIT_sum"] / max(e["TCC_HIT_sum"] + g("TCC_MISS_sum", 0), 1)
-    json.dump({"command": " ".join(cmd), "kernels": res}, open(out, "w"), indent=1, sort_keys=True)
+    steps = int(os.environ.get("PMC_STEPS", "0"))            # train steps the command ran (warm-up + timed): per-step totals
+    summary = {}
+    if steps:
+        summary = {"steps_profiled": steps,
+                   "hbm_bytes_per_step": sum(e.get("hbm_bytes_per_dispatch", 0) * e["dispatches"] for e in res.values()) / steps,
+                   "dispatches_per_step": sum(e["dispatches"] for e in res.values()) / steps,
+                   "mfma_busy_time_weighted": (sum(e.get("mfma_busy", 0) * e.get("avg_us_profiled", 0) * e["dispatches"] for e in res.values())
+                                               / max(sum(e.get("avg_us_profiled", 0) * e["dispatches"] for e in res.values()), 1e-9))}
+    json.dump({"command": " ".join(cmd), "filter": flt, "summary": summary, "kernels": res,
+               "notes": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md "
+                        "HBM); WRITE_SIZE uncalibrated; Infinity-Cache hits are included in both.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
+                        "(4 * SQ_BUSY_CU_CYCLES).  Each counter group is its own pass of the same command."},
+              open(out, "w"), indent=1, sort_keys=True)
     for k, e in sorted(res.items(), key=lambda kv: -kv[1].get("SQ_WAVE_CYCLES", 0)):
         print("%-34s us %7.1f mfma %.3f wait %.2f stall %.2f (lds %.2f) active %.2f ldsconf %.2f l2hit %.2f hbmMB %.1f" % (
             k[:34], e.get("avg_us_profiled", 0), e.get("mfma_busy", 0), e.get("wait_frac", 0), e.get("issue_stall_frac", 0),
