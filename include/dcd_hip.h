@@ -273,6 +273,31 @@ int dcd_upsample_dw_forward(void *stream, const float *x, const float *weight, f
 int dcd_upsample_dw_backward(void *stream, const float *x, const float *weight, const float *grad_y, float *grad_x,
                              float *grad_weight, int B, int C, int H, int W, int f);
 
+/* ------------------------------------------------------------------------------------------------
+ * Training-target encoding of a whole batch on the device (csrc/targets.hip).
+ * Replaces the numpy work of `KITTIDataset.__getitem__` (DGDE/data/datasets/kitti.py:354-606): box / key-point projection and
+ * visibility, truncated-object centres (`approx_proj_center`, kitti_utils.py:1040-1078), Gaussian heat map
+ * (`gaussian_radius`, `draw_umich_gaussian`, `draw_umich_gaussian_2D`, DGDE/model/heatmap_coder.py:37-124), multi-bin
+ * orientation (`encode_alpha_multibin`, kitti.py:225-244) and the border walk (`get_edge_utils`, kitti.py:165-223).
+ *   objs     (B, M, 16) float64: truncation, occlusion, box x1 y1 x2 y2, h, w, l, t x y z, ry, alpha, find_pcl, class id
+ *            (the values an `Object3d` holds, kitti_utils.py:61-113; box and t are float32 there and are rounded as such)
+ *   kpts3d   (B, M, n_extra, 3) float64  object-frame key points, already shifted by -h/2 (kitti_utils.py:112)
+ *   P        (B, 3, 4) float64; img_size (B, 2) int32 (w, h) before padding; n_obj (B) int32 objects per image (<= M)
+ *   outputs  26 device pointers, caller-allocated, ALL ZERO-FILLED except ori_mask (which the caller keeps as ones), in this
+ *            order: hm (B,n_classes,H/down,W/down) f32 | cls_ids (B,M) i32 | target_centers (B,M,2) i32 | gt_bboxes (B,M,4) f32 |
+ *            2d_bboxes (B,M,4) f32 | keypoints (B,M,10,3) f32 | keypoints_depth_mask (B,M,3) f32 | extra_kpts_2d (B,M,K,3) f32 |
+ *            extra_kpts_3d (B,M,K,3) f32 | extra_kpts_depth_mask (B,M,K) f32 | Calib_P (B,M,3,4) f32 | find_pcl (B,M) u8 |
+ *            dimensions (B,M,3) f32 | locations (B,M,3) f32 | rotys (B,M) f32 | alphas (B,M) f32 | offset_3D (B,M,2) f32 |
+ *            occlusions (B,M) f64 | truncations (B,M) f64 | orientations (B,M,8) f32 | reg_mask (B,M) u8 | trunc_mask (B,M) u8 |
+ *            reg_weight (B,M) f32 | pad_size (B,2) i64 | edge_indices (B,2(W+H)/down,2) i64 | edge_len (B) i64;  K = n_extra + 10.
+ * The configuration is the reference's: INPUT.HEATMAP_CENTER '3D', KEYPOINT_VISIBLE_MODIFY, ADJUST_BOUNDARY_HEATMAP,
+ * CONSIDER_OUTSIDE_OBJS with APPROX_3D_CENTER 'intersect', ORIENTATION 'multi-bin' with 4 bins (anything else: bad argument).
+ * ---------------------------------------------------------------------------------------------- */
+int dcd_encode_targets(void *stream, const double *objs, const double *kpts3d, const double *P, const int32_t *img_size,
+                       const int32_t *n_obj, int B, int M, int n_extra, int in_w, int in_h, int down_ratio, double filter_trunc,
+                       double filter_size, double edge_heatmap_ratio, int num_bin, int n_classes, void *const *outputs,
+                       int n_outputs);
+
 #ifdef __cplusplus
 }
 #endif
