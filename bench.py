@@ -258,6 +258,31 @@ def cpu_baseline_child(args):
                                 "oracle DCNv2 (C, OpenMP) + PyTorch CPU convs; %.1f s" % (args.cpu_batch, args.objects, dt)}))
 
 
+def cpu_serial_dcn_child(args):
+    """Variant A of SURVEY section 8(d): the reference's CPU DCN is single-threaded scalar loops (cpu/dcn_v2_im2col_cpu.cpp) --
+    our C restatement of them on ONE core (OMP_NUM_THREADS=1 set by the parent).  Bounded sample: one forward+backward of each
+    of the 7 distinct DCN geometries at one image, scaled by how often the geometry occurs (16 layers)."""
+    import torch
+    from oracle import dcn_oracle
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    g = torch.Generator().manual_seed(0)
+    total = 0.0
+    for cin, cout, h, w, n in DCN_LAYERS:
+        x = torch.randn(1, cin, h, w, generator=g)
+        off = torch.randn(1, 18, h, w, generator=g) * 0.5
+        m = torch.rand(1, 9, h, w, generator=g)
+        wt = torch.randn(cout, cin, 3, 3, generator=g) * 0.05
+        b = torch.zeros(cout)
+        gy = torch.randn(1, cout, h, w, generator=g)
+        t0 = time.perf_counter()
+        dcn_oracle.dcn_v2_forward(x, wt, b, off, m, *a)
+        dcn_oracle.dcn_v2_backward(x, wt, b, off, m, gy, *a)
+        total += n * (time.perf_counter() - t0)
+    print(json.dumps({"dcn_s_per_image": total, "cores": 1, "kind": "port",
+                      "sample": "DCNv2 forward+backward, serial C loops on one core: one call per distinct geometry (7) at 1 image, "
+                                "scaled by the layer counts (16 layers)"}))
+
+
 def cpu_baseline(args):
     cmd = [sys.executable, os.path.abspath(__file__), "--cpu-baseline-child", "--cpu-batch", str(args.cpu_batch),
            "--objects", str(args.objects), "--workload", args.workload]
@@ -265,10 +290,18 @@ def cpu_baseline(args):
     try:
         res = subprocess.run(cmd, capture_output=True, text=True, timeout=args.cpu_timeout, env=env)
         line = [l for l in res.stdout.splitlines() if l.startswith("{")][-1]
-        return json.loads(line)
+        out = json.loads(line)
     except Exception as e:  # a missing baseline must not kill the GPU number
         return {"value": None, "unit": "objects/s" if args.workload == "gmw" else "images/s", "cores": None, "kind": "port",
                 "sample": "failed: %r" % (e,)}
+    if args.workload == "dgde":          # variant A (serial, like the reference's own CPU loops) beside variant B (all cores)
+        try:
+            res = subprocess.run([sys.executable, os.path.abspath(__file__), "--cpu-serial-dcn-child"], capture_output=True, text=True,
+                                 timeout=args.cpu_timeout, env=dict(env, OMP_NUM_THREADS="1"))
+            out["serial_dcn"] = json.loads([l for l in res.stdout.splitlines() if l.startswith("{")][-1])
+        except Exception as e:
+            out["serial_dcn"] = {"dcn_s_per_image": None, "sample": "failed: %r" % (e,)}
+    return out
 
 
 # ------------------------------------------------------------------------------------------------
@@ -463,8 +496,12 @@ def main():
     ap.add_argument("--cpu-batch", type=int, default=1)
     ap.add_argument("--cpu-timeout", type=int, default=420)
     ap.add_argument("--cpu-baseline-child", action="store_true", help=argparse.SUPPRESS)
+    ap.add_argument("--cpu-serial-dcn-child", action="store_true", help=argparse.SUPPRESS)
     ap.add_argument("--dry", action="store_true", help="exercise the multi-rank launch path on the host (gloo), no GPU work")
     args = ap.parse_args()
+    if args.cpu_serial_dcn_child:
+        cpu_serial_dcn_child(args)
+        return
     if args.cpu_baseline_child:
         (gmw_cpu_baseline_child if args.workload == "gmw" else cpu_baseline_child)(args)
         return

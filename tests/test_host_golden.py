@@ -75,7 +75,7 @@ def check_loss_computation(device, tol):
 def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2):
     """Whole KeypointDetector vs a fixture of the reference's run: `truth` = "model_96x320" (the reference in fp32 on the CPU)
     or "model_96x320_f64" (the reference in float64: the exact result up to ~1e-12).  tol: activations; loss_tol: the 13
-    losses (default tol); gtol: per-parameter gradient norms, relative to the norm (floored at 1e-6 of the largest)."""
+    losses (default tol); gtol: per-parameter gradient norms, relative to the norm (floored at 1e-4 of the largest)."""
     from dcd_amd.model.detector import KeypointDetector
     g = load(truth)
     loss_tol = tol if loss_tol is None else loss_tol
@@ -117,7 +117,9 @@ def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_t
     for n, p in model.named_parameters():
         ref = norms[n]
         got = 0.0 if p.grad is None else float(p.grad.double().norm())
-        worst = max(worst, abs(got - ref) / max(ref, 1e-6 * max(norms.values())))
+        # norms below 1e-4 of the largest are compared on that absolute scale: the biases that sit in front of a BatchNorm have
+        # an exactly zero gradient, and what fp32 leaves there (1e-7 .. 4e-6 here) is summation-order noise, different every run
+        worst = max(worst, abs(got - ref) / max(ref, 1e-4 * max(norms.values())))
     assert worst <= gtol, "per-parameter gradient norms deviate by %.3e" % worst
     g = load("model_96x320")                                   # BN buffers and the eval decode: fp32 fixture only
     np.testing.assert_allclose(model.backbone.base.base_layer[1].running_mean.cpu().numpy(), g["bn_running_mean_sample"],
