@@ -28,13 +28,6 @@ from torch.nn import functional as F
 ENABLED = os.environ.get("DCD_TRUNK_MOMENTS", "1") != "0"
 
 
-def _chunk(hw, limit=4096):
-    for c in range(min(limit, hw), 0, -1):
-        if hw % c == 0:
-            return c
-    return hw
-
-
 class _Gram(torch.autograd.Function):
     """G = sum over batches of  U_b U_b^T  (fp32 products, fp64 sum over the batches); backward = (Q + Q^T) U_b."""
 
@@ -50,16 +43,28 @@ class _Gram(torch.autograd.Function):
         return torch.matmul(q, ub)
 
 
+def _row_block(H, W, limit=4096):
+    """Rows per block: the largest divisor of H whose block (rows x W pixels) stays within `limit` pixels."""
+    best = 1
+    for r in range(1, H + 1):
+        if H % r == 0 and r * W <= limit:
+            best = r
+    return best
+
+
 def patch_moments(x):
-    """x (B,C,H,W) -> U (B, 9C, HW) [row c*9 + tap, the order of `weight.view(out, -1)`], S1 (9C,) fp64, G (9C, 9C) fp64."""
+    """x (B,C,H,W) -> S1 (9C,) fp64 and G (9C, 9C) fp64 over every pixel's zero-padded 3x3 patch [index c*9 + tap, the order of
+    `weight.view(out, -1)`].  The image is cut into blocks of whole rows (with a one-row halo) BEFORE the patches are formed, so
+    the patch matrix comes out block-major -- (B * blocks, 9C, pixels per block), contiguous -- and each block's Gram matrix is
+    one batch entry of a single bmm; blocks are summed in fp64."""
     B, C, H, W = x.shape
-    U = F.unfold(x, 3, padding=1)
-    K, HW = U.shape[1], U.shape[2]
-    ch = _chunk(HW)
-    Uc = U.view(B, K, HW // ch, ch)
-    S1 = Uc.sum(3).double().sum((0, 2))
-    ub = Uc.permute(0, 2, 1, 3).reshape(B * (HW // ch), K, ch)
-    return U, S1, _Gram.apply(ub)
+    r = _row_block(H, W)
+    nb = H // r
+    xb = F.pad(x, (0, 0, 1, 1)).unfold(2, r + 2, r)                    # (B, C, nb, W, r + 2): row blocks with their halo rows
+    xb = xb.permute(0, 2, 1, 4, 3).reshape(B * nb, C, r + 2, W)
+    ub = F.unfold(xb, 3, padding=(0, 1))                                # (B * nb, 9C, r * W)
+    S1 = ub.sum(2).double().sum(0)
+    return S1, _Gram.apply(ub)
 
 
 def usable(trunks, x):
@@ -82,8 +87,8 @@ def trunks_at(x, trunks, centers, extra=None):
     BatchNorm running estimates like a dense training forward."""
     B, C, H, W = x.shape
     T = len(trunks)
-    U, S1, G = patch_moments(x)
-    K = U.shape[1]
+    S1, G = patch_moments(x)
+    K = S1.shape[0]
     Wall = torch.stack([t[0].weight.reshape(t[0].out_channels, K) for t in trunks])            # (T, O, 9C)
     Wd = Wall.double()
     sums = torch.stack((Wd @ S1, ((Wd @ G) * Wd).sum(-1)), dim=-1)                              # (T, O, 2): sum y, sum y^2
@@ -109,13 +114,23 @@ def trunks_at(x, trunks, centers, extra=None):
             bn.running_var.mul_(1 - bn.momentum).add_(unbiased[i].to(bn.running_var.dtype), alpha=bn.momentum)
             bn.num_batches_tracked.add_(1)
     scale, shift = scale.to(x.dtype), shift.to(x.dtype)
-    M = centers.shape[1]
-    Xc = U.gather(2, centers.long().unsqueeze(1).expand(B, K, M))                              # (B, 9C, M)
+    # patches at the listed positions straight from the (zero-padded) input, not from U: their backward is then a scatter of a
+    # few thousand values into dx instead of a zero-filled (B, 9C, HW) tensor, a scatter into it and one more full-size addition
+    xp = F.pad(x, (1, 1, 1, 1)).flatten(2)                                                     # (B, C, (H+2)(W+2))
+    taps = torch.tensor([dy * (W + 2) + dx for dy in range(3) for dx in range(3)], device=x.device)
+
+    def patches(pos):                                                                          # (B, n) -> (B, 9C, n), row c*9 + tap
+        pos = pos.long()
+        base = (pos // W) * (W + 2) + pos % W                                                  # top-left of the 3x3 window in xp
+        n = pos.shape[1]
+        idx = (base.unsqueeze(1) + taps.view(1, 9, 1)).reshape(B, 1, 9 * n).expand(B, C, 9 * n)
+        return xp.gather(2, idx).reshape(B, K, n)                                              # (B, C, 9, n) -> (B, 9C, n)
+    Xc = patches(centers)                                                                      # (B, 9C, M)
     y = torch.einsum('bkm,tok->tbmo', Xc, Wall)
     out = list(torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1)).unbind(0))
     if extra is not None:
         i, pos = extra
-        Xe = U.gather(2, pos.long().unsqueeze(1).expand(B, K, pos.shape[1]))
+        Xe = patches(pos)
         ye = torch.einsum('bkm,ok->bmo', Xe, Wall[i])
         out[i] = torch.cat((out[i], torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))), dim=1)
     return out
