@@ -56,10 +56,10 @@ class DcnTimer:
         self.pairs = []
         self.enabled = False
         self._f, self._b = ext.dcn_v2_forward, ext.dcn_v2_backward
-        ext.dcn_v2_forward = self._wrap(self._f)
-        ext.dcn_v2_backward = self._wrap(self._b)
+        ext.dcn_v2_forward = self._wrap(self._f, "fwd")
+        ext.dcn_v2_backward = self._wrap(self._b, "bwd")
 
-    def _wrap(self, fn):
+    def _wrap(self, fn, tag):
         def timed(*a, **k):
             if not self.enabled:
                 return fn(*a, **k)
@@ -67,12 +67,29 @@ class DcnTimer:
             e0.record()
             out = fn(*a, **k)
             e1.record()
-            self.pairs.append((e0, e1))
+            x, w = a[0], a[1]                                   # input (B, Cin, H, W), weight (Cout, Cin, kh, kw)
+            self.pairs.append((e0, e1, tag, (x.shape[1], w.shape[0], x.shape[2], x.shape[3])))
             return out
         return timed
 
     def total_ms(self):
-        return sum(a.elapsed_time(b) for a, b in self.pairs)
+        return sum(p[0].elapsed_time(p[1]) for p in self.pairs)
+
+    def per_layer(self, steps, batch):
+        """{"CinxCout@HxW": {"n": layers, "fwd_ms": per layer, "bwd_ms": per layer, "tflops": GEMM rate of fwd+bwd}}"""
+        acc = {}
+        for e0, e1, tag, geom in self.pairs:
+            d = acc.setdefault(geom, {"fwd": 0.0, "bwd": 0.0, "calls": 0})
+            d[tag] += e0.elapsed_time(e1)
+            d["calls"] += tag == "fwd"
+        out = {}
+        for (cin, cout, h, w), d in acc.items():
+            n = max(d["calls"] // max(steps, 1), 1)
+            f, b = d["fwd"] / steps / n, d["bwd"] / steps / n
+            fl = 3 * 2 * batch * cout * 9 * cin * h * w
+            out["%dx%d@%dx%d" % (cin, cout, h, w)] = {"n": n, "fwd_ms": round(f, 4), "bwd_ms": round(b, 4),
+                                                     "tflops": round(fl / 1e9 / (f + b), 2) if f + b > 0 else None}
+        return out
 
 
 def build_everything(args, device, world, local_rank):
@@ -202,7 +219,8 @@ def run_gpu(args):
                          "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                          "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
                          "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
-                         "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source},
+                         "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source,
+                         "layers": timer.per_layer(max(dcn_count, 1), per_rank)},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
                              "algorithmic_bytes": by},

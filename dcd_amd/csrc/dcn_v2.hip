@@ -2024,6 +2024,8 @@ inline int pick_mb(int nb, int tiles_total)
 
 }  // namespace
 
+#include "dcn_dense.inc"
+
 extern "C" {
 
 // partial grad_weight blocks of the tiled kernel: (channel blocks x output slices x pixel splits) x [64 o][32 c][9]
@@ -2033,16 +2035,23 @@ static size_t dw_partial_floats(int Cin, int Cout)
     return (nb > 512 ? nb : 512) * (size_t)(2 * 32 * DW_CB * 9);
 }
 
+static size_t base_workspace_bytes(const Geom &g)
+{
+    // [Wf | Wb | scalars (256 B) | inverse lists: cnt, idx, w | far-tile flags | far-tile list | grad_weight partials]
+    const size_t cells = (size_t)g.B * g.dg * g.KK * g.H * g.W;
+    const size_t ntile = (size_t)g.B * ((g.HoWo + 31) / 32);
+    const size_t n = (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256 +
+                     ((ntile + 255) / 256 * 256) + (ntile + 63) / 64 * 64 * sizeof(int) + dw_partial_floats(g.C, g.Co) * sizeof(float);
+    return (n + 255) / 256 * 256;
+}
+
 size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
                                   int pw, int dh, int dw, int dg)
 {
     Geom g;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return 0;
-    // [Wf | Wb | scalars (256 B) | inverse lists: cnt, idx, w | far-tile flags | far-tile list]
-    const size_t cells = (size_t)B * dg * g.KK * H * W;
-    const size_t ntile = (size_t)B * ((g.HoWo + 31) / 32);
-    return (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256 +
-           ((ntile + 255) / 256 * 256) + (ntile + 63) / 64 * 64 * sizeof(int) + dw_partial_floats(Cin, Cout) * sizeof(float);
+    // dense path (dcn_dense.inc): [column buffer | split-K partials] after the lists
+    return base_workspace_bytes(g) + dense_workspace_bytes(g);
 }
 
 int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, const float *bias,
@@ -2061,6 +2070,11 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     const bool split = precision == DCD_PREC_BF16X3;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
+    if (dense_ok(g)) {                                         // wide input, small map: column buffer + GEMM, exact fp32
+        if (workspace_bytes < base_workspace_bytes(g) + dense_workspace_bytes(g)) return DCD_ERR_WORKSPACE;
+        dense_forward(stream, input, weight, bias, offset, mask, output, g, (float *)((char *)workspace + base_workspace_bytes(g)));
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     float *wf = (float *)workspace, *wb = wf + nw;
 
     const int tiles = (g.HoWo + 31) / 32;
@@ -2210,6 +2224,26 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     int *far_list = (int *)(far_flag + (ntile + 255) / 256 * 256);
     float *dw_part = (float *)(far_list + (ntile + 63) / 64 * 64);
 
+    if (dense_ok(g)) {
+        ZeroRanges z;
+        for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        z.p[0] = absmax; z.n[0] = 4;
+        z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
+        z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
+        hipLaunchKernelGGL(dcn_zero_ranges, dim3(8), dim3(256), 0, stream, z);
+        const int64_t noff = (int64_t)B * dg * 2 * g.KK * g.HoWo;
+        int gsz = (int)((noff + 4095) / 4096);
+        if (gsz > 512) gsz = 512;
+        hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
+                           (g.HoWo + 31) / 32, far_flag, far_list);
+        hipLaunchKernelGGL(dcn_build_inverse, dim3((H * W + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
+        int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
+        if (splits > 32) splits = 32;
+        hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
+        dense_backward(stream, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, g, inv,
+                       (float *)((char *)workspace + base_workspace_bytes(g)));
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
                        0, stream, weight, wf, wb, g);
 

@@ -273,6 +273,86 @@ def test_full_size_layer_properties(cuda, oracle_dcn, geom, off_scale):
     close(grads[4], g07[4] + g7[4], 2e-5, "grad_bias additivity over images")
 
 
+# ---- dense path (dcd_amd/csrc/dcn_dense.inc: column buffer + three GEMMs).  By default it takes the layers with Cin >= 256
+# (CASES has one, DGDE_GEOMETRIES four); DCD_DCN_DENSE=1 sends every geometry the alignment rules allow through it.
+DENSE_CASES = [
+    # B, C, Co, H, W, dg, off_scale, (kh, kw, sh, sw, ph, pw, dh, dw)
+    (2, 16, 8, 6, 10, 1, 2.0, (3, 3, 1, 1, 1, 1, 1, 1)),
+    (2, 64, 32, 9, 12, 2, 2.0, (3, 3, 1, 1, 1, 1, 1, 1)),      # two deformable groups
+    (1, 32, 40, 8, 8, 1, 12.0, (3, 3, 1, 1, 1, 1, 1, 1)),      # most samples beyond the 8-px list radius: scattered atomically
+    (2, 16, 136, 11, 16, 1, 1.5, (3, 3, 1, 1, 1, 1, 1, 1)),    # Cout over one GEMM tile, partial second tile
+    (1, 48, 24, 23, 24, 1, 3.0, (3, 3, 1, 1, 1, 1, 1, 1)),     # 552 pixels: partial pixel tiles, split-K forward
+    (2, 16, 8, 15, 17, 1, 2.0, (3, 3, 2, 2, 1, 1, 1, 1)),      # stride 2 -> 8 x 9 outputs
+    (2, 16, 8, 12, 12, 1, 2.0, (3, 3, 1, 1, 2, 2, 2, 2)),      # dilation 2
+    (1, 32, 8, 6, 10, 1, 1.0, (1, 1, 1, 1, 0, 0, 1, 1)),       # 1x1 kernel
+]
+
+
+@pytest.mark.parametrize("case", DENSE_CASES)
+def test_dense_path_matches_oracle(cuda, oracle_dcn, monkeypatch, case):
+    from dcd_amd import _ext
+    monkeypatch.setenv("DCD_DCN_DENSE", "1")
+    B, C, Co, H, W, dg, osc, geo = case
+    kh, kw, sh, sw, ph, pw, dh, dw = geo
+    Ho = (H + 2 * ph - (dh * (kh - 1) + 1)) // sh + 1
+    Wo = (W + 2 * pw - (dw * (kw - 1) + 1)) // sw + 1
+    g = torch.Generator().manual_seed(21)
+    x = torch.randn(B, C, H, W, generator=g)
+    off = torch.randn(B, 2 * dg * kh * kw, Ho, Wo, generator=g) * osc
+    m = torch.rand(B, dg * kh * kw, Ho, Wo, generator=g)
+    w = torch.randn(Co, C, kh, kw, generator=g) / (C * kh * kw) ** 0.5
+    b = torch.randn(Co, generator=g)
+    gy = torch.randn(B, Co, Ho, Wo, generator=g)
+    args = geo + (dg,)
+    dev = [t.to(cuda) for t in (x, w, b, off, m, gy)]
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, *args)
+    got = _ext.dcn_v2_forward(*dev[:5], *args)
+    close(got, ref, 2e-5, "dense forward %s" % (case,))
+    refg = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *args)
+    gotg = _ext.dcn_v2_backward(*dev, *args)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gotg, refg):
+        close(g_, r_, 5e-5, "dense %s %s" % (name, case))
+    # and it is a different code path from the fused kernels, agreeing with them to summation-order noise
+    monkeypatch.setenv("DCD_DCN_DENSE", "0")
+    fused = _ext.dcn_v2_forward(*dev[:5], *args)
+    close(got, fused, 2e-5, "dense vs fused forward %s" % (case,))
+
+
+def test_dense_path_overflow_and_far(cuda, oracle_dcn, monkeypatch):
+    """The convergent-offset case above through the dense path: overflowed lists and far samples are scattered by the
+    coordinate kernel, the rest comes from the lists."""
+    from dcd_amd import _ext
+    monkeypatch.setenv("DCD_DCN_DENSE", "1")
+    B, C, Co, H, W = 2, 16, 8, 16, 20
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=11)
+    ys = torch.arange(H).view(1, 1, H, 1).float()
+    xs = torch.arange(W).view(1, 1, 1, W).float()
+    for k in range(9):
+        i, j = k // 3, k % 3
+        off[:, 2 * k] = ((ys // 4) * 4 + 1.3) - (ys - 1 + i)
+        off[:, 2 * k + 1] = ((xs // 4) * 4 + 1.6) - (xs - 1 + j)
+    off[1, :, 8:] += 9.0                                   # second image: half the rows beyond the list radius
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    got = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda), *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, 5e-5, "dense convergent " + name)
+
+
+def test_dense_backward_is_deterministic(cuda, monkeypatch):
+    """No atomics when the lists hold every sample: all five gradients are bit-reproducible (split-K partials are summed
+    in a fixed order)."""
+    from dcd_amd import _ext
+    monkeypatch.setenv("DCD_DCN_DENSE", "1")
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 64, 64, 24, 40, off_scale=0.25, seed=5))
+    off.clamp_(-0.9, 0.9)
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    g1 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    g2 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    for u, v in zip(g1[:4], g2[:4]):
+        assert torch.equal(u, v)
+
+
 def test_errors_raise(cuda):
     from dcd_amd import _ext
     x, w, b, off, m, gy = (t.to(cuda) for t in make_case(1, 4, 4, 5, 5))
