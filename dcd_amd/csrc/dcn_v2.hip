@@ -104,6 +104,7 @@ struct Tap {
     // onto the loaded pair (at the left / right image edge the valid corner moves to the other element).
     int pt, pb;
     float a0, a1, b0, b1;
+    int shift;               // 0: pair = (corner 1|3, corner 2|4); +1: first element is corner 2|4; -1: second element is corner 1|3
     bool c1, c2, c3, c4;     // corner validity
 };
 
@@ -154,6 +155,7 @@ __device__ __forceinline__ Tap finish_tap(const TapRaw &raw, const Geom &g, int 
         const int shift = xb - wl;          // 0 inside, +1 at the left edge (wl == -1), -1 at the right edge (wl == W-1)
         s.pt = ya * g.W + xb;
         s.pb = yb * g.W + xb;
+        s.shift = shift;
         s.a0 = shift == 0 ? s.w1 : (shift == 1 ? s.w2 : 0.f);
         s.a1 = shift == 0 ? s.w2 : (shift == -1 ? s.w1 : 0.f);
         s.b0 = shift == 0 ? s.w3 : (shift == 1 ? s.w4 : 0.f);
@@ -2070,7 +2072,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     const bool split = precision == DCD_PREC_BF16X3;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
-    if (dense_ok(g)) {                                         // wide input, small map: column buffer + GEMM, exact fp32
+    if (dense_ok(g, false)) {                                  // wide input, small map: column buffer + GEMM, exact fp32
         if (workspace_bytes < base_workspace_bytes(g) + dense_workspace_bytes(g)) return DCD_ERR_WORKSPACE;
         dense_forward(stream, input, weight, bias, offset, mask, output, g, (float *)((char *)workspace + base_workspace_bytes(g)));
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
@@ -2224,13 +2226,15 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     int *far_list = (int *)(far_flag + (ntile + 255) / 256 * 256);
     float *dw_part = (float *)(far_list + (ntile + 63) / 64 * 64);
 
-    if (dense_ok(g)) {
+    if (dense_ok(g, true)) {
         ZeroRanges z;
         for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
         hipLaunchKernelGGL(dcn_zero_ranges, dim3(8), dim3(256), 0, stream, z);
+        hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
+                           0, stream, weight, wf, wb, g);
         const int64_t noff = (int64_t)B * dg * 2 * g.KK * g.HoWo;
         int gsz = (int)((noff + 4095) / 4096);
         if (gsz > 512) gsz = 512;
@@ -2240,7 +2244,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
         if (splits > 32) splits = 32;
         hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
-        dense_backward(stream, input, weight, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, g, inv,
+        dense_backward(stream, input, wb, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, g, inv,
                        (float *)((char *)workspace + base_workspace_bytes(g)));
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }

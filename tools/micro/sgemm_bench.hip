@@ -24,7 +24,7 @@ static double check(bool ak, bool bk, int M, int N, int K, int Z, int nsplit)
     hipMemcpy(dB, B.data(), B.size() * 4, hipMemcpyHostToDevice);
     hipMemcpy(dbias, bias.data(), M * 4, hipMemcpyHostToDevice);
     SgemmArgs a{dA, dB, dC, nsplit == 1 ? dbias : nullptr, M, N, K, lda, ldb, N, (long long)M * K, (long long)K * N,
-                (long long)nsplit * M * N, (long long)M * N, nsplit, ((K + nsplit - 1) / nsplit + 15) / 16 * 16};
+                (long long)nsplit * M * N, (long long)M * N, nsplit, ((K + nsplit - 1) / nsplit + 15) / 16 * 16, 0};
     sgemm_f32(0, ak, bk, a, Z);
     hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
     double worst = 0;
@@ -52,7 +52,7 @@ static void timeit(const char *name, bool ak, bool bk, int M, int N, int K, int 
     hipMalloc(&dA, nA * 4); hipMalloc(&dB, nB * 4); hipMalloc(&dC, nC * 4);
     hipMemset(dA, 0, nA * 4); hipMemset(dB, 0, nB * 4);
     SgemmArgs a{dA, dB, dC, nullptr, M, N, K, lda, ldb, N, sA, sB, (long long)nsplit * M * N, (long long)M * N, nsplit,
-                ((K + nsplit - 1) / nsplit + 15) / 16 * 16};
+                ((K + nsplit - 1) / nsplit + 15) / 16 * 16, 0};
     hipEvent_t e0, e1;
     hipEventCreate(&e0); hipEventCreate(&e1);
     for (int i = 0; i < 3; ++i) sgemm_f32(0, ak, bk, a, Z);
