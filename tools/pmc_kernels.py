@@ -1,7 +1,7 @@
 """Hardware counters per kernel, one `rocprofv3 --pmc` pass per counter group (the program goes directly after `--`: no shell,
 no wrapper).  Aggregates the rocpd databases into one JSON: counter sums and dispatch counts per kernel short name.
 
-  python3 tools/pmc_kernels.py <out.json> <name-filter> -- python3 tools/one_layer.py 64 64 96 320
+  python3 tools/pmc_kernels.py <out.json> <name-filter[|name-filter...]> -- python3 tools/one_layer.py 64 64 96 320
 
 Derived per kernel (MI355X_MICROARCH.md "rocprofv3 PMC slots" / per-instruction constants):
   mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / (SQ_BUSY_CU_CYCLES x 4 SIMDs)   fraction of SIMD-cycles the matrix pipe is busy
@@ -56,7 +56,7 @@ def main():
         # the instances; the number of dispatches comes from the kernel trace of the same pass
         for name, counter, val in cur.execute("select name, counter_name, sum(counter_value) from pmc_events group by name, counter_name"):
             k = short(name)
-            if flt not in k:
+            if not any(f in k for f in flt.split('|')):
                 continue
             res.setdefault(k, {"dispatches": 0})[counter] = val
         for name, dur, n in cur.execute("select name, sum(end-start), count(*) from kernels group by name"):
