@@ -220,7 +220,7 @@ class _predictor(nn.Module):
                 if fused and j == self.offset_index[1]:
                     o = o + self._edge_fusion_at_pois(at_all[:, M:].transpose(1, 2), edge_lin, edge_valid, centers_lin)
                     # the class map gets its edge term densely (it is consumed densely by the focal loss)
-                    self._edge_fusion_cls(feature_cls, output_cls, targets)
+                    output_cls = self._edge_fusion_cls(feature_cls, output_cls, targets)
                 outs.append(o)
         output_cls = sigmoid_hm(output_cls)
         return {'cls': output_cls.float(), 'reg': None, 'reg_pois': torch.cat(outs, dim=2).float()}
@@ -234,11 +234,19 @@ class _predictor(nn.Module):
         bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
         yi = edge_indices[:, :, 1].long().view(b, 1, K)
         xi = edge_indices[:, :, 0].long().view(b, 1, K)
+        valid = torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens
+        if feature_cls.is_cuda and output_cls.dtype == torch.float32 and output_cls.is_contiguous():
+            # gather / scatter-add at linear cell indices on the HIP kernels (one launch each)
+            lin = (yi * feature_cls.shape[3] + xi).view(b, K)
+            edge_cls_output = self.trunc_heatmap_conv(ops.select_point_of_interest(b, lin, feature_cls).transpose(1, 2))
+            vals = (edge_cls_output * valid.unsqueeze(1).to(edge_cls_output.dtype)).transpose(1, 2)
+            return ops.scatter_add_at(output_cls, vals, lin)
         ci = torch.arange(self.head_conv, device=feature_cls.device).view(1, -1, 1)
         edge_cls_output = self.trunc_heatmap_conv(feature_cls[bi, ci, yi, xi])
-        valid = (torch.arange(K, device=edge_indices.device).view(1, K) < edge_lens).to(edge_cls_output.dtype)
+        valid = valid.to(edge_cls_output.dtype)
         co = torch.arange(output_cls.shape[1], device=output_cls.device).view(1, -1, 1)
         output_cls.index_put_((bi, co, yi, xi), edge_cls_output * valid.unsqueeze(1), accumulate=True)
+        return output_cls
 
     def forward(self, features, targets):
         if (self.training and self.sparse_training_heads and targets is not None and self.exact_edge_gather

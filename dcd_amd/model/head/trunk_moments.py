@@ -81,6 +81,17 @@ def usable(trunks, x):
     return True
 
 
+_TAPS = {}
+
+
+def _taps(W, device):
+    """Offsets of the nine taps inside the padded plane, cached per (width, device): no host-to-device copy per step."""
+    key = (W, str(device))
+    if key not in _TAPS:
+        _TAPS[key] = torch.tensor([dy * (W + 2) + dx for dy in range(3) for dx in range(3)], device=device)
+    return _TAPS[key]
+
+
 def trunks_at(x, trunks, centers, extra=None):
     """BN + ReLU outputs of every trunk at `centers` (B, M) linear pixel indices -> list of (B, M, Cout); `extra` = (trunk index,
     positions (B, Ke)) appends that trunk's outputs at further positions (the border cells of the edge-fusion branch).  Updates the
@@ -108,16 +119,27 @@ def trunks_at(x, trunks, centers, extra=None):
     shift = beta - mean * scale
     with torch.no_grad():
         unbiased = var * (n / max(n - 1, 1))
-        for i, t in enumerate(trunks):
-            bn = t[1]
-            bn.running_mean.mul_(1 - bn.momentum).add_(mean[i].to(bn.running_mean.dtype), alpha=bn.momentum)
-            bn.running_var.mul_(1 - bn.momentum).add_(unbiased[i].to(bn.running_var.dtype), alpha=bn.momentum)
-            bn.num_batches_tracked.add_(1)
+        bns = [t[1] for t in trunks]
+        mom = bns[0].momentum
+        if all(bn.momentum == mom and bn.running_mean.dtype == bns[0].running_mean.dtype for bn in bns):
+            # one multi-tensor launch per operation instead of five small kernels per trunk
+            rm, rv = [bn.running_mean for bn in bns], [bn.running_var for bn in bns]
+            dt = rm[0].dtype
+            torch._foreach_mul_(rm, 1 - mom)
+            torch._foreach_add_(rm, list(mean.to(dt).unbind(0)), alpha=mom)
+            torch._foreach_mul_(rv, 1 - mom)
+            torch._foreach_add_(rv, list(unbiased.to(dt).unbind(0)), alpha=mom)
+            torch._foreach_add_([bn.num_batches_tracked for bn in bns], 1)
+        else:
+            for i, bn in enumerate(bns):
+                bn.running_mean.mul_(1 - bn.momentum).add_(mean[i].to(bn.running_mean.dtype), alpha=bn.momentum)
+                bn.running_var.mul_(1 - bn.momentum).add_(unbiased[i].to(bn.running_var.dtype), alpha=bn.momentum)
+                bn.num_batches_tracked.add_(1)
     scale, shift = scale.to(x.dtype), shift.to(x.dtype)
     # patches at the listed positions straight from the (zero-padded) input, not from U: their backward is then a scatter of a
     # few thousand values into dx instead of a zero-filled (B, 9C, HW) tensor, a scatter into it and one more full-size addition
     xp = F.pad(x, (1, 1, 1, 1)).flatten(2)                                                     # (B, C, (H+2)(W+2))
-    taps = torch.tensor([dy * (W + 2) + dx for dy in range(3) for dx in range(3)], device=x.device)
+    taps = _taps(W, x.device)
 
     def patches(pos):                                                                          # (B, n) -> (B, 9C, n), row c*9 + tap
         pos = pos.long()

@@ -233,6 +233,46 @@ def select_point_of_interest(batch, index, feature_maps):
     return _POI.apply(feature_maps, index)
 
 
+class _ScatterAddAt(torch.autograd.Function):
+    """fmap[b, :, index[b, m]] += vals[b, m, :] in place (one kernel, fp32 atomics); the gradient of `vals` is a gather of the
+    map's gradient.  Replaces `index_put_(..., accumulate=True)` with four index tensors (eight bounds-check reductions, a
+    sort and the scatter: ~40 launches) where the edge-fusion branch adds its outputs into the class map
+    (DGDE/model/head/detector_predictor.py:186-196)."""
+
+    @staticmethod
+    def forward(ctx, fmap, vals, index):
+        _lib.require_cuda(fmap, vals, index)
+        if fmap.dtype != torch.float32 or not fmap.is_contiguous():
+            raise RuntimeError("scatter_add_at: the map must be a contiguous float32 tensor (it is updated in place)")
+        B, C, H, W = fmap.shape
+        idx = index.to(torch.int64).contiguous()
+        v = _f32c(vals)
+        st = _lib.lib().dcd_poi_scatter_add(_lib.stream_of(fmap), v.data_ptr(), idx.data_ptr(), B, C, H, W, idx.shape[1],
+                                            fmap.data_ptr())
+        _lib.check(st, "dcd_poi_scatter_add")
+        ctx.mark_dirty(fmap)
+        ctx.save_for_backward(idx)
+        return fmap
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        (idx,) = ctx.saved_tensors
+        g = _f32c(g)
+        B, C, H, W = g.shape
+        gv = None
+        if ctx.needs_input_grad[1]:
+            gv = torch.empty((B, idx.shape[1], C), dtype=torch.float32, device=g.device)
+            st = _lib.lib().dcd_poi_gather(_lib.stream_of(g), g.data_ptr(), idx.data_ptr(), B, C, H, W, idx.shape[1], gv.data_ptr())
+            _lib.check(st, "dcd_poi_gather")
+        return g, gv, None
+
+
+def scatter_add_at(fmap, vals, index):
+    """fmap (B,C,H,W) += vals (B,M,C) at the linear cell indices index (B,M); returns fmap (updated in place)."""
+    return _ScatterAddAt.apply(fmap, vals, index)
+
+
 def iou_3d(pred_corners, target_corners):
     """(N,8,3) x (N,8,3) -> (N) 3-D IoU (BEV rectangle overlap x height overlap); no gradient."""
     _lib.require_cuda(pred_corners, target_corners)
