@@ -6,9 +6,10 @@
       started bare, by bench.py itself (it spawns torch.distributed.run as a child before touching the GPU).
 
 A step = forward + 13-term loss + backward + gradient all-reduce (RCCL, N>1) + grad clip + AdamW, on a synthetic
-KITTI-shaped batch that is resident in HBM before the timed region.  The batch named by the metric (8 images) is
-split over the ranks like the reference does (IMS_PER_BATCH // world, DGDE/data/build.py:63-67), so the total work is
-fixed: "scaling": "strong"  (`--scaling weak` keeps 8 images per GPU instead).
+KITTI-shaped batch that is resident in HBM before the timed region.  Every rank trains on 8 images (the metric's batch on
+one GPU; BASELINE.json configs[2] is this at N = 4: bs 32 on 4 GPUs), value = all ranks' images / time: "scaling": "weak".
+`--scaling strong` splits ONE batch of 8 over the ranks instead (IMS_PER_BATCH // world, DGDE/data/build.py:63-67: one
+image per rank at N = 8, north_star's wording); DESIGN.md section 6 gives the measured one-image step and what it projects to.
 
 One JSON line on rank 0.  Besides the driver's contract it carries
   roofline     -- DCNv2 forward+backward of the 16 DLA-34 DCN layers: GEMM flops (computed from the
@@ -129,8 +130,11 @@ def run_gpu(args):
         raise SystemExit("--gpus %d but WORLD_SIZE=%d" % (args.gpus, world))
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
-    if world > 1 or "RANK" in os.environ:                               # launched by torch.distributed.run
-        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if world > 1 or "RANK" in os.environ or os.environ.get("DCD_FORCE_DDP", "0") == "1":   # launched by torch.distributed.run
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")               # (or a one-rank group for DCD_FORCE_DDP=1)
+        os.environ.setdefault("MASTER_PORT", "29533")
+        os.environ.setdefault("RANK", "0")
+        os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)       # "nccl" is RCCL on ROCm
     # MIOpen: its exhaustive find costs minutes on a fresh box, so by default its heuristics (immediate mode) pick the
     # conv kernels.  DCD_MIOPEN_FIND=1 turns the search on (measured in round 1: no gain).
@@ -503,7 +507,7 @@ def main():
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
     ap.add_argument("--batch", type=int, default=8, help="global batch (strong) or per-GPU batch (weak)")
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak")
     ap.add_argument("--objects", type=int, default=6)
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
                     help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")

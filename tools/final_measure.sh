@@ -1,0 +1,24 @@
+# Round-end measurement set (one GPU):  bash tools/final_measure.sh <tag>
+tag=$1
+R=$GRAFT_REPO_ROOT
+cd $R
+python bench.py --steps 20 --warmup 5 > gpurun_out/${tag}_f32.json 2> gpurun_out/${tag}_f32.err
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --amp > gpurun_out/${tag}_amp.json 2> /dev/null
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --precision bf16x3 > gpurun_out/${tag}_bf16x3.json 2> /dev/null
+python bench.py --steps 10 --warmup 4 --no-cpu-baseline --batch 1 > gpurun_out/${tag}_b1.json 2> /dev/null
+DCD_FORCE_DDP=1 python bench.py --steps 10 --warmup 4 --no-cpu-baseline --batch 1 > gpurun_out/${tag}_ddp_b1.json 2> /dev/null
+DCD_FORCE_DDP=1 python bench.py --steps 10 --warmup 4 --no-cpu-baseline > gpurun_out/${tag}_ddp_b8.json 2> /dev/null
+python bench.py --workload gmw --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_gmw.json 2> /dev/null
+bash tools/prof_step.sh ${tag} > gpurun_out/${tag}_prof.log 2>&1
+cd $R
+PMC_STEPS=4 python3 tools/pmc_kernels.py gpurun_out/${tag}_dcn_pmc.json "dcn_|sgemm" -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_pmc.log 2>&1
+for f in f32 amp bf16x3 b1 ddp_b1 ddp_b8 gmw; do python3 - <<P
+import json
+try:
+    d=json.load(open("gpurun_out/${tag}_$f.json"))
+    r=d.get("roofline",{})
+    print("$f", round(d["value"],2), d["unit"], round(d["ms_per_step"],2), "ms | roofline", r.get("ms_per_step"), r.get("frac"))
+except Exception as e:
+    print("$f", "failed", e)
+P
+done
