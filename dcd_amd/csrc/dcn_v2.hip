@@ -777,6 +777,7 @@ struct InvLists {
     int *idx;                      // [B][S][INV_CAP][HW]
     float *w;                      // [B][S][INV_CAP][HW]
     int packed;                    // idx holds (py << 16 | px) instead of the flat pixel index (tiled grad_input kernel)
+    const unsigned char *blockmax; // [B][S][ceil(Ho/8)][ceil(Wo/8)]: ceil(max |offset|) over an 8x8 block of output pixels (<= 255)
 };
 
 __device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
@@ -828,6 +829,29 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
         atomicMax(scal, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));   // non-negative floats order like their bits
 }
 
+// ceil(max(|dh|, |dw|)) over each 8x8 block of output pixels, per (image, tap segment): lets dcn_build_inverse search a
+// window as wide as the offsets NEAR a cell require instead of as wide as the call's largest offset (learned offset fields
+// are smooth: the local bound is typically 1-2 px where the global one is 3-8, and the search costs (2R+1)^2 reads).
+// grid = (blocks_x * blocks_y, S, B), one wave per block.
+__global__ __launch_bounds__(64) void dcn_offset_blockmax(const float *__restrict__ off, Geom g, unsigned char *__restrict__ blockmax)
+{
+    const int nbx = (g.Wo + 7) >> 3, nby = (g.Ho + 7) >> 3;
+    const int blk = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
+    const int by = blk / nbx, bx = blk - by * nbx;
+    const int S = g.dg * g.KK;
+    const int py = by * 8 + (threadIdx.x >> 3), px = bx * 8 + (threadIdx.x & 7);
+    float m = 0.f;
+    if (py < g.Ho && px < g.Wo) {
+        const float *oh_p = off + ((size_t)b * S + seg) * 2 * g.HoWo;
+        const int P = py * g.Wo + px;
+        m = fmaxf(fabsf(oh_p[P]), fabsf(oh_p[g.HoWo + P]));
+        if (!(m == m)) m = 1e6f;                                   // NaN offsets: widest
+    }
+#pragma unroll
+    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    if (threadIdx.x == 0) blockmax[(((size_t)b * S + seg) * nby + by) * nbx + bx] = (unsigned char)fminf(ceilf(m), 255.f);
+}
+
 // one thread per (input cell q, tap segment, image)
 __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict__ off, const float *__restrict__ msk,
                                                          InvLists inv, Geom g)
@@ -839,14 +863,31 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
     const int S = g.dg * g.KK;
     const int t = seg % g.KK, i = t / g.kw, j = t - i * g.kw;
     const int qy = q / g.W, qx = q - qy * g.W;
-    const int rm1 = inv_radius(inv.absmax_bits), R = rm1 + 1;
-    const float rlim = (float)rm1;
+    const int rg = inv_radius(inv.absmax_bits);                   // call-wide bound: samples beyond it are "far" (atomic fallback)
+    // output pixels whose un-deformed tap position lies within R of this cell
+    const int cy = qy + g.ph - i * g.dh, cx = qx + g.pw - j * g.dw;
+    int rm1 = rg;
+    if (inv.blockmax) {
+        // Local bound: the 3x3 neighbourhood of 8x8 output blocks around the cell's own output position reaches >= 8 output
+        // pixels (>= 8 input pixels for any stride) in every direction.  If the offsets in it are all <= r0 <= 7, only pixels
+        // within r0 + 1 <= 8 can put a non-far sample next to this cell, and they all lie inside the neighbourhood.
+        const int nbx = (g.Wo + 7) >> 3, nby = (g.Ho + 7) >> 3;
+        const int pcy = min(max(cy / g.sh, 0), g.Ho - 1) >> 3, pcx = min(max(cx / g.sw, 0), g.Wo - 1) >> 3;
+        const unsigned char *bm = inv.blockmax + ((size_t)b * S + seg) * nby * nbx;
+        int r0 = 0;
+        for (int dy = -1; dy <= 1; ++dy)
+            for (int dx = -1; dx <= 1; ++dx) {
+                const int yy = pcy + dy, xx = pcx + dx;
+                if (yy >= 0 && yy < nby && xx >= 0 && xx < nbx) r0 = max(r0, (int)bm[yy * nbx + xx]);
+            }
+        if (r0 <= 7 && r0 < rg) rm1 = r0;
+    }
+    const int R = rm1 + 1;
+    const float rlim = (float)rg;
     const float *oh_p = off + ((size_t)b * S + seg) * 2 * g.HoWo;
     const float *ow_p = oh_p + g.HoWo;
     const float *m_p = msk + ((size_t)b * S + seg) * g.HoWo;
     const size_t base = ((size_t)b * S + seg) * INV_CAP * HW + q;
-    // output pixels whose un-deformed tap position lies within R of this cell
-    const int cy = qy + g.ph - i * g.dh, cx = qx + g.pw - j * g.dw;
     int py0 = (cy - R + g.sh - 1) / g.sh, py1 = (cy + R) / g.sh;
     int px0 = (cx - R + g.sw - 1) / g.sw, px1 = (cx + R) / g.sw;
     if (cy - R < 0) py0 = 0;
@@ -863,7 +904,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             const float dw_ = ((float)(px * g.sw - g.pw + j * g.dw) + ow) - (float)qx;
             if (fabsf(dh_) < 1.f && fabsf(dw_) < 1.f) {
                 if (cnt < INV_CAP) {
-                    inv.idx[base + (size_t)cnt * HW] = (inv.packed && rm1 <= INV_RTILE) ? ((py << 16) | px) : P;
+                    inv.idx[base + (size_t)cnt * HW] = (inv.packed && rg <= INV_RTILE) ? ((py << 16) | px) : P;
                     inv.w[base + (size_t)cnt * HW] = (1.f - fabsf(dh_)) * (1.f - fabsf(dw_)) * m_p[P];
                 }
                 ++cnt;
@@ -2037,6 +2078,12 @@ static size_t dw_partial_floats(int Cin, int Cout)
     return (nb > 512 ? nb : 512) * (size_t)(2 * 32 * DW_CB * 9);
 }
 
+// per (image, tap segment, 8x8 block of output pixels) one byte, after the grad_weight partials
+static size_t blockmax_bytes(const Geom &g)
+{
+    return ((size_t)g.B * g.dg * g.KK * ((g.Ho + 7) / 8) * ((g.Wo + 7) / 8) + 255) / 256 * 256;
+}
+
 static size_t base_workspace_bytes(const Geom &g)
 {
     // [Wf | Wb | scalars (256 B) | inverse lists: cnt, idx, w | far-tile flags | far-tile list | grad_weight partials]
@@ -2044,7 +2091,7 @@ static size_t base_workspace_bytes(const Geom &g)
     const size_t ntile = (size_t)g.B * ((g.HoWo + 31) / 32);
     const size_t n = (size_t)g.Kp * g.Cop * sizeof(float) * 2 + 256 + ((cells + 255) / 256 * 256) + cells * INV_CAP * 8 + 256 +
                      ((ntile + 255) / 256 * 256) + (ntile + 63) / 64 * 64 * sizeof(int) + dw_partial_floats(g.C, g.Co) * sizeof(float);
-    return (n + 255) / 256 * 256;
+    return (n + 255) / 256 * 256 + blockmax_bytes(g);
 }
 
 size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph,
@@ -2225,6 +2272,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     unsigned char *far_flag = (unsigned char *)(((uintptr_t)(inv.w + cells * INV_CAP) + 255) / 256 * 256);
     int *far_list = (int *)(far_flag + (ntile + 255) / 256 * 256);
     float *dw_part = (float *)(far_list + (ntile + 63) / 64 * 64);
+    unsigned char *blockmax = (unsigned char *)workspace + (base_workspace_bytes(g) - blockmax_bytes(g));
+    inv.blockmax = blockmax;
+    const dim3 bm_grid(((g.Ho + 7) / 8) * ((g.Wo + 7) / 8), dg * g.KK, B);
 
     if (dense_ok(g, true)) {
         ZeroRanges z;
@@ -2240,6 +2290,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (gsz > 512) gsz = 512;
         hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
                            (g.HoWo + 31) / 32, far_flag, far_list);
+        hipLaunchKernelGGL(dcn_offset_blockmax, bm_grid, dim3(64), 0, stream, offset, g, blockmax);
         hipLaunchKernelGGL(dcn_build_inverse, dim3((H * W + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
         if (splits > 32) splits = 32;
@@ -2298,6 +2349,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const bool bi_tile_ok = false;
 #endif
         inv.packed = bi_tile_ok ? 1 : 0;
+        hipLaunchKernelGGL(dcn_offset_blockmax, bm_grid, dim3(64), 0, stream, offset, g, blockmax);
         hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         bool bi_tiled = false;
 #ifndef DCN_NO_BWD_TILE

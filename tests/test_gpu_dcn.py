@@ -353,6 +353,26 @@ def test_dense_backward_is_deterministic(cuda, monkeypatch):
         assert torch.equal(u, v)
 
 
+@pytest.mark.parametrize("jump", [3.0, 6.0, 7.5])
+@pytest.mark.parametrize("dense", ["0", "1"])
+def test_local_search_radius_of_the_inverse_lists(cuda, oracle_dcn, monkeypatch, jump, dense):
+    """dcn_build_inverse searches as far as the offsets in the 3x3 neighbourhood of 8x8 blocks around a cell require
+    (dcn_offset_blockmax), not as far as the call's largest offset.  A smooth field (0.2 px) with one 8x8 patch whose samples
+    jump `jump` px to the right: the cells that receive them lie in blocks with small offsets of their own and must still find
+    them (7.5 px: the local bound saturates and the call-wide radius is used)."""
+    from dcd_amd import _ext
+    monkeypatch.setenv("DCD_DCN_DENSE", dense)
+    B, C, Co, H, W = 2, 16, 8, 40, 40
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=0.2, seed=13)
+    off[:, 1::2, 16:24, 16:24] += jump                     # x offsets of every tap inside the patch
+    off[1, 0::2, 24:32, 8:16] -= jump                      # second image: another patch jumping up
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    got = _ext.dcn_v2_backward(x.to(cuda), w.to(cuda), b.to(cuda), off.to(cuda), m.to(cuda), gy.to(cuda), *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, 5e-5, "local radius %s jump %s dense %s" % (name, jump, dense))
+
+
 def test_errors_raise(cuda):
     from dcd_amd import _ext
     x, w, b, off, m, gy = (t.to(cuda) for t in make_case(1, 4, 4, 5, 5))
