@@ -57,6 +57,8 @@ SIGNATURES = {
     "dcd_bn_train_forward": (c_int, [c_void_p] * 8 + [c_float, c_float, c_int] + [c_void_p] * 3 + [c_int, c_int, c_int64]
                              + [c_void_p, c_size_t]),
     "dcd_bn_backward": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int64] + [c_void_p, c_size_t]),
+    "dcd_sgemm_shifted": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
+                                  c_int64, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "dcd_encode_targets": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_double] * 3 + [c_int, c_int, c_void_p, c_int]),
 }
 

@@ -2484,4 +2484,21 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
+int dcd_sgemm_shifted(void *stream_, const float *A, int lda, long long strideA, const float *Bbase, const long long *b_off,
+                      long long strideB, int b_kcontig, const float *bias, float *C, int ldc, long long strideC,
+                      long long strideCs, int M, int N, int K, int Z, int nsplit)
+{
+    (void)hipGetLastError();
+    if (!A || !Bbase || !b_off || !C || M <= 0 || N <= 0 || K <= 0 || Z <= 0 || nsplit <= 0 || (lda & 3) || ((uintptr_t)A & 15) ||
+        (strideA & 3) || (bias && nsplit != 1))
+        return DCD_ERR_BAD_ARG;
+    SgemmArgs a;
+    a.A = A; a.B = Bbase; a.C = C; a.bias = bias; a.M = M; a.N = N; a.K = K; a.lda = lda; a.ldb = 0; a.ldc = ldc;
+    a.strideA = strideA; a.strideB = strideB; a.strideC = strideC; a.strideCs = strideCs;
+    a.nsplit = nsplit; a.kchunk = ((K + nsplit - 1) / nsplit + SG_K - 1) / SG_K * SG_K; a.ct = 0; a.b_off = b_off;
+    if ((long long)a.kchunk * (nsplit - 1) >= K) return DCD_ERR_BAD_ARG;      // an empty split would leave its partial unwritten
+    sgemm_f32_rows64((hipStream_t)stream_, b_kcontig != 0, a, Z);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
 }  // extern "C"

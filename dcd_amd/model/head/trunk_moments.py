@@ -52,11 +52,12 @@ def _row_block(H, W, limit=4096):
     return best
 
 
-def patch_moments(x):
+def patch_moments_gram(x):
     """x (B,C,H,W) -> S1 (9C,) fp64 and G (9C, 9C) fp64 over every pixel's zero-padded 3x3 patch [index c*9 + tap, the order of
     `weight.view(out, -1)`].  The image is cut into blocks of whole rows (with a one-row halo) BEFORE the patches are formed, so
     the patch matrix comes out block-major -- (B * blocks, 9C, pixels per block), contiguous -- and each block's Gram matrix is
-    one batch entry of a single bmm; blocks are summed in fp64."""
+    one batch entry of a single bmm; blocks are summed in fp64.  (First form of this path: 2 (9C)^2 HW flops per image; kept for
+    A/B runs, DCD_TRUNK_GRAM=bmm.)"""
     B, C, H, W = x.shape
     r = _row_block(H, W)
     nb = H // r
@@ -65,6 +66,152 @@ def patch_moments(x):
     ub = F.unfold(xb, 3, padding=(0, 1))                                # (B * nb, 9C, r * W)
     S1 = ub.sum(2).double().sum(0)
     return S1, _Gram.apply(ub)
+
+
+# ---- autocorrelation form ---------------------------------------------------------------------------------------------------
+# G[(c,t),(c',t')] = sum_p X[c, p+t-1] X[c', p+t'-1] depends on the taps only through d = t' - t, up to border terms:
+#     G(t,t') = R_d - (terms of the one image row / column that the zero padding cuts off for tap t)
+#     R_d[c,c'] = sum_u X[c,u] X[c',u+d]                 (X = 0 outside the image; d in [-2,2]^2, R_-d = R_d^T)
+# 13 products of size C x C x BHW instead of (9C)^2 x BHW: 6x fewer flops, and no patch matrix at all -- the shifted operand is a
+# pointer offset into the zero-padded image (dcd_sgemm_shifted).  The border terms need the three outermost rows / columns only.
+HALF = [(dy, dx) for dy in range(0, 3) for dx in range(-2, 3) if dy > 0 or dx >= 0]           # 13 shifts, (0,0) first
+ALL25 = [(dy, dx) for dy in range(-2, 3) for dx in range(-2, 3)]
+_CONST = {}
+
+
+def _const(key, build):
+    if key not in _CONST:
+        _CONST[key] = build()
+    return _CONST[key]
+
+
+class _ShiftCorr(torch.autograd.Function):
+    """x (B,C,H,W) -> R (13,C,C) fp64 [HALF order], total (C,) fp64 = sum of x per channel, and copies of the border bands
+    (top / bottom three rows, left / right three columns) through which autograd reaches the border terms.
+    Device tensors: two launches of the shifted-view GEMM (forward: A = padded x, B = its 13 shifts, split-K partials summed in
+    fp64; backward: dX = K Xshift over all 25 shifts with the gradient of `total` as the row bias).  Host tensors (the fp64
+    host-logic tests): the same sums written with torch slices."""
+
+    @staticmethod
+    def forward(ctx, x):
+        B, C, H, W = x.shape
+        Hp, Wp = H + 4, (W + 4 + 3) // 4 * 4
+        Lp = Hp * Wp
+        guard = 2 * Wp + 8
+        buf = x.new_zeros(2 * guard + B * C * Lp)
+        xp = buf[guard:guard + B * C * Lp].view(B, C, Hp, Wp)
+        xp[:, :, 2:2 + H, 2:2 + W] = x
+        ctx.geom = (B, C, H, W, Hp, Wp, Lp, guard)
+        ctx.save_for_backward(buf)
+        if x.is_cuda:
+            from dcd_amd import _lib
+            L = _lib.lib()
+            dev = x.device
+            off = _const(("fwd", C, Lp, Wp, str(dev)), lambda: torch.tensor(
+                [c * Lp + dy * Wp + dx for (dy, dx) in HALF for c in range(C)], dtype=torch.int64, device=dev))
+            nsplit = max(1, min(8, Lp // 2048))          # fp32 partial sums of <= ~4000 products, summed in fp64
+            part = torch.empty((B * nsplit, C, len(HALF) * C), dtype=torch.float32, device=dev)
+            st = L.dcd_sgemm_shifted(_lib.stream_of(x), xp.data_ptr(), Lp, C * Lp, xp.data_ptr(), off.data_ptr(), C * Lp, 1, None,
+                                     part.data_ptr(), len(HALF) * C, nsplit * C * len(HALF) * C, C * len(HALF) * C,
+                                     C, len(HALF) * C, Lp, B, nsplit)
+            _lib.check(st, "dcd_sgemm_shifted")
+            R = part.double().sum(0).view(C, len(HALF), C).transpose(0, 1).contiguous()
+        else:
+            R = torch.stack([torch.einsum('bcyx,bkyx->ck', xp[:, :, 2:2 + H, 2:2 + W], xp[:, :, 2 + dy:2 + dy + H, 2 + dx:2 + dx + W])
+                             for (dy, dx) in HALF]).double()
+        total = x.sum(3).double().sum((0, 2))
+        return (R, total, x[:, :, 0:3, :].clone(), x[:, :, H - 3:H, :].clone(), x[:, :, :, 0:3].clone(), x[:, :, :, W - 3:W].clone())
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dR, dtotal, dT, dBt, dL, dRr):
+        buf, = ctx.saved_tensors
+        B, C, H, W, Hp, Wp, Lp, guard = ctx.geom
+        xp = buf[guard:guard + B * C * Lp].view(B, C, Hp, Wp)
+        dR = dR.to(buf.dtype)
+        # dX[c,u] = sum_d sum_c' ( dR_d[c,c'] X[c',u+d] + dR_d[c',c] X[c',u-d] ) + dtotal[c]
+        ia, ma, ib, mb = _const(("k1", str(buf.device)), lambda: (
+            torch.tensor([HALF.index(e) if e in HALF else 0 for e in ALL25], device=buf.device),
+            torch.tensor([float(e in HALF) for e in ALL25], device=buf.device).view(25, 1, 1),
+            torch.tensor([HALF.index((-e[0], -e[1])) if (-e[0], -e[1]) in HALF else 0 for e in ALL25], device=buf.device),
+            torch.tensor([float((-e[0], -e[1]) in HALF) for e in ALL25], device=buf.device).view(25, 1, 1)))
+        K1 = (dR[ia] * ma.to(dR.dtype) + dR[ib].transpose(1, 2) * mb.to(dR.dtype)).transpose(0, 1).contiguous()   # (C, 25, C)
+        if buf.is_cuda:
+            from dcd_amd import _lib
+            L = _lib.lib()
+            dev = buf.device
+            off = _const(("bwd", C, Lp, Wp, str(dev)), lambda: torch.tensor(
+                [c * Lp + dy * Wp + dx for (dy, dx) in ALL25 for c in range(C)], dtype=torch.int64, device=dev))
+            dxp = torch.empty((B, C, Hp, Wp), dtype=torch.float32, device=dev)
+            bias = dtotal.to(torch.float32).contiguous()
+            K1 = K1.view(C, 25 * C)
+            st = L.dcd_sgemm_shifted(_lib.stream_of(buf), K1.data_ptr(), 25 * C, 0, xp.data_ptr(), off.data_ptr(), C * Lp, 0,
+                                     bias.data_ptr(), dxp.data_ptr(), Lp, C * Lp, 0, C, Lp, 25 * C, B, 1)
+            _lib.check(st, "dcd_sgemm_shifted")
+            dx = dxp[:, :, 2:2 + H, 2:2 + W]
+        else:
+            dx = dtotal.to(buf.dtype).view(1, C, 1, 1).expand(B, C, H, W).clone()
+            for j, (dy, dx_) in enumerate(ALL25):
+                dx += torch.einsum('ck,bkyx->bcyx', K1[:, j, :], xp[:, :, 2 + dy:2 + dy + H, 2 + dx_:2 + dx_ + W])
+        dx = dx.contiguous()
+        dx[:, :, 0:3, :] += dT
+        dx[:, :, H - 3:H, :] += dBt
+        dx[:, :, :, 0:3] += dL
+        dx[:, :, :, W - 3:W] += dRr
+        return dx
+
+
+def _border_tables(device):
+    """Constant tables of the assembly: E[t,t'] = index of d = t' - t in ALL25; Mk[t, s] = coefficient of border term s
+    (bottom row, top row, right column, left column, corners BR, BL, TR, TL) that tap t subtracts."""
+    def build():
+        E = torch.tensor([[ALL25.index((t2 // 3 - t1 // 3, t2 % 3 - t1 % 3)) for t2 in range(9)] for t1 in range(9)], device=device)
+        Mk = torch.zeros(9, 8, dtype=torch.float64)
+        for t in range(9):
+            ty, tx = t // 3, t % 3
+            # tap t reads u = p + t - 1: over all p it misses the LAST row when ty == 0, the FIRST row when ty == 2 (same for columns)
+            Mk[t, 0] = ty == 0; Mk[t, 1] = ty == 2; Mk[t, 2] = tx == 0; Mk[t, 3] = tx == 2
+            Mk[t, 4] = -(ty == 0 and tx == 0); Mk[t, 5] = -(ty == 0 and tx == 2)
+            Mk[t, 6] = -(ty == 2 and tx == 0); Mk[t, 7] = -(ty == 2 and tx == 2)
+        half_of = torch.tensor([HALF.index(d) if d in HALF else HALF.index((-d[0], -d[1])) for d in ALL25], device=device)
+        flip = torch.tensor([d not in HALF for d in ALL25], device=device)
+        return E, Mk.to(device), half_of, flip
+    return _const(("tables", str(device)), build)
+
+
+def patch_moments(x):
+    """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above)."""
+    if os.environ.get("DCD_TRUNK_GRAM", "shift") == "bmm" or x.shape[2] < 5 or x.shape[3] < 5:
+        return patch_moments_gram(x)
+    B, C, H, W = x.shape
+    R13, total, T, Bt, Lb, Rb = _ShiftCorr.apply(x)
+    E, Mk, half_of, flip = _border_tables(x.device)
+    R25 = R13[half_of]
+    R25 = torch.where(flip.view(25, 1, 1), R25.transpose(1, 2), R25)                           # R_-d = R_d^T
+    T, Bt, Lb, Rb = T.double(), Bt.double(), Lb.double(), Rb.double()
+
+    # Border terms, two bands per call: the bottom / right band is mirrored so that its strip line sits at index 0 like the
+    # top / left band's (a mirrored axis turns d into -d along it: the result is mirrored back).
+    rows = torch.stack((T, Bt.flip(2)))                                                         # (2,B,C,3,W), strip row = index 0
+    nbr = F.pad(rows, (2, 2, 2, 0))                                                             # rows -2..2 around the strip row
+    row_t = torch.einsum('sbcx,sbkijx->sijck', rows[:, :, :, 0, :], nbr.unfold(4, W, 1))        # (2,5,5,C,C): [band, dy, dx]
+    cols = torch.stack((Lb, Rb.flip(3)))                                                        # (2,B,C,H,3), strip column = index 0
+    nbc = F.pad(cols, (2, 0, 2, 2))
+    col_t = torch.einsum('sbcy,sbkijy->sijck', cols[:, :, :, :, 0], nbc.unfold(3, H, 1))        # (2,5(dy),5(dx),C,C)
+    # corners: the strip row's first / last pixel against its 5x5 neighbourhood
+    cor_l = torch.einsum('sbc,sbkij->sijck', rows[:, :, :, 0, 0], nbr[..., 0:5])                # column 0:    (top-left, bottom-left)
+    cor_r = torch.einsum('sbc,sbkij->sijck', rows[:, :, :, 0, W - 1], nbr[..., W - 1:W + 4])    # column W-1:  (top-right, bottom-right)
+    top_row, bot_row = row_t[0], row_t[1].flip(0)
+    left_col, right_col = col_t[0], col_t[1].flip(1)
+    strips = torch.stack((bot_row, top_row, right_col, left_col, cor_r[1].flip(0), cor_l[1].flip(0), cor_r[0], cor_l[0])).reshape(8, 25, C, C)
+    corr = (Mk @ strips.view(8, -1)).view(9, 25, C, C)
+    Gt = (R25.unsqueeze(0) - corr)[torch.arange(9, device=x.device).view(9, 1), E]            # (9, 9, C, C): [t, t', c, c']
+    G = Gt.permute(2, 0, 3, 1).reshape(9 * C, 9 * C)
+    # S1[c,t] = sum over u in the image minus the row / column tap t never reads (+ the corner counted twice)
+    sums = torch.stack((Bt[:, :, 2, :].sum((0, 2)), T[:, :, 0, :].sum((0, 2)), Rb[:, :, :, 2].sum((0, 2)), Lb[:, :, :, 0].sum((0, 2)),
+                        Bt[:, :, 2, W - 1].sum(0), Bt[:, :, 2, 0].sum(0), T[:, :, 0, W - 1].sum(0), T[:, :, 0, 0].sum(0)))   # (8, C)
+    S1 = (total.view(1, C) - Mk @ sums).t().reshape(9 * C)
+    return S1, G
 
 
 def usable(trunks, x):

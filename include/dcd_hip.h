@@ -155,6 +155,19 @@ int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corne
  * head trunks (DGDE/model/head/detector_predictor.py:149-160 call every trunk on the same `features`). */
 int dcd_sum_tensors(void *stream, const float *const *srcs, int n, float *out, int64_t numel);
 
+/* Batched fp32 product on the matrix pipe whose second operand is a set of SHIFTED VIEWS of one buffer:
+ *     C[z][s] (M x N, row-major, ldc) = A[z] (M x K, row-major, lda) * B[z] (K x N)   over k in split s,   (+ bias[m] when nsplit == 1)
+ *     B[z](k, n) = b_kcontig ? Bbase[z*strideB + b_off[n] + k] : Bbase[z*strideB + b_off[k] + n]
+ * b_off: device array (N resp. K entries) of element offsets, any 4-byte aligned position -- e.g. row c of a zero-padded image
+ * plane shifted by (dy, dx).  64-row tiles (M is the 64 channels of the head feature map).  It evaluates the 3x3-patch Gram
+ * matrix of the regression-head input through its 25 autocorrelation matrices R_d[c,c'] = sum_p x[c,p] x[c',p+d] and the
+ * gradient dX = sum_d K_d Xshift_d (dcd_amd/model/head/trunk_moments.py): what the reference spends on eleven dense
+ * 3x3 convolutions + BatchNorm statistics of one shared input (DGDE/model/head/detector_predictor.py:104-120, 149-160).
+ * Partials of split s go to C + z*strideC + s*strideCs; the caller sums them (in fp64). */
+int dcd_sgemm_shifted(void *stream, const float *A, int lda, long long strideA, const float *Bbase, const long long *b_off,
+                      long long strideB, int b_kcontig, const float *bias, float *C, int ldc, long long strideC,
+                      long long strideCs, int M, int N, int K, int Z, int nsplit);
+
 /* Context normalisation of GMW's feature extractor (`gcn`, GMW/model/yi2018cvpr/ops.py:5-17): x (rows, K) -> y = (x - mean) /
  * sqrt(var_unbiased + eps) per row, inv (rows) = the scale; backward from (grad_y, y, inv).  rows = batch * channels. */
 int dcd_context_norm_forward(void *stream, const float *x, float *y, float *inv, int rows, int K, float eps);

@@ -1,0 +1,43 @@
+"""GPU: the shifted-view GEMM behind dcd_amd/model/head/trunk_moments.py (dcd_sgemm_shifted, 64-row tiles of sgemm_f32.inc)
+against the same sums written with torch slices in float64 on the host, forward and backward, and the assembled moments against
+the patch-matrix form."""
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("shape", [(2, 64, 24, 40), (3, 16, 9, 14), (1, 80, 12, 21)])
+def test_shift_correlations_match_host_float64(cuda, shape):
+    from dcd_amd.model.head import trunk_moments as TM
+    torch.manual_seed(3)
+    B, C, H, W = shape
+    x = torch.randn(B, C, H, W)
+    outs = []
+    for dev, dt in ((cuda, torch.float32), (torch.device("cpu"), torch.float64)):
+        xi = x.to(dev, dt).requires_grad_(True)
+        R, total, T, Bt, L, Rr = TM._ShiftCorr.apply(xi)
+        g = torch.Generator().manual_seed(5)
+        wR = torch.randn(R.shape, generator=g, dtype=torch.float64).to(dev)
+        wt = torch.randn(total.shape, generator=g, dtype=torch.float64).to(dev)
+        wb = [torch.randn(t.shape, generator=g).to(dev, dt) for t in (T, Bt, L, Rr)]
+        loss = (R * wR).sum() + (total * wt).sum() + sum((t * w_).sum().double() for t, w_ in zip((T, Bt, L, Rr), wb))
+        loss.backward()
+        outs.append((R.detach().cpu().double(), total.detach().cpu().double(), xi.grad.detach().cpu().double()))
+    (R0, t0, g0), (R1, t1, g1) = outs
+    n = B * H * W
+    assert (R0 - R1).abs().max().item() <= 2e-6 * n ** 0.5 * max(R1.abs().max().item() / n ** 0.5, 1.0)
+    assert (t0 - t1).abs().max().item() <= 1e-5 * n ** 0.5
+    assert (g0 - g1).abs().max().item() <= 2e-5 * g1.abs().max().item()
+
+
+def test_moments_equal_patch_matrix_form(cuda, monkeypatch):
+    """S1 and G from the autocorrelation form == from the explicit patch matrix (the round's first form), on the device."""
+    from dcd_amd.model.head import trunk_moments as TM
+    torch.manual_seed(1)
+    x = torch.randn(2, 64, 24, 40, device=cuda)
+    S1a, Ga = TM.patch_moments(x)
+    monkeypatch.setenv("DCD_TRUNK_GRAM", "bmm")
+    S1b, Gb = TM.patch_moments(x)
+    assert (S1a - S1b).abs().max().item() <= 1e-3
+    assert (Ga - Gb).abs().max().item() <= 2e-5 * Gb.abs().max().item()

@@ -69,8 +69,76 @@ static void timeit(const char *name, bool ak, bool bk, int M, int N, int K, int 
     hipFree(dA); hipFree(dB); hipFree(dC);
 }
 
+
+// 64-row tile with B rows at listed offsets (shifted views of one padded buffer): the autocorrelation products
+static double check_rows(bool bk, int M, int N, int K, int nsplit)
+{
+    // buffer of R rows of length L; B row (BK: n, else k) starts at an arbitrary 4-byte aligned offset
+    const int nrows = bk ? N : K, len = bk ? K : N;
+    const int L = len + 37;
+    std::vector<float> A((size_t)M * K), buf((size_t)nrows * L + 64), C((size_t)nsplit * M * N);
+    std::vector<long long> off(nrows);
+    for (auto &v : A) v = frand();
+    for (auto &v : buf) v = frand();
+    for (int r = 0; r < nrows; ++r) off[r] = (long long)r * L + (r * 7) % 31;
+    float *dA, *dB, *dC;
+    long long *doff;
+    hipMalloc(&dA, A.size() * 4); hipMalloc(&dB, buf.size() * 4); hipMalloc(&dC, C.size() * 4); hipMalloc(&doff, nrows * 8);
+    hipMemcpy(dA, A.data(), A.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(dB, buf.data(), buf.size() * 4, hipMemcpyHostToDevice);
+    hipMemcpy(doff, off.data(), nrows * 8, hipMemcpyHostToDevice);
+    SgemmArgs a{dA, dB, dC, nullptr, M, N, K, K, 0, N, 0, 0, (long long)nsplit * M * N, (long long)M * N, nsplit,
+                ((K + nsplit - 1) / nsplit + 15) / 16 * 16, 0, doff};
+    sgemm_f32_rows64(0, bk, a, 1);
+    hipMemcpy(C.data(), dC, C.size() * 4, hipMemcpyDeviceToHost);
+    double worst = 0;
+    for (int m = 0; m < M; m += 3)
+        for (int n = 0; n < N; n += 5) {
+            double ref = 0, got = 0;
+            for (int k = 0; k < K; ++k) ref += (double)A[(size_t)m * K + k] * (bk ? buf[off[n] + k] : buf[off[k] + n]);
+            for (int s = 0; s < nsplit; ++s) got += C[((size_t)s * M + m) * N + n];
+            worst = fmax(worst, fabs(got - ref));
+        }
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(doff);
+    return worst;
+}
+
+static void time_rows(const char *name, bool bk, int M, int N, int K, int Z, int nsplit, int L)
+{
+    const int nrows = bk ? N : K;
+    float *dA, *dB, *dC;
+    long long *doff;
+    std::vector<long long> off(nrows);
+    for (int r = 0; r < nrows; ++r) off[r] = (long long)(r % 64) * L + 700 + (r / 64) * 3;
+    const size_t nB = (size_t)Z * 64 * L + 4096;
+    hipMalloc(&dA, (size_t)Z * M * K * 4); hipMalloc(&dB, nB * 4); hipMalloc(&dC, (size_t)Z * nsplit * M * N * 4); hipMalloc(&doff, nrows * 8);
+    hipMemset(dA, 0, (size_t)Z * M * K * 4); hipMemset(dB, 0, nB * 4);
+    hipMemcpy(doff, off.data(), nrows * 8, hipMemcpyHostToDevice);
+    SgemmArgs a{dA, dB, dC, nullptr, M, N, K, K, 0, N, bk ? (long long)64 * L : 0, (long long)64 * L, (long long)nsplit * M * N, (long long)M * N,
+                nsplit, ((K + nsplit - 1) / nsplit + 15) / 16 * 16, 0, doff};
+    if (bk) a.lda = L;
+    hipEvent_t e0, e1;
+    hipEventCreate(&e0); hipEventCreate(&e1);
+    for (int i = 0; i < 3; ++i) sgemm_f32_rows64(0, bk, a, Z);
+    hipEventRecord(e0, 0);
+    const int reps = 20;
+    for (int i = 0; i < reps; ++i) sgemm_f32_rows64(0, bk, a, Z);
+    hipEventRecord(e1, 0);
+    hipEventSynchronize(e1);
+    float ms;
+    hipEventElapsedTime(&ms, e0, e1);
+    ms /= reps;
+    printf("%-34s M %5d N %5d K %5d Z %d split %d: %.3f ms  %.1f TF/s\n", name, M, N, K, Z, nsplit, ms, 2.0 * M * N * K * Z / ms / 1e9);
+    hipFree(dA); hipFree(dB); hipFree(dC); hipFree(doff);
+}
+
 int main()
 {
+    printf("rows64: BK %.2e  free-contig %.2e  BK split3 %.2e  edges %.2e\n", check_rows(true, 64, 192, 100, 1), check_rows(false, 64, 200, 96, 1),
+           check_rows(true, 50, 130, 333, 3), check_rows(false, 40, 70, 50, 1));
+    time_rows("gram fwd  R = X Xshift^T (13 d)", true, 64, 832, 32400, 8, 8, 32400);
+    time_rows("gram fwd  (25 d)", true, 64, 1600, 32400, 8, 8, 32400);
+    time_rows("gram bwd  dX = K1 Xshift (25 d)", false, 64, 32400, 1600, 8, 1, 32400);
     printf("max abs err  NN %.2e  NT-ish(ak) %.2e  TN(bk only) %.2e  (ak,bk) split3 %.2e  edges %.2e\n",
            check(false, false, 256, 384, 64, 2, 1), check(true, false, 256, 256, 80, 1, 1), check(false, true, 128, 256, 48, 2, 1),
            check(true, true, 256, 384, 200, 2, 3), check(true, false, 200, 100, 40, 1, 1));
