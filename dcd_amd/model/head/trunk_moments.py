@@ -109,7 +109,7 @@ class _ShiftCorr(torch.autograd.Function):
             dev = x.device
             off = _const(("fwd", C, Lp, Wp, str(dev)), lambda: torch.tensor(
                 [c * Lp + dy * Wp + dx for (dy, dx) in HALF for c in range(C)], dtype=torch.int64, device=dev))
-            nsplit = max(1, min(8, Lp // 2048))          # fp32 partial sums of <= ~4000 products, summed in fp64
+            nsplit = max(1, min(16, Lp // 1024))         # fp32 partial sums of ~2000 products, summed in fp64; 832 workgroups at 96x320
             part = torch.empty((B * nsplit, C, len(HALF) * C), dtype=torch.float32, device=dev)
             st = L.dcd_sgemm_shifted(_lib.stream_of(x), xp.data_ptr(), Lp, C * Lp, xp.data_ptr(), off.data_ptr(), C * Lp, 1, None,
                                      part.data_ptr(), len(HALF) * C, nsplit * C * len(HALF) * C, C * len(HALF) * C,

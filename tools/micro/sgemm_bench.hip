@@ -137,6 +137,8 @@ int main()
     printf("rows64: BK %.2e  free-contig %.2e  BK split3 %.2e  edges %.2e\n", check_rows(true, 64, 192, 100, 1), check_rows(false, 64, 200, 96, 1),
            check_rows(true, 50, 130, 333, 3), check_rows(false, 40, 70, 50, 1));
     time_rows("gram fwd  R = X Xshift^T (13 d)", true, 64, 832, 32400, 8, 8, 32400);
+    time_rows("gram fwd  (13 d) split 16", true, 64, 832, 32400, 8, 16, 32400);
+    time_rows("gram fwd  (13 d) split 24", true, 64, 832, 32400, 8, 24, 32400);
     time_rows("gram fwd  (25 d)", true, 64, 1600, 32400, 8, 8, 32400);
     time_rows("gram bwd  dX = K1 Xshift (25 d)", false, 64, 32400, 1600, 8, 1, 32400);
     printf("max abs err  NN %.2e  NT-ish(ak) %.2e  TN(bk only) %.2e  (ak,bk) split3 %.2e  edges %.2e\n",
