@@ -413,7 +413,7 @@ def run_gmw(args):
                "dtype": "f32", "data": "synthetic",
                "config": {"workload": "GMW train step, %d objects (%d per GPU) x 2628 edges, cls 0.1 + reg 1.0 (GMW/main.py:313-315)" % (
                    per_rank * world, per_rank), "global_batch": per_rank * world, "per_gpu_batch": per_rank, "parallelism": "dp%d" % world},
-               "roofline": {"bound": "mfma", "kernel": "transport-layer backward (S formation, Cholesky, inverse of the factor; library kernels)",
+               "roofline": {"bound": "mfma", "kernel": "transport-layer backward (Schur complement on the MFMA GEMM, blocked Cholesky + substitutions: csrc/spd.hip)",
                             "achieved": flops / 1e12 / (tb_ms / 1e3) if tb_ms > 0 else None, "peak": MFMA_PEAK_TFLOPS["f32"],
                             "unit": "TFLOP/s", "frac": (flops / 1e12 / (tb_ms / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if tb_ms > 0 else None,
                             "traffic": None, "flops": flops, "ms_per_step": tb_ms}}

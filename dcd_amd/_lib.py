@@ -59,6 +59,10 @@ SIGNATURES = {
     "dcd_bn_backward": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int64] + [c_void_p, c_size_t]),
     "dcd_sgemm_shifted": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                   c_int64, c_int64, c_int, c_int, c_int, c_int, c_int]),
+    "dcd_sgemm": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64,
+                          c_int, c_int, c_int, c_int, c_float, c_int, c_int]),
+    "dcd_spd_solve_workspace_bytes": (c_size_t, [c_int, c_int]),
+    "dcd_spd_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
     "dcd_encode_targets": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_double] * 3 + [c_int, c_int, c_void_p, c_int]),
 }
 

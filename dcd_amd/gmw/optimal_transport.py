@@ -6,6 +6,8 @@ one n x n Cholesky factorisation per object; the products are associated so that
 explicit inverse and the two dense blocks the reference builds (see `gradient`).  Only the uniform-marginal case the GMW model
 uses (r, c > 0) is implemented.
 """
+import os
+
 import torch
 
 
@@ -48,21 +50,33 @@ class RegularisedTransportFn(torch.autograd.Function):
             G = lamP[:, 1:, :]
             inv_rows = G.sum(-1).reciprocal()                    # b x (m-1)
             cols = lamP.sum(-2)                                  # b x n
-            S = -G.transpose(-2, -1).matmul(inv_rows.unsqueeze(-1) * G)
-            S.diagonal(dim1=-2, dim2=-1).add_(cols)
-            L = torch.linalg.cholesky(S)
             a = (w.sum(-1)[:, 1:] * inv_rows).unsqueeze(-2)      # b x 1 x (m-1)
             rhs = w.sum(-2).unsqueeze(-2) - a.matmul(G)          # b x 1 x n
-            if P.is_cuda:
-                # y = rhs S^-1 = (rhs L^-T) L^-1.  On this ROCm build batched potrs with one right-hand side faults
-                # (hipErrorLaunchFailure from torch.cholesky_solve on (b, 2628, 1)), two single-column trsm take 8.2 ms
-                # and potri 15.3 ms at b = 8; inverting the triangular factor against the identity takes 5.0 ms
-                # (tools/micro/chol_time.py), followed by two mat-vecs
-                eye = torch.eye(n, dtype=P.dtype, device=P.device).expand(b, n, n)
-                Linv = torch.linalg.solve_triangular(L, eye, upper=False)
-                y = rhs.matmul(Linv.transpose(-2, -1)).matmul(Linv)
+            hip = (P.is_cuda and P.dtype == torch.float32 and n % 4 == 0 and lamP.is_contiguous()
+                   and os.environ.get("DCD_GMW_SOLVER", "hip") == "hip")
+            if hip:
+                # y = rhs S^-1 on our own kernels (csrc/spd.hip): S's lower triangle straight into the solver's buffer (MFMA GEMM,
+                # tiles above the diagonal skipped), blocked Cholesky with 128-wide panels whose panel / trailing updates are the
+                # same GEMM, the right-hand side carried through the factorisation, blocked backward substitution.
+                # The stock route on this ROCm build: MAGMA potrf 8.7 ms for eight 2628^2 systems, then no usable solve --
+                # batched potrs with one right-hand side faults (hipErrorLaunchFailure from torch.cholesky_solve on
+                # (b, 2628, 1)), two single-column trsm take 8.2 ms, potri 15.3 ms, inverting the factor against the identity
+                # 5.0 ms (tools/micro/chol_time.py; kept below as DCD_GMW_SOLVER=stock).
+                from dcd_amd import ops
+                aug = ops.spd_buffer(b, n, P.device)
+                ops.schur_lower(G, inv_rows, cols, aug)
+                aug[:, n] = rhs.squeeze(-2)
+                y = ops.spd_solve_inplace(aug).unsqueeze(-2)
             else:
-                y = torch.cholesky_solve(rhs.transpose(-2, -1), L).transpose(-2, -1)
+                S = -G.transpose(-2, -1).matmul(inv_rows.unsqueeze(-1) * G)
+                S.diagonal(dim1=-2, dim2=-1).add_(cols)
+                L = torch.linalg.cholesky(S)
+                if P.is_cuda:
+                    eye = torch.eye(n, dtype=P.dtype, device=P.device).expand(b, n, n)
+                    Linv = torch.linalg.solve_triangular(L, eye, upper=False)
+                    y = rhs.matmul(Linv.transpose(-2, -1)).matmul(Linv)
+                else:
+                    y = torch.cholesky_solve(rhs.transpose(-2, -1), L).transpose(-2, -1)
             row_mult = a - y.matmul(G.transpose(-2, -1)) * inv_rows.unsqueeze(-2)     # b x 1 x (m-1)
             # A^T [row multipliers; column multipliers] as an m x n field: entry (i, j) = row_mult[i-1] (i >= 1) + y[j]
             field = y.expand(b, m, n).clone()

@@ -273,6 +273,55 @@ def scatter_add_at(fmap, vals, index):
     return _ScatterAddAt.apply(fmap, vals, index)
 
 
+def spd_buffer(b, n, device):
+    """(b, n + 4, n) float32 buffer for `spd_solve_inplace`: rows 0..n-1 take the matrix, row n the right-hand side."""
+    return torch.empty((b, n + 4, n), dtype=torch.float32, device=device)
+
+
+def spd_solve_inplace(aug):
+    """y[b] = S[b]^-1 r[b] with S = aug[b, :n], r = aug[b, n] (see `spd_buffer`); aug is overwritten (Cholesky factor / L^-1 r).
+    Blocked Cholesky + substitutions on csrc/spd.hip; no host synchronisation (a matrix that is not positive definite yields a
+    meaningless y instead of the exception torch.linalg.cholesky raises)."""
+    _lib.require_cuda(aug)
+    b, rows, n = aug.shape
+    if aug.dtype != torch.float32 or not aug.is_contiguous() or rows < n + 1:
+        raise RuntimeError("spd_solve_inplace: a contiguous float32 (b, >= n + 1, n) buffer is required")
+    L = _lib.lib()
+    nbytes = L.dcd_spd_solve_workspace_bytes(b, n)
+    ws = torch.empty(nbytes, dtype=torch.uint8, device=aug.device)
+    y = torch.empty((b, n), dtype=torch.float32, device=aug.device)
+    st = L.dcd_spd_solve(_lib.stream_of(aug), aug.data_ptr(), y.data_ptr(), b, n, rows, None, ws.data_ptr(), nbytes)
+    _lib.check(st, "dcd_spd_solve")
+    return y
+
+
+def spd_solve(S, rhs):
+    """y[b] = S[b]^-1 rhs[b] for symmetric positive definite S (b, n, n) fp32 with n % 4 == 0 and rhs (b, n); S is left intact."""
+    _lib.require_cuda(S, rhs)
+    if S.dtype != torch.float32 or S.dim() != 3 or S.shape[1] != S.shape[2]:
+        raise RuntimeError("spd_solve: S must be a float32 (b, n, n) tensor")
+    b, n = S.shape[0], S.shape[1]
+    aug = spd_buffer(b, n, S.device)
+    aug[:, :n] = S
+    aug[:, n] = rhs.reshape(b, n)
+    return spd_solve_inplace(aug)
+
+
+def schur_lower(G, inv_rows, cols, out):
+    """out[b, :n, :n] (lower triangle and the tiles on the diagonal) = diag(cols[b]) - G[b]^T diag(inv_rows[b]) G[b] for
+    G (b, m, n) fp32 (a view whose rows are n apart), on our own GEMM with the upper tiles skipped."""
+    _lib.require_cuda(G, inv_rows, cols, out)
+    b, m, n = G.shape
+    if G.stride(2) != 1 or G.stride(1) != n or (G.stride(0) & 3) or (G.data_ptr() & 15):
+        raise RuntimeError("schur_lower: G must be row-contiguous with row stride n")
+    DG = (inv_rows.unsqueeze(-1) * G).contiguous()
+    st = _lib.lib().dcd_sgemm(_lib.stream_of(G), G.data_ptr(), n, G.stride(0), 0, DG.data_ptr(), n, m * n, 0,
+                              out.data_ptr(), n, out.stride(0), n, n, m, b, -1.0, 0, 1)
+    _lib.check(st, "dcd_sgemm")
+    out[:, :n].diagonal(dim1=-2, dim2=-1).add_(cols)
+    return out
+
+
 def iou_3d(pred_corners, target_corners):
     """(N,8,3) x (N,8,3) -> (N) 3-D IoU (BEV rectangle overlap x height overlap); no gradient."""
     _lib.require_cuda(pred_corners, target_corners)

@@ -168,6 +168,28 @@ int dcd_sgemm_shifted(void *stream, const float *A, int lda, long long strideA, 
                       long long strideB, int b_kcontig, const float *bias, float *C, int ldc, long long strideC,
                       long long strideCs, int M, int N, int K, int Z, int nsplit);
 
+/* Batched fp32 GEMM on the matrix pipe (csrc/sgemm_f32.inc, 128 x 128 tiles):
+ *     C[z] (M x N, row-major, ldc) = alpha * A[z] B[z]  (+ C[z] when accumulate)
+ *     A(m,k) = a_kcontig ? A[m*lda + k] : A[k*lda + m]        B(k,n) = b_kcontig ? B[n*ldb + k] : B[k*ldb + n]
+ * lower_only: tiles entirely above the diagonal are skipped (symmetric results; entries above the diagonal of the remaining
+ * tiles are still written).  All pointers 16-byte aligned, lda / ldb / strides multiples of 4.  Used for the Schur complement
+ * S = diag(c) - G^T diag(1/r) G of the transport layer's backward (GMW/lib/optimal_transport.py:93-100), written straight into
+ * the buffer dcd_spd_solve factorises. */
+int dcd_sgemm(void *stream, const float *A, int lda, long long strideA, int a_kcontig, const float *B, int ldb, long long strideB,
+              int b_kcontig, float *C, int ldc, long long strideC, int M, int N, int K, int Z, float alpha, int accumulate,
+              int lower_only);
+
+/* Batched SPD solve  y[b] = S[b]^-1 r[b]  (one right-hand side per matrix) on the fp32 matrix pipe: blocked Cholesky whose panel
+ * and trailing updates are MFMA GEMMs, forward substitution carried along with the factorisation, blocked backward substitution
+ * (csrc/spd.hip).  Replaces `torch.cholesky` + `torch.cholesky_inverse` of the Schur complement in the backward of the
+ * optimal-transport layer (GMW/lib/optimal_transport.py:102-128; n = 2628 edges).
+ *   S: batch x rows x n fp32 (row stride n, rows >= n + 1, 16-byte aligned, n % 4 == 0): rows 0..n-1 = the symmetric positive
+ *   definite matrix (lower triangle read, overwritten by the factor), row n = the right-hand side (overwritten).  y: batch x n.
+ *   info (batch ints, zeroed by the caller, may be NULL): 0, or 1 + the first row of the 128-block in which a pivot was not
+ *   positive (the reference raises there; here y is meaningless for that matrix). */
+size_t dcd_spd_solve_workspace_bytes(int batch, int n);
+int dcd_spd_solve(void *stream, float *S, float *y, int batch, int n, int rows, int *info, void *workspace, size_t workspace_bytes);
+
 /* Context normalisation of GMW's feature extractor (`gcn`, GMW/model/yi2018cvpr/ops.py:5-17): x (rows, K) -> y = (x - mean) /
  * sqrt(var_unbiased + eps) per row, inv (rows) = the scale; backward from (grad_y, y, inv).  rows = batch * channels. */
 int dcd_context_norm_forward(void *stream, const float *x, float *y, float *inv, int rows, int K, float eps);
