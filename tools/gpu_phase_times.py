@@ -1,0 +1,52 @@
+"""GPU time of the phases of a train step (events on the launch stream; no synchronisation inside the step):
+backbone forward | heads + loss forward | backward | clip + AdamW.   python tools/gpu_phase_times.py [--batch 8]"""
+import argparse, os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--batch", type=int, default=8)
+    ap.add_argument("--steps", type=int, default=10)
+    ap.add_argument("--objects", type=int, default=6)
+    ap.add_argument("--precision", default="f32")
+    ap.add_argument("--scaling", default="weak")
+    ap.add_argument("--amp", action="store_true")
+    args = ap.parse_args()
+    import torch
+    import bench
+    from dcd_amd.engine import trainer
+    from dcd_amd.structures.image_list import to_image_list
+    device = torch.device("cuda", 0)
+    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)
+    clip = cfg.SOLVER.GRAD_NORM_CLIP
+    for _ in range(4):
+        trainer.train_step(model, optimizer, images, targets, clip)
+    torch.cuda.synchronize()
+    marks = []
+    for _ in range(args.steps):
+        ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        ev[0].record()
+        features = model.backbone(to_image_list(images).tensors)
+        ev[1].record()
+        loss_dict, _ = model.heads(features, targets)
+        total = getattr(loss_dict, "total", None)
+        losses = total if total is not None else sum(loss_dict.values())
+        ev[2].record()
+        optimizer.zero_grad(set_to_none=True)
+        losses.backward()
+        ev[3].record()
+        trainer.guard_nonfinite_step(optimizer, trainer.clip_grad_norm(trainer._parameters_of(model), clip))
+        optimizer.step()
+        ev[4].record()
+        marks.append(ev)
+    torch.cuda.synchronize()
+    n = len(marks)
+    acc = [sum(e[i].elapsed_time(e[i + 1]) for e in marks) / n for i in range(4)]
+    print("batch %d: GPU ms/step  backbone fwd %.2f | heads+loss fwd %.2f | backward %.2f | clip+adam %.2f | sum %.2f" % (
+        per_rank, acc[0], acc[1], acc[2], acc[3], sum(acc)))
+
+
+if __name__ == "__main__":
+    main()
