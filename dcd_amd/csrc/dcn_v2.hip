@@ -2344,7 +2344,14 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 #ifndef DCN_NO_BWD_TILE
         // tiled grad_input: one 64-channel slice per workgroup; wider inputs re-stage the dY window and re-read the lists per
         // slice and lose to the register-gather kernel (measured: 128->128 1.56 vs 1.48 ms, 256->256 2.25 vs 1.64 ms per backward)
-        const bool bi_tile_ok = tile_shape && nblk <= 2 && H < 65536 && W < 65536 && getenv("DCD_NO_BI_TILE") == nullptr;
+        static int bi_nblk = 0;                                  // A/B: DCD_BI_TILE_NBLK=4 lets the tiled kernel take 128-channel inputs
+        if (bi_nblk == 0) {
+            const char *e = getenv("DCD_BI_TILE_NBLK");
+            bi_nblk = e ? atoi(e) : 2;
+            if (bi_nblk < 1) bi_nblk = 2;
+        }
+        const bool bi_tile_ok = tile_shape && nblk <= bi_nblk && (nblk <= 2 || g.Cop <= 64) && H < 65536 && W < 65536 &&
+                                getenv("DCD_NO_BI_TILE") == nullptr;
 #else
         const bool bi_tile_ok = false;
 #endif

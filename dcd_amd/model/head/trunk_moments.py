@@ -181,7 +181,11 @@ def _border_tables(device):
 
 def patch_moments(x):
     """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above)."""
-    if os.environ.get("DCD_TRUNK_GRAM", "shift") == "bmm" or x.shape[2] < 5 or x.shape[3] < 5:
+    mode = os.environ.get("DCD_TRUNK_GRAM", "auto")
+    # auto: the autocorrelation form pays from ~100k pixels per rank on (its border terms are ~60 small launches: at one
+    # 96x320 image per rank the step is launch-bound and the single bmm is 1 ms faster; at eight images it is 1.7 ms slower)
+    small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 100000
+    if mode == "bmm" or (mode == "auto" and small) or x.shape[2] < 5 or x.shape[3] < 5:
         return patch_moments_gram(x)
     B, C, H, W = x.shape
     R13, total, T, Bt, Lb, Rb = _ShiftCorr.apply(x)

@@ -103,7 +103,8 @@ def test_post_processor_matches_reference(cuda):
     H.check_post_processor(cuda, 1e-4)
 
 
-def test_whole_model_matches_reference(cuda):
+@pytest.mark.parametrize("trunk_form", ["shift", "bmm"])
+def test_whole_model_matches_reference(cuda, monkeypatch, trunk_form):
     """KeypointDetector on the GPU (HIP DCNv2 / Winograd / BN / heads kernels + MIOpen for the remaining convs) against the
     EXACT result: the reference model run in float64 (tests/golden/model_96x320_f64.npz; our shell reproduces that run bit for
     bit on the host, test_float64_model_equals_reference_float64).  Measured on MI355X (tools/model_dist_f64.py): activations
@@ -112,6 +113,7 @@ def test_whole_model_matches_reference(cuda):
     3e-4 on the 13 losses (north_star: 1e-3), 6e-3 on gradient norms -- i.e. the GPU run must stay as close to the exact
     result as the reference's fp32 run is, not merely close to that run."""
     torch.backends.cudnn.benchmark = False
+    monkeypatch.setenv("DCD_TRUNK_GRAM", trunk_form)       # both forms of the trunk statistics (trunk_moments.py; "auto" picks by size)
     H.check_model(cuda, 1e-4, 6e-3, truth="model_96x320_f64", loss_tol=3e-4)
 
 

@@ -36,6 +36,7 @@ def test_moments_equal_patch_matrix_form(cuda, monkeypatch):
     from dcd_amd.model.head import trunk_moments as TM
     torch.manual_seed(1)
     x = torch.randn(2, 64, 24, 40, device=cuda)
+    monkeypatch.setenv("DCD_TRUNK_GRAM", "shift")          # ("auto" picks by size: this input would take the patch form)
     S1a, Ga = TM.patch_moments(x)
     monkeypatch.setenv("DCD_TRUNK_GRAM", "bmm")
     S1b, Gb = TM.patch_moments(x)
