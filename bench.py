@@ -145,10 +145,9 @@ def run_gpu(args):
     clip = cfg.SOLVER.GRAD_NORM_CLIP
 
     # DCD_STEP_GRAPH=1 (one process only): the whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep).
-    # EXPERIMENTAL and off by default: on this ROCm stack memset nodes inside a captured graph are not reliably ordered before
-    # the kernel that follows (profiles/r02_graph_memset_hazard.txt); our own kernels no longer use them, but ATen's multi-block
-    # reductions and library kernels in the backward do, and at 384x1280 the second replay faults.  The loss section's own
-    # graph (free of such nodes since round 2) stays on.
+    # Opt-in: at bs 8 the GPU is the limit either way (52.95 vs 53.1 ms); at one image per GPU it is 21.4 -> 17.7 ms
+    # (tools/check_step_graph.py compares its loss trajectory with eager steps at full size).  The loss section's own graph is
+    # always on.
     force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
     use_graph = world == 1 and not force_ddp and os.environ.get("DCD_STEP_GRAPH", "0") == "1"
     if use_graph:
