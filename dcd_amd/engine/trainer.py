@@ -295,10 +295,12 @@ class GraphedTrainStep:
     gradient collectives would have to be captured too -- `train_step` is used there.  Returned loss tensors are the graph's
     static outputs (read them before the next call).
 
-    EXPERIMENTAL (round 2): correct at 96x320 (tests/test_gpu_golden.py, opt-in), but at 384x1280 the second replay faults on
-    this ROCm stack -- memset nodes inside a captured graph are not reliably ordered before the kernel that follows
-    (profiles/r02_graph_memset_hazard.txt); ours are gone (csrc/zero_fill.h), ATen's multi-block reductions and library kernels
-    in the backward still issue them.  bench.py therefore uses it only with DCD_STEP_GRAPH=1."""
+    Opt-in (bench.py: DCD_STEP_GRAPH=1).  Checked at 96x320 against eager steps (tests/test_gpu_golden.py, opt-in) and at
+    384x1280 over eight steps (tools/check_step_graph.py: same loss trajectory, parameter distance equal to the distance between
+    two eager runs).  Earlier in round 2 the second replay faulted at full size; it stopped when the last per-step
+    host-to-device constants left the step.  Flat multi-block ATen reductions inside a captured graph did return wrong sums on
+    this stack (profiles/r02_graph_memset_hazard.txt), so the graphed loss uses two-stage sums and our kernels zero-fill with
+    kernels (csrc/zero_fill.h)."""
 
     def __init__(self, model, optimizer, grad_norm_clip=15.0, warmup=2):
         self.model, self.optimizer, self.clip, self.warmup = model, optimizer, grad_norm_clip, warmup
