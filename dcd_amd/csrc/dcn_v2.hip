@@ -1018,8 +1018,10 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
             if (st < nsteps) compute(ga, wa, st);
         };
         (void)row2;
-        if (mu <= 4) run(IntC<4>{});
+        if (mu <= 2) run(IntC<2>{});
+        else if (mu <= 4) run(IntC<4>{});
         else if (mu <= 6) run(IntC<6>{});
+        else if (mu <= 8) run(IntC<8>{});
         else run(IntC<INV_CAP>{});
     }
 
@@ -1207,8 +1209,10 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
                 }
             };
             const int mu = __builtin_amdgcn_readfirstlane(maxc);
-            if (mu <= 4) run(IntC<4>{});
+            if (mu <= 2) run(IntC<2>{});
+            else if (mu <= 4) run(IntC<4>{});
             else if (mu <= 6) run(IntC<6>{});
+            else if (mu <= 8) run(IntC<8>{});
             else run(IntC<INV_CAP>{});
         }
     }
