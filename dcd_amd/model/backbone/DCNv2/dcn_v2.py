@@ -43,10 +43,13 @@ def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, de
     the op itself stays an fp32 op like the reference's (its extension reads `.data<float>()`, cuda/dcn_v2_cuda.cu:58):
     half-precision activations are cast back to fp32 at its boundary, and the weight contraction may then take the split-bf16
     matrix path (DCD_PREC_BF16X3: fp32 in, fp32 out, ~2^-16 per product), which is what a reduced-precision run is for."""
-    if input.is_cuda and torch.is_autocast_enabled():
-        with torch.autocast(device_type="cuda", enabled=False):
-            return _DCNv2.apply(input.float(), offset.float(), mask.float(), weight.float(), bias.float(), stride, padding,
-                                dilation, deformable_groups, "bf16x3")
+    dev = input.device.type
+    if torch.is_autocast_enabled(dev):
+        with torch.autocast(device_type=dev, enabled=False):
+            args = (input.float(), offset.float(), mask.float(), weight.float(), bias.float(), stride, padding, dilation,
+                    deformable_groups)
+            # the split-bf16 contraction exists on the device only; the host-logic tests run the fp32 oracle behind the cast
+            return _DCNv2.apply(*args, "bf16x3") if input.is_cuda else _DCNv2.apply(*args)
     return _DCNv2.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)
 
 

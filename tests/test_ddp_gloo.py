@@ -132,6 +132,76 @@ def test_sync_bn_two_ranks_equal_full_batch(tmp_path):
         assert torch.load(os.path.join(str(tmp_path), "s%d.pt" % r))["ok"]
 
 
+def _config3_worker(rank, world, port, out_dir):
+    """BASELINE configs[2] in miniature: DDP + SyncBN + MODEL.FP16 (bf16 autocast), one image per rank."""
+    sys.path.insert(0, ROOT)
+    sys.path.insert(0, os.path.join(ROOT, "tests"))
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    import cpu_syncbn
+    from dcd_amd import ops
+    from dcd_amd.model.backbone.DCNv2 import dcn_v2
+    from oracle import dcn_oracle, torch_ops
+    for name in ("pairs_kpts_depth", "compute_z", "focal_loss", "giou_loss", "nms_hm", "select_topk",
+                 "select_point_of_interest", "iou_3d"):
+        setattr(ops, name, getattr(torch_ops, name))
+    dcn_v2._backend = dcn_oracle
+    cpu_syncbn.install()
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step, wrap_distributed
+    from dcd_amd.model.detector import KeypointDetector
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", True, "MODEL.FP16", True,
+                        "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).train()
+    init_like_trained(model)
+    ddp = wrap_distributed(model, cfg, local_rank=rank)
+    opt = build_optimizer(ddp, cfg)
+    images, targets = make_batch(1, seed=20 + rank, n_objects=3, input_size=(320, 96))
+    losses = []
+    for _ in range(2):
+        ld, _ = train_step(ddp, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+        total = getattr(ld, "total", None)
+        losses.append(float(total if total is not None else sum(ld.values())))
+    flat = torch.cat([p.detach().flatten() for p in ddp.parameters()])
+    # (the two BatchNorm1d of the edge-fusion branch become torch SyncBatchNorm on the GPU only -- torch has no CPU SyncBN,
+    # engine.trainer.enable_sync_bn -- so their statistics are local in this host test and left out of the comparison)
+    named = [(n, b.detach().flatten().float()) for n, b in ddp.named_buffers() if "running" in n and ".trunc_" not in n]
+    stats = torch.cat([b for _, b in named])
+    others = [torch.zeros_like(flat) for _ in range(world)]
+    dist.all_gather(others, flat)
+    others_s = [torch.zeros_like(stats) for _ in range(world)]
+    dist.all_gather(others_s, stats)
+    worst = ""
+    if rank == 0:
+        off, diffs = 0, []
+        for n, b in named:
+            d = (others_s[0][off:off + b.numel()] - others_s[1][off:off + b.numel()]).abs().max().item()
+            diffs.append((d, n))
+            off += b.numel()
+        worst = str(sorted(diffs, reverse=True)[:4])
+    torch.save({"worst": worst, "finite": all(l == l and abs(l) < 1e6 for l in losses) and bool(torch.isfinite(flat).all()),
+                "same": all(torch.equal(others[0], o) for o in others),
+                "same_stats": all(torch.allclose(others_s[0], o, atol=1e-6) for o in others_s)},
+               os.path.join(out_dir, "c%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_config3_ddp_syncbn_fp16_two_ranks(tmp_path, oracle_dcn):
+    """DDP + SyncBN + bf16 autocast together (what `bench.py --gpus 4 --amp` runs over RCCL): two steps on two gloo ranks keep
+    the replicas identical (parameters bit for bit, running statistics), finite losses."""
+    port = _free_port()
+    mp.spawn(_config3_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    for r in range(2):
+        res = torch.load(os.path.join(str(tmp_path), "c%d.pt" % r))
+        assert res["finite"] and res["same"] and res["same_stats"], res
+
+
 def _gmw_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     sys.path.insert(0, os.path.join(ROOT, "tests", "golden"))
