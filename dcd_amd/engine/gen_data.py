@@ -11,6 +11,8 @@ takes the files unchanged.
 import json
 import os
 
+import torch
+
 
 def dump_gen_data_train(loss_evaluator, out_dir="gen_data"):
     os.makedirs(out_dir, exist_ok=True)
@@ -22,15 +24,21 @@ def dump_gen_data_train(loss_evaluator, out_dir="gen_data"):
 
 def infer_records(output, visualize_preds, cat="Car"):
     """One image's detections (N,14) + the PostProcessor's `gen_*` tensors -> list of GMW records."""
-    out = output.detach().cpu()
-    k2 = visualize_preds['gen_pred_extra_kpts_2d'].detach().cpu()
-    k3 = visualize_preds['gen_pred_extra_kpts_3d'].detach().cpu()
+    n = output.shape[0]
+    k2, k3 = visualize_preds['gen_pred_extra_kpts_2d'], visualize_preds['gen_pred_extra_kpts_3d']
+    nk = k2.shape[1] if n else 0
+    if n == 0:
+        return []
+    # one packed device buffer, one device-to-host copy for the whole image (SURVEY 8f-2)
+    f32 = output.dtype
+    packed = torch.cat((output.detach(), k2.detach().reshape(n, nk * 2).to(f32), k3.detach().reshape(n, nk * 3).to(f32)), dim=1).cpu().numpy()
+    out, k2h, k3h = packed[:, :14], packed[:, 14:14 + nk * 2].reshape(n, nk, 2), packed[:, 14 + nk * 2:].reshape(n, nk, 3)
     recs = []
-    for i in range(out.shape[0]):
-        recs.append({'kpts_2d': k2[i].numpy().tolist(), 'kpts_3d': k3[i].numpy().tolist(),
-                     'pred_rot': out[i][12:13].numpy().tolist(), 'box': out[i][2:6].numpy().tolist(),
-                     'dim': out[i][6:9].numpy().tolist(), 'pred_location': out[i][9:12].numpy().tolist(),
-                     'score': out[i][13:14].numpy().tolist(), 'cat': cat})
+    for i in range(n):
+        recs.append({'kpts_2d': k2h[i].tolist(), 'kpts_3d': k3h[i].tolist(),
+                     'pred_rot': out[i][12:13].tolist(), 'box': out[i][2:6].tolist(),
+                     'dim': out[i][6:9].tolist(), 'pred_location': out[i][9:12].tolist(),
+                     'score': out[i][13:14].tolist(), 'cat': cat})
     return recs
 
 

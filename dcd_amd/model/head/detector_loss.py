@@ -125,16 +125,26 @@ class Loss_Computation():
                             device=pred_extra_kpts_2D_img.device)
         kps = pred_extra_kpts_2D_img
         kn = torch.stack(((kps[:, :, 0] - K[0, 2]) / K[0, 0], (kps[:, :, 1] - K[1, 2]) / K[1, 1]), dim=-1)
-        self.gen_data['kpts_2d'].append(kn.detach().cpu().numpy().tolist())
-        self.gen_data['kpts_3d'].append(pred_extra_kpts_3D_real.detach().cpu().numpy().tolist())
-        counts = reg_mask_gt.sum(-1).tolist()
+        # one device buffer per iteration, ONE device-to-host copy: [k2 (K*2) | k3 (K*3) | roty | gt xyz | pred xyz | count row]
+        n, nk = kn.shape[0], kn.shape[1]
+        f32 = torch.float32
+        rows = torch.cat((kn.detach().reshape(n, nk * 2).to(f32), pred_extra_kpts_3D_real.detach().reshape(n, nk * 3).to(f32),
+                          pred_rotys_3D.detach().reshape(n, 1).to(f32), target_locations_3D.detach().reshape(n, 3).to(f32),
+                          pred_locations_3D.detach().reshape(n, 3).to(f32)), dim=1)
+        counts_row = torch.zeros((1, rows.shape[1]), dtype=f32, device=rows.device)
+        cnt = reg_mask_gt.sum(-1).to(f32)
+        counts_row[0, :cnt.numel()] = cnt
+        host = torch.cat((rows, counts_row)).cpu().numpy()
+        body, counts = host[:n], host[n, :cnt.numel()]
+        self.gen_data['kpts_2d'].append(body[:, :nk * 2].reshape(n, nk, 2).tolist())
+        self.gen_data['kpts_3d'].append(body[:, nk * 2:nk * 5].reshape(n, nk, 3).tolist())
         ids = []
-        for i, num in enumerate(counts):
+        for i, num in enumerate(counts.tolist()):
             ids += [targets_variables['img_idx'][i]] * int(num)
         self.gen_data['img_idx'].append(ids)
-        self.gen_data['pred_rot'].append(pred_rotys_3D.detach().cpu().numpy().tolist())
-        self.gen_data['gt_location'].append(target_locations_3D.detach().cpu().numpy().tolist())
-        self.gen_data['pred_location'].append(pred_locations_3D.detach().cpu().numpy().tolist())
+        self.gen_data['pred_rot'].append(body[:, nk * 5].tolist())
+        self.gen_data['gt_location'].append(body[:, nk * 5 + 1:nk * 5 + 4].tolist())
+        self.gen_data['pred_location'].append(body[:, nk * 5 + 4:nk * 5 + 7].tolist())
 
     # ------------------------------------------------------------------------------------------
     def compute_pairs_kpts_loss(self, preds, pred_targets, batch_weight):
