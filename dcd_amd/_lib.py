@@ -57,6 +57,8 @@ SIGNATURES = {
     "dcd_bn_train_forward": (c_int, [c_void_p] * 8 + [c_float, c_float, c_int] + [c_void_p] * 3 + [c_int, c_int, c_int64]
                              + [c_void_p, c_size_t]),
     "dcd_bn_backward": (c_int, [c_void_p] * 11 + [c_int, c_int, c_int64] + [c_void_p, c_size_t]),
+    "dcd_dcn_offset_mask_split": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
+    "dcd_dcn_offset_mask_merge": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "dcd_sgemm_shifted": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_void_p, c_void_p, c_int64, c_int, c_void_p, c_void_p, c_int,
                                   c_int64, c_int64, c_int, c_int, c_int, c_int, c_int]),
     "dcd_sgemm": (c_int, [c_void_p, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64, c_int, c_void_p, c_int, c_int64,

@@ -2071,6 +2071,67 @@ inline int pick_mb(int nb, int tiles_total)
 
 }  // namespace
 
+namespace {
+
+// DCN.forward's glue (dcn_v2.py:118-123): out (B, 3T, HW) of conv_offset_mask -> offset = its first 2T channels (contiguous copy),
+// mask = sigmoid of the last T; and the adjoint.  One launch each instead of slice copy + sigmoid (forward) and two zero-fills,
+// two slice copies, sigmoid backward and an accumulation (backward).  grid.x covers B * 3T * HW / 4 (HW % 4 == 0) or scalars.
+template <int V>
+__global__ void dcn_offset_mask_split(const float *__restrict__ out, float *__restrict__ offset, float *__restrict__ mask, int B, int T,
+                                      int64_t HW)
+{
+    const int64_t per_img = (int64_t)3 * T * HW / V, n = (int64_t)B * per_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_img, r = (i - b * per_img) * V;       // r = c * HW + p
+        const bool is_off = r < (int64_t)2 * T * HW;
+        float *dst = is_off ? offset + b * 2 * T * HW + r : mask + b * T * HW + (r - (int64_t)2 * T * HW);
+        if (V == 4) {
+            f32x4 v = *reinterpret_cast<const f32x4 *>(out + b * 3 * T * HW + r);
+            if (!is_off) {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = 1.f / (1.f + __expf(-v[j]));
+            }
+            *reinterpret_cast<f32x4 *>(dst) = v;
+        } else {
+            const float v = out[b * 3 * T * HW + r];
+            *dst = is_off ? v : 1.f / (1.f + __expf(-v));
+        }
+    }
+}
+
+template <int V>
+__global__ void dcn_offset_mask_merge(const float *__restrict__ goff, const float *__restrict__ gmask, const float *__restrict__ mask,
+                                      float *__restrict__ gout, int B, int T, int64_t HW)
+{
+    const int64_t per_img = (int64_t)3 * T * HW / V, n = (int64_t)B * per_img;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t b = i / per_img, r = (i - b * per_img) * V;
+        const bool is_off = r < (int64_t)2 * T * HW;
+        const int64_t rm = r - (int64_t)2 * T * HW;
+        if (V == 4) {
+            f32x4 v;
+            if (is_off) v = *reinterpret_cast<const f32x4 *>(goff + b * 2 * T * HW + r);
+            else {
+                const f32x4 g = *reinterpret_cast<const f32x4 *>(gmask + b * T * HW + rm);
+                const f32x4 m = *reinterpret_cast<const f32x4 *>(mask + b * T * HW + rm);
+#pragma unroll
+                for (int j = 0; j < 4; ++j) v[j] = g[j] * m[j] * (1.f - m[j]);
+            }
+            *reinterpret_cast<f32x4 *>(gout + b * 3 * T * HW + r) = v;
+        } else {
+            float v;
+            if (is_off) v = goff[b * 2 * T * HW + r];
+            else {
+                const float m = mask[b * T * HW + rm];
+                v = gmask[b * T * HW + rm] * m * (1.f - m);
+            }
+            gout[b * 3 * T * HW + r] = v;
+        }
+    }
+}
+
+}  // namespace
+
 #include "dcn_dense.inc"
 
 extern "C" {
@@ -2492,6 +2553,36 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         else DCD_LAUNCH_BW(1);
 #undef DCD_LAUNCH_BW
     }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_dcn_offset_mask_split(void *stream_, const float *out, float *offset, float *mask, int B, int taps, int64_t HW)
+{
+    (void)hipGetLastError();
+    if (!out || !offset || !mask || B <= 0 || taps <= 0 || HW <= 0) return DCD_ERR_BAD_ARG;
+    const bool v4 = (HW & 3) == 0 && (((uintptr_t)out | (uintptr_t)offset | (uintptr_t)mask) & 15) == 0;
+    const int64_t n = (int64_t)B * 3 * taps * HW / (v4 ? 4 : 1);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (v4) hipLaunchKernelGGL(dcn_offset_mask_split<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, out, offset, mask, B, taps, HW);
+    else hipLaunchKernelGGL(dcn_offset_mask_split<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, out, offset, mask, B, taps, HW);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_dcn_offset_mask_merge(void *stream_, const float *grad_offset, const float *grad_mask, const float *mask, float *grad_out, int B,
+                              int taps, int64_t HW)
+{
+    (void)hipGetLastError();
+    if (!grad_offset || !grad_mask || !mask || !grad_out || B <= 0 || taps <= 0 || HW <= 0) return DCD_ERR_BAD_ARG;
+    const bool v4 = (HW & 3) == 0 &&
+                    (((uintptr_t)grad_offset | (uintptr_t)grad_mask | (uintptr_t)mask | (uintptr_t)grad_out) & 15) == 0;
+    const int64_t n = (int64_t)B * 3 * taps * HW / (v4 ? 4 : 1);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 8192 ? (n + 255) / 256 : 8192);
+    if (v4)
+        hipLaunchKernelGGL(dcn_offset_mask_merge<4>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, grad_offset, grad_mask, mask, grad_out,
+                           B, taps, HW);
+    else
+        hipLaunchKernelGGL(dcn_offset_mask_merge<1>, dim3(grid), dim3(256), 0, (hipStream_t)stream_, grad_offset, grad_mask, mask, grad_out,
+                           B, taps, HW);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

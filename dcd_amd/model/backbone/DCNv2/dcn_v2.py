@@ -5,6 +5,7 @@
 State-dict keys are the reference's: `weight`, `bias`, `conv_offset_mask.{weight,bias}`.
 """
 import math
+import os
 
 import torch
 from torch import nn
@@ -36,6 +37,39 @@ class _DCNv2(Function):
                                          *ctx.geometry, **ctx.precision)
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = grads
         return (grad_input, grad_offset, grad_mask, grad_weight, grad_bias) + (None,) * 5
+
+
+_FUSED_GLUE = os.environ.get("DCD_OFFSET_MASK_FUSED", "1") != "0"      # 0: slice + sigmoid through stock ops (A/B timing)
+
+
+class _OffsetMask(torch.autograd.Function):
+    """out (B, 3T, H, W) of `conv_offset_mask` -> (offset (B, 2T, H, W) contiguous, mask = sigmoid(last T channels)); the backward
+    assembles grad_out in one pass (csrc/dcn_v2.hip: dcn_offset_mask_split / _merge)."""
+
+    @staticmethod
+    def forward(ctx, out):
+        from dcd_amd import _lib
+        B, C3, H, W = out.shape
+        T = C3 // 3
+        offset = torch.empty((B, 2 * T, H, W), dtype=out.dtype, device=out.device)
+        mask = torch.empty((B, T, H, W), dtype=out.dtype, device=out.device)
+        st = _lib.lib().dcd_dcn_offset_mask_split(_lib.stream_of(out), out.data_ptr(), offset.data_ptr(), mask.data_ptr(), B, T, H * W)
+        _lib.check(st, "dcd_dcn_offset_mask_split")
+        ctx.save_for_backward(mask)
+        return offset, mask
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, goff, gmask):
+        from dcd_amd import _lib
+        (mask,) = ctx.saved_tensors
+        B, T, H, W = mask.shape
+        goff, gmask = goff.contiguous(), gmask.contiguous()
+        gout = torch.empty((B, 3 * T, H, W), dtype=mask.dtype, device=mask.device)
+        st = _lib.lib().dcd_dcn_offset_mask_merge(_lib.stream_of(mask), goff.data_ptr(), gmask.data_ptr(), mask.data_ptr(),
+                                                  gout.data_ptr(), B, T, H * W)
+        _lib.check(st, "dcd_dcn_offset_mask_merge")
+        return gout
 
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
@@ -99,7 +133,10 @@ class DCN(DCNv2):
         out = self.conv_offset_mask(input)
         taps2 = out.shape[1] // 3 * 2
         # chunk(3) then cat(o1, o2) is the identity on the first 2/3 of the channels (dcn_v2.py:120-121)
-        offset = out[:, :taps2]
-        mask = torch.sigmoid(out[:, taps2:])
+        if out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and _FUSED_GLUE:
+            offset, mask = _OffsetMask.apply(out)               # one launch (and one in the backward) instead of eight
+        else:
+            offset = out[:, :taps2]
+            mask = torch.sigmoid(out[:, taps2:])
         return dcn_v2_conv(input, offset, mask, self.weight, self.bias, self.stride, self.padding, self.dilation,
                            self.deformable_groups)

@@ -155,6 +155,14 @@ int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corne
  * head trunks (DGDE/model/head/detector_predictor.py:149-160 call every trunk on the same `features`). */
 int dcd_sum_tensors(void *stream, const float *const *srcs, int n, float *out, int64_t numel);
 
+/* The glue between `conv_offset_mask` and the deformable convolution in `DCN.forward` (DGDE/model/backbone/DCNv2/dcn_v2.py:118-123:
+ * chunk into o1, o2, mask; offset = cat(o1, o2); mask = sigmoid(mask)) and its adjoint, one launch each.
+ *   split: out (B, 3*taps, HW) -> offset (B, 2*taps, HW) = the first 2*taps channels, mask (B, taps, HW) = sigmoid of the rest
+ *   merge: grad_out (B, 3*taps, HW) = [grad_offset | grad_mask * mask * (1 - mask)]                       (taps = dg * kh * kw) */
+int dcd_dcn_offset_mask_split(void *stream, const float *out, float *offset, float *mask, int B, int taps, int64_t HW);
+int dcd_dcn_offset_mask_merge(void *stream, const float *grad_offset, const float *grad_mask, const float *mask, float *grad_out, int B,
+                              int taps, int64_t HW);
+
 /* Batched fp32 product on the matrix pipe whose second operand is a set of SHIFTED VIEWS of one buffer:
  *     C[z][s] (M x N, row-major, ldc) = A[z] (M x K, row-major, lda) * B[z] (K x N)   over k in split s,   (+ bias[m] when nsplit == 1)
  *     B[z](k, n) = b_kcontig ? Bbase[z*strideB + b_off[n] + k] : Bbase[z*strideB + b_off[k] + n]

@@ -373,6 +373,27 @@ def test_local_search_radius_of_the_inverse_lists(cuda, oracle_dcn, monkeypatch,
         close(g_, r_, 5e-5, "local radius %s jump %s dense %s" % (name, jump, dense))
 
 
+@pytest.mark.parametrize("shape", [(2, 27, 12, 20), (3, 54, 7, 9), (8, 27, 96, 320)])
+def test_offset_mask_glue_matches_stock_ops(cuda, shape):
+    """DCN.forward's chunk / cat / sigmoid between conv_offset_mask and the deformable convolution as one kernel each way
+    (dcn_offset_mask_split / _merge) against the stock slicing + sigmoid and their autograd."""
+    from dcd_amd.model.backbone.DCNv2.dcn_v2 import _OffsetMask
+    g = torch.Generator().manual_seed(17)
+    out = (torch.randn(shape, generator=g) * 2).to(cuda)
+    T = shape[1] // 3
+    a = out.clone().requires_grad_(True)
+    off_a, m_a = _OffsetMask.apply(a)
+    b = out.clone().requires_grad_(True)
+    off_b, m_b = b[:, :2 * T], torch.sigmoid(b[:, 2 * T:])
+    assert off_a.is_contiguous() and torch.equal(off_a, off_b)
+    assert (m_a - m_b).abs().max().item() <= 2e-7
+    w1 = torch.randn(off_a.shape, generator=g).to(cuda)
+    w2 = torch.randn(m_a.shape, generator=g).to(cuda)
+    ((off_a * w1).sum() + (m_a * w2).sum()).backward()
+    ((off_b * w1).sum() + (m_b * w2).sum()).backward()
+    assert (a.grad - b.grad).abs().max().item() <= 1e-6 * b.grad.abs().max().item()
+
+
 def test_errors_raise(cuda):
     from dcd_amd import _ext
     x, w, b, off, m, gy = (t.to(cuda) for t in make_case(1, 4, 4, 5, 5))
