@@ -18,7 +18,7 @@ namespace {
 // grid = (ceil(Ho*Wo / 1024), B*C); 256 threads x 4 outputs (consecutive X)
 template <int F>
 __global__ __launch_bounds__(256) void up_dw_fwd(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
-                                                 int C, int H, int W)
+                                                 int C, int H, int W, const float *__restrict__ skip)
 {
     constexpr int K = 2 * F, P = F / 2;
     __shared__ float ws[K * K];
@@ -49,6 +49,10 @@ __global__ __launch_bounds__(256) void up_dw_fwd(const float *__restrict__ x, co
             if (ix0 >= 0) acc += xp[iy0 * W + ix0] * ws[ky0 * K + kx0];
         }
         out[u] = acc;
+    }
+    if (skip) {                                               // IDAUp: node(up(x) + skip) -- the sum leaves this kernel
+        const float4 sk = *reinterpret_cast<const float4 *>(skip + (size_t)plane * Ho * Wo + o0);
+        out[0] += sk.x; out[1] += sk.y; out[2] += sk.z; out[3] += sk.w;
     }
     *reinterpret_cast<float4 *>(yp + o0) = make_float4(out[0], out[1], out[2], out[3]);
 }
@@ -98,18 +102,30 @@ __global__ __launch_bounds__(256) void up_dw_bwd(const float *__restrict__ x, co
 
 extern "C" {
 
-int dcd_upsample_dw_forward(void *stream_, const float *x, const float *weight, float *y, int B, int C, int H, int W, int f)
+static int upsample_forward(hipStream_t stream, const float *x, const float *weight, const float *skip, float *y, int B, int C, int H,
+                            int W, int f)
 {
-    hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (!x || !weight || !y || B <= 0 || C <= 0 || H <= 0 || W <= 0 || (int64_t)B * C > 65535) return DCD_ERR_BAD_ARG;
     if ((f != 2 && f != 4 && f != 8) || ((W * f) & 3)) return DCD_ERR_BAD_ARG;
     const int no = H * f * W * f;
     dim3 grid((no / 4 + 255) / 256, B * C), block(256);
-    if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W);
-    else if (f == 4) hipLaunchKernelGGL(up_dw_fwd<4>, grid, block, 0, stream, x, weight, y, C, H, W);
-    else hipLaunchKernelGGL(up_dw_fwd<8>, grid, block, 0, stream, x, weight, y, C, H, W);
+    if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
+    else if (f == 4) hipLaunchKernelGGL(up_dw_fwd<4>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
+    else hipLaunchKernelGGL(up_dw_fwd<8>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_upsample_dw_forward(void *stream_, const float *x, const float *weight, float *y, int B, int C, int H, int W, int f)
+{
+    return upsample_forward((hipStream_t)stream_, x, weight, nullptr, y, B, C, H, W, f);
+}
+
+int dcd_upsample_dw_forward_add(void *stream_, const float *x, const float *weight, const float *skip, float *y, int B, int C, int H,
+                                int W, int f)
+{
+    if (!skip) return DCD_ERR_BAD_ARG;
+    return upsample_forward((hipStream_t)stream_, x, weight, skip, y, B, C, H, W, f);
 }
 
 int dcd_upsample_dw_backward(void *stream_, const float *x, const float *weight, const float *grad_y, float *grad_x,

@@ -206,8 +206,11 @@ class IDAUp(nn.Module):
     def forward(self, layers, startp, endp):
         for i in range(startp + 1, endp):
             k = str(i - startp)
-            layers[i] = getattr(self, "up_" + k)(getattr(self, "proj_" + k)(layers[i]))
-            layers[i] = getattr(self, "node_" + k)(layers[i] + layers[i - 1])
+            # layers[i] = up(proj(layers[i])); layers[i] = node(layers[i] + layers[i - 1])   (dla_dcn.py:433-436): the sum is
+            # formed inside the up-sampling kernel
+            up = getattr(self, "up_" + k)
+            summed = up.forward_add(getattr(self, "proj_" + k)(layers[i]), layers[i - 1])
+            layers[i] = getattr(self, "node_" + k)(summed)
 
 
 class DLAUp(nn.Module):

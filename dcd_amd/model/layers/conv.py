@@ -41,6 +41,20 @@ class DepthwiseUpsample(nn.ConvTranspose2d):
     (DGDE/model/backbone/dla_dcn.py:416-418) on csrc/upsample.hip; same parameter / state-dict key (`weight`).  MIOpen has no
     solver for this shape and runs naive / im2col kernels (5.1 ms per step for the eight layers)."""
 
+    def forward_add(self, x, skip):
+        """up(x) + skip; on the HIP path the sum leaves the up-sampling kernel (IDAUp: node(up(proj(x)) + skip))."""
+        f = self.stride[0]
+        if self._hip_ok(x, None) and skip.is_cuda and skip.dtype == torch.float32:
+            return ops.upsample_dw(x, self.weight, f, skip)
+        return self.forward(x) + skip
+
+    def _hip_ok(self, x, output_size):
+        f = self.stride[0]
+        return (_ENABLED and output_size is None and x.is_cuda and x.dtype == torch.float32 and self.bias is None
+                and self.groups == self.in_channels == self.out_channels and self.stride == (f, f) and f in (2, 4, 8)
+                and self.kernel_size == (2 * f, 2 * f) and self.padding == (f // 2, f // 2) and self.output_padding == (0, 0)
+                and self.dilation == (1, 1) and (x.shape[3] * f) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535)
+
     def forward(self, x, output_size=None):
         f = self.stride[0]
         if (_ENABLED and output_size is None and x.is_cuda and x.dtype == torch.float32 and self.bias is None

@@ -706,15 +706,24 @@ def conv2d_bias(x, weight, bias, stride, padding, dilation):
 # ----------------------------------------------------------------------------------------------
 class _UpsampleDW(torch.autograd.Function):
     @staticmethod
-    def forward(ctx, x, weight, f):
+    def forward(ctx, x, weight, f, skip=None):
         _lib.require_cuda(x, weight)
         x, weight = _f32c(x), _f32c(weight)
         B, C, H, W = x.shape
         y = torch.empty((B, C, H * f, W * f), dtype=torch.float32, device=x.device)
-        st = _lib.lib().dcd_upsample_dw_forward(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H, W, f)
+        L = _lib.lib()
+        if skip is None:
+            st = L.dcd_upsample_dw_forward(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H, W, f)
+        else:
+            skip = _f32c(skip)
+            if tuple(skip.shape) != tuple(y.shape):
+                raise RuntimeError("upsample_dw: skip must have the output's shape")
+            st = L.dcd_upsample_dw_forward_add(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), skip.data_ptr(), y.data_ptr(),
+                                               B, C, H, W, f)
         _lib.check(st, "dcd_upsample_dw_forward")
         ctx.save_for_backward(x, weight)
         ctx.f = f
+        ctx.has_skip = skip is not None
         return y
 
     @staticmethod
@@ -727,12 +736,12 @@ class _UpsampleDW(torch.autograd.Function):
         st = _lib.lib().dcd_upsample_dw_backward(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), gy.data_ptr(), gx.data_ptr(),
                                                  gw.data_ptr(), B, C, H, W, ctx.f)
         _lib.check(st, "dcd_upsample_dw_backward")
-        return gx, gw, None
+        return gx, gw, None, (gy if ctx.has_skip else None)       # the skip's gradient is the incoming one, untouched
 
 
-def upsample_dw(x, weight, f):
-    """y = conv_transpose2d(x, weight, stride=f, padding=f//2, groups=C) for weight (C,1,2f,2f)."""
-    return _UpsampleDW.apply(x, weight, f)
+def upsample_dw(x, weight, f, skip=None):
+    """y = conv_transpose2d(x, weight, stride=f, padding=f//2, groups=C) for weight (C,1,2f,2f) (+ skip, in the same pass)."""
+    return _UpsampleDW.apply(x, weight, f, skip)
 
 
 # ----------------------------------------------------------------------------------------------

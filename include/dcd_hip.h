@@ -313,6 +313,10 @@ int dcd_conv_stem_wrw(void *stream, const float *input, const float *grad_output
  * x (B,C,H,W) -> y (B,C,H*f,W*f); weight (C,1,2f,2f).  Requires (W*f) % 4 == 0.  Backward overwrites grad_x and grad_weight.
  * ---------------------------------------------------------------------------------------------- */
 int dcd_upsample_dw_forward(void *stream, const float *x, const float *weight, float *y, int B, int C, int H, int W, int f);
+/* y = up(x) + skip: the sum that feeds IDAUp's node (`layers[i] = node(layers[i] + layers[i-1])`, dla_dcn.py:430-436) leaves the
+ * up-sampling kernel directly; skip (B, C, H*f, W*f). */
+int dcd_upsample_dw_forward_add(void *stream, const float *x, const float *weight, const float *skip, float *y, int B, int C, int H,
+                                int W, int f);
 int dcd_upsample_dw_backward(void *stream, const float *x, const float *weight, const float *grad_y, float *grad_x,
                              float *grad_weight, int B, int C, int H, int W, int f);
 

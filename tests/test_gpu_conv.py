@@ -81,6 +81,31 @@ def test_depthwise_upsample_matches_conv_transpose(cuda, B, C, H, W, f):
     _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
 
 
+@pytest.mark.parametrize("B,C,H,W,f", [(2, 8, 5, 6, 2), (1, 64, 24, 80, 4)])
+def test_depthwise_upsample_with_skip_sum(cuda, B, C, H, W, f):
+    """IDAUp's `node(up(x) + skip)`: the sum formed inside the up-sampling kernel (DepthwiseUpsample.forward_add) against
+    conv_transpose2d + add in fp64, all three gradients (the skip's is the incoming gradient itself)."""
+    from dcd_amd.model.layers.conv import DepthwiseUpsample
+    g = torch.Generator().manual_seed(C * f)
+    up = DepthwiseUpsample(C, C, 2 * f, stride=f, padding=f // 2, output_padding=0, groups=C, bias=False)
+    with torch.no_grad():
+        up.weight.copy_(torch.randn(up.weight.shape, generator=g))
+    x = torch.randn(B, C, H, W, generator=g)
+    skip = torch.randn(B, C, H * f, W * f, generator=g)
+    gy = torch.randn(B, C, H * f, W * f, generator=g)
+    xd, sd, wd = x.double().requires_grad_(), skip.double().requires_grad_(), up.weight.detach().double().requires_grad_()
+    ref = F.conv_transpose2d(xd, wd, stride=f, padding=f // 2, groups=C) + sd
+    ref.backward(gy.double())
+    up = up.to(cuda)
+    xg, sg = x.to(cuda).requires_grad_(), skip.to(cuda).requires_grad_()
+    y = up.forward_add(xg, sg)
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref.detach(), "forward", 1e-6)
+    _close(xg.grad.cpu(), xd.grad, "grad_input", 1e-5)
+    _close(sg.grad.cpu(), sd.grad, "grad_skip", 1e-7)
+    _close(up.weight.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+
+
 def test_depthwise_upsample_module_dispatch(cuda):
     from dcd_amd.model.layers.conv import DepthwiseUpsample
     up = DepthwiseUpsample(16, 16, 4, stride=2, padding=1, output_padding=0, groups=16, bias=False).to(cuda)
