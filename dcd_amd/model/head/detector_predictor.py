@@ -20,6 +20,9 @@ from dcd_amd.model.layers.norm import BatchNorm2d
 from dcd_amd.model.layers.conv import Conv2d
 from dcd_amd.model.head import trunk_moments
 
+import os
+_HEAD_FUSED = os.environ.get("DCD_HEAD_FUSED", "1") != "0"      # 0: stock 1x1 conv + separate gather (A/B timing)
+
 
 @registry.PREDICTOR.register("Base_Predictor")
 class _predictor(nn.Module):
@@ -186,8 +189,17 @@ class _predictor(nn.Module):
         else:
             feat_cls_in, reg_inputs = features, [features] * n_reg
         feature_cls = self.class_head[:-1](feat_cls_in)
-        output_cls = self.class_head[-1](feature_cls)
         b, _, h, w = feature_cls.shape
+        last = self.class_head[-1]
+        edge_cls_feature = None
+        if (_HEAD_FUSED and self.enable_edge_fusion and feature_cls.is_cuda and feature_cls.dtype == torch.float32 and isinstance(last, nn.Conv2d)
+                and last.kernel_size == (1, 1) and last.stride == (1, 1) and last.padding == (0, 0) and last.groups == 1):
+            # the class head's output layer and the edge-fusion gather read the same feature map: one node, one gradient write
+            ei = torch.stack([t.get_field("edge_indices") for t in targets])
+            output_cls, edge_cls_feature = ops.head_out_and_gather(feature_cls, last.weight, last.bias,
+                                                                   ei[:, :, 1].long() * w + ei[:, :, 0].long())
+        else:
+            output_cls = last(feature_cls)
         centers = torch.stack([t.get_field("target_centers") for t in targets])              # B x M x 2 (x, y)
         centers_lin = centers[:, :, 1].long() * w + centers[:, :, 0].long()                  # B x M
         M = centers_lin.shape[1]
@@ -220,13 +232,14 @@ class _predictor(nn.Module):
                 if fused and j == self.offset_index[1]:
                     o = o + self._edge_fusion_at_pois(at_all[:, M:].transpose(1, 2), edge_lin, edge_valid, centers_lin)
                     # the class map gets its edge term densely (it is consumed densely by the focal loss)
-                    output_cls = self._edge_fusion_cls(feature_cls, output_cls, targets)
+                    output_cls = self._edge_fusion_cls(feature_cls, output_cls, targets, edge_cls_feature)
                 outs.append(o)
         output_cls = sigmoid_hm(output_cls)
         return {'cls': output_cls.float(), 'reg': None, 'reg_pois': torch.cat(outs, dim=2).float()}
 
-    def _edge_fusion_cls(self, feature_cls, output_cls, targets):
-        """The class-map half of `_edge_fusion` (dense: the focal loss reads every cell)."""
+    def _edge_fusion_cls(self, feature_cls, output_cls, targets, gathered=None):
+        """The class-map half of `_edge_fusion` (dense: the focal loss reads every cell).  gathered: feature_cls at the border
+        cells (B, K, C) when the caller already has it (ops.head_out_and_gather)."""
         b = feature_cls.shape[0]
         edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])
         edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
@@ -238,7 +251,8 @@ class _predictor(nn.Module):
         if feature_cls.is_cuda and output_cls.dtype == torch.float32 and output_cls.is_contiguous():
             # gather / scatter-add at linear cell indices on the HIP kernels (one launch each)
             lin = (yi * feature_cls.shape[3] + xi).view(b, K)
-            edge_cls_output = self.trunc_heatmap_conv(ops.select_point_of_interest(b, lin, feature_cls).transpose(1, 2))
+            at_edges = gathered if gathered is not None else ops.select_point_of_interest(b, lin, feature_cls)
+            edge_cls_output = self.trunc_heatmap_conv(at_edges.transpose(1, 2))
             vals = (edge_cls_output * valid.unsqueeze(1).to(edge_cls_output.dtype)).transpose(1, 2)
             return ops.scatter_add_at(output_cls, vals, lin)
         ci = torch.arange(self.head_conv, device=feature_cls.device).view(1, -1, 1)

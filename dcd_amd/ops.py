@@ -268,6 +268,55 @@ class _ScatterAddAt(torch.autograd.Function):
         return g, gv, None
 
 
+class _HeadOutAndGather(torch.autograd.Function):
+    """(W x + b, x at listed cells) for a 1x1 output convolution whose input is ALSO gathered at positions: the class head's last
+    layer and the edge-fusion gather read the same 256-channel feature map (DGDE/model/head/detector_predictor.py:150-152,178-188).
+    As one node the backward writes the feature gradient once -- W^T g as a batched GEMM, the gathered rows' gradient scatter-added
+    into it in place -- instead of a zero-filled 251 MB map, a scatter and a full-size addition; the products are plain GEMMs on
+    (B, C, HW) views, so the stock solver's NHWC transposes of the 251 MB operand (113 us per step) go too."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias, index):
+        _lib.require_cuda(x, weight, index)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        O = weight.shape[0]
+        w2 = weight.reshape(O, C)
+        out = torch.empty((B, O, H, W), dtype=torch.float32, device=x.device)      # returned as is (not a view: the edge-fusion
+        torch.matmul(w2, x.view(B, C, H * W), out=out.view(B, O, H * W))            # term is added into it in place later)
+        if bias is not None:
+            out.add_(bias.view(1, O, 1, 1))
+        idx = index.to(torch.int64).contiguous()
+        M = idx.shape[1]
+        g = torch.empty((B, M, C), dtype=torch.float32, device=x.device)
+        st = _lib.lib().dcd_poi_gather(_lib.stream_of(x), x.data_ptr(), idx.data_ptr(), B, C, H, W, M, g.data_ptr())
+        _lib.check(st, "dcd_poi_gather")
+        ctx.save_for_backward(x, w2, idx)
+        ctx.has_bias = bias is not None
+        ctx.wshape = weight.shape
+        return out, g
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gout, ggather):
+        x, w2, idx = ctx.saved_tensors
+        B, C, H, W = x.shape
+        O = w2.shape[0]
+        go = _f32c(gout).view(B, O, H * W)
+        gx = torch.matmul(w2.t(), go)                                                     # (B, C, HW), written once
+        gg = _f32c(ggather)
+        st = _lib.lib().dcd_poi_scatter_add(_lib.stream_of(x), gg.data_ptr(), idx.data_ptr(), B, C, H, W, idx.shape[1], gx.data_ptr())
+        _lib.check(st, "dcd_poi_scatter_add")
+        gw = torch.bmm(go, x.view(B, C, H * W).transpose(1, 2)).sum(0).reshape(ctx.wshape)     # transposed VIEW: no 251 MB copy
+        gb = go.sum((0, 2)) if ctx.has_bias else None
+        return gx.view(B, C, H, W), gw, gb, None
+
+
+def head_out_and_gather(x, weight, bias, index):
+    """(conv1x1(x, weight, bias) (B,O,H,W), x gathered at the linear cell indices index (B,M) -> (B,M,C))."""
+    return _HeadOutAndGather.apply(x, weight, bias, index)
+
+
 def scatter_add_at(fmap, vals, index):
     """fmap (B,C,H,W) += vals (B,M,C) at the linear cell indices index (B,M); returns fmap (updated in place)."""
     return _ScatterAddAt.apply(fmap, vals, index)
