@@ -93,7 +93,7 @@ class _ShiftCorr(torch.autograd.Function):
     host-logic tests): the same sums written with torch slices."""
 
     @staticmethod
-    def forward(ctx, x):
+    def forward(ctx, x, positions=None):
         B, C, H, W = x.shape
         Hp, Wp = H + 4, (W + 4 + 3) // 4 * 4
         Lp = Hp * Wp
@@ -120,11 +120,24 @@ class _ShiftCorr(torch.autograd.Function):
             R = torch.stack([torch.einsum('bcyx,bkyx->ck', xp[:, :, 2:2 + H, 2:2 + W], xp[:, :, 2 + dy:2 + dy + H, 2 + dx:2 + dx + W])
                              for (dy, dx) in HALF]).double()
         total = x.sum(3).double().sum((0, 2))
-        return (R, total, x[:, :, 0:3, :].clone(), x[:, :, H - 3:H, :].clone(), x[:, :, :, 0:3].clone(), x[:, :, :, W - 3:W].clone())
+        outs = (R, total, x[:, :, 0:3, :].clone(), x[:, :, H - 3:H, :].clone(), x[:, :, :, 0:3].clone(), x[:, :, :, W - 3:W].clone())
+        ctx.pidx = None
+        if positions is not None:
+            # the 3x3 patches at listed cells (B, n) -> (B, 9C, n) [row c*9 + tap] read from the padded buffer: their gradient is
+            # scatter-added into this node's dx in the backward (no zero-filled map, no extra full-size addition)
+            pos = positions.long()
+            n = pos.shape[1]
+            taps = _const(("ptaps", Wp, str(x.device)), lambda: torch.tensor(
+                [(dy + 1) * Wp + dx + 1 for dy in range(3) for dx in range(3)], device=x.device))
+            idx = ((pos // W) * Wp + pos % W).unsqueeze(1) + taps.view(1, 9, 1)                 # (B, 9, n) into the padded plane
+            idx = idx.reshape(B, 1, 9 * n)
+            ctx.pidx = idx
+            outs = outs + (xp.reshape(B, C, Lp).gather(2, idx.expand(B, C, 9 * n)).reshape(B, 9 * C, n),)
+        return outs
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dR, dtotal, dT, dBt, dL, dRr):
+    def backward(ctx, dR, dtotal, dT, dBt, dL, dRr, dP=None):
         buf, = ctx.saved_tensors
         B, C, H, W, Hp, Wp, Lp, guard = ctx.geom
         xp = buf[guard:guard + B * C * Lp].view(B, C, Hp, Wp)
@@ -148,17 +161,21 @@ class _ShiftCorr(torch.autograd.Function):
             st = L.dcd_sgemm_shifted(_lib.stream_of(buf), K1.data_ptr(), 25 * C, 0, xp.data_ptr(), off.data_ptr(), C * Lp, 0,
                                      bias.data_ptr(), dxp.data_ptr(), Lp, C * Lp, 0, C, Lp, 25 * C, B, 1)
             _lib.check(st, "dcd_sgemm_shifted")
-            dx = dxp[:, :, 2:2 + H, 2:2 + W]
         else:
-            dx = dtotal.to(buf.dtype).view(1, C, 1, 1).expand(B, C, H, W).clone()
+            dxp = buf.new_zeros((B, C, Hp, Wp))
+            dxi = dtotal.to(buf.dtype).view(1, C, 1, 1).expand(B, C, H, W).clone()
             for j, (dy, dx_) in enumerate(ALL25):
-                dx += torch.einsum('ck,bkyx->bcyx', K1[:, j, :], xp[:, :, 2 + dy:2 + dy + H, 2 + dx_:2 + dx_ + W])
-        dx = dx.contiguous()
+                dxi += torch.einsum('ck,bkyx->bcyx', K1[:, j, :], xp[:, :, 2 + dy:2 + dy + H, 2 + dx_:2 + dx_ + W])
+            dxp[:, :, 2:2 + H, 2:2 + W] = dxi
+        if ctx.pidx is not None and dP is not None:
+            n9 = ctx.pidx.shape[2]
+            dxp.view(B, C, Lp).scatter_add_(2, ctx.pidx.expand(B, C, n9), dP.reshape(B, C, n9).to(dxp.dtype))
+        dx = dxp[:, :, 2:2 + H, 2:2 + W].contiguous()
         dx[:, :, 0:3, :] += dT
         dx[:, :, H - 3:H, :] += dBt
         dx[:, :, :, 0:3] += dL
         dx[:, :, :, W - 3:W] += dRr
-        return dx
+        return dx, None
 
 
 def _border_tables(device):
@@ -179,16 +196,19 @@ def _border_tables(device):
     return _const(("tables", str(device)), build)
 
 
-def patch_moments(x):
-    """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above)."""
+def patch_moments(x, positions=None):
+    """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above); with `positions`
+    (B, n) also the 3x3 patches at those cells (B, 9C, n) from the same node, else None as third value."""
     mode = os.environ.get("DCD_TRUNK_GRAM", "auto")
     # auto: the autocorrelation form pays from ~100k pixels per rank on (its border terms are ~60 small launches: at one
     # 96x320 image per rank the step is launch-bound and the single bmm is 1 ms faster; at eight images it is 1.7 ms slower)
     small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 100000
     if mode == "bmm" or (mode == "auto" and small) or x.shape[2] < 5 or x.shape[3] < 5:
-        return patch_moments_gram(x)
+        return patch_moments_gram(x) + (None,)
     B, C, H, W = x.shape
-    R13, total, T, Bt, Lb, Rb = _ShiftCorr.apply(x)
+    res = _ShiftCorr.apply(x, positions)
+    R13, total, T, Bt, Lb, Rb = res[:6]
+    P = res[6] if positions is not None else None
     E, Mk, half_of, flip = _border_tables(x.device)
     R25 = R13[half_of]
     R25 = torch.where(flip.view(25, 1, 1), R25.transpose(1, 2), R25)                           # R_-d = R_d^T
@@ -215,7 +235,7 @@ def patch_moments(x):
     sums = torch.stack((Bt[:, :, 2, :].sum((0, 2)), T[:, :, 0, :].sum((0, 2)), Rb[:, :, :, 2].sum((0, 2)), Lb[:, :, :, 0].sum((0, 2)),
                         Bt[:, :, 2, W - 1].sum(0), Bt[:, :, 2, 0].sum(0), T[:, :, 0, W - 1].sum(0), T[:, :, 0, 0].sum(0)))   # (8, C)
     S1 = (total.view(1, C) - Mk @ sums).t().reshape(9 * C)
-    return S1, G
+    return S1, G, P
 
 
 def usable(trunks, x):
@@ -249,7 +269,8 @@ def trunks_at(x, trunks, centers, extra=None):
     BatchNorm running estimates like a dense training forward."""
     B, C, H, W = x.shape
     T = len(trunks)
-    S1, G = patch_moments(x)
+    pos_all = centers.long() if extra is None else torch.cat((centers.long(), extra[1].long()), dim=1)
+    S1, G, P_all = patch_moments(x, pos_all if os.environ.get("DCD_TRUNK_PATCH_NODE", "1") != "0" else None)   # 0: separate gather (A/B)
     K = S1.shape[0]
     Wall = torch.stack([t[0].weight.reshape(t[0].out_channels, K) for t in trunks])            # (T, O, 9C)
     Wd = Wall.double()
@@ -289,21 +310,27 @@ def trunks_at(x, trunks, centers, extra=None):
     scale, shift = scale.to(x.dtype), shift.to(x.dtype)
     # patches at the listed positions straight from the (zero-padded) input, not from U: their backward is then a scatter of a
     # few thousand values into dx instead of a zero-filled (B, 9C, HW) tensor, a scatter into it and one more full-size addition
-    xp = F.pad(x, (1, 1, 1, 1)).flatten(2)                                                     # (B, C, (H+2)(W+2))
-    taps = _taps(W, x.device)
+    if P_all is not None:                                      # gathered inside the correlation node (its backward scatters into dx)
+        M0 = centers.shape[1]
 
-    def patches(pos):                                                                          # (B, n) -> (B, 9C, n), row c*9 + tap
-        pos = pos.long()
-        base = (pos // W) * (W + 2) + pos % W                                                  # top-left of the 3x3 window in xp
-        n = pos.shape[1]
-        idx = (base.unsqueeze(1) + taps.view(1, 9, 1)).reshape(B, 1, 9 * n).expand(B, C, 9 * n)
-        return xp.gather(2, idx).reshape(B, K, n)                                              # (B, C, 9, n) -> (B, 9C, n)
-    Xc = patches(centers)                                                                      # (B, 9C, M)
+        def patches(pos, first):
+            return P_all[:, :, :M0] if first else P_all[:, :, M0:]
+    else:
+        xp = F.pad(x, (1, 1, 1, 1)).flatten(2)                                                 # (B, C, (H+2)(W+2))
+        taps = _taps(W, x.device)
+
+        def patches(pos, first):                                                               # (B, n) -> (B, 9C, n), row c*9 + tap
+            pos = pos.long()
+            base = (pos // W) * (W + 2) + pos % W                                              # top-left of the 3x3 window in xp
+            n = pos.shape[1]
+            idx = (base.unsqueeze(1) + taps.view(1, 9, 1)).reshape(B, 1, 9 * n).expand(B, C, 9 * n)
+            return xp.gather(2, idx).reshape(B, K, n)                                          # (B, C, 9, n) -> (B, 9C, n)
+    Xc = patches(centers, True)                                                                # (B, 9C, M)
     y = torch.einsum('bkm,tok->tbmo', Xc, Wall)
     out = list(torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1)).unbind(0))
     if extra is not None:
         i, pos = extra
-        Xe = patches(pos)
+        Xe = patches(pos, False)
         ye = torch.einsum('bkm,ok->bmo', Xe, Wall[i])
         out[i] = torch.cat((out[i], torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))), dim=1)
     return out

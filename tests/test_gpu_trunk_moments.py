@@ -37,8 +37,8 @@ def test_moments_equal_patch_matrix_form(cuda, monkeypatch):
     torch.manual_seed(1)
     x = torch.randn(2, 64, 24, 40, device=cuda)
     monkeypatch.setenv("DCD_TRUNK_GRAM", "shift")          # ("auto" picks by size: this input would take the patch form)
-    S1a, Ga = TM.patch_moments(x)
+    S1a, Ga, _ = TM.patch_moments(x)
     monkeypatch.setenv("DCD_TRUNK_GRAM", "bmm")
-    S1b, Gb = TM.patch_moments(x)
+    S1b, Gb, _ = TM.patch_moments(x)
     assert (S1a - S1b).abs().max().item() <= 1e-3
     assert (Ga - Gb).abs().max().item() <= 2e-5 * Gb.abs().max().item()
