@@ -497,6 +497,22 @@ __global__ void poi_scatter_kernel(const float *__restrict__ gout, const int64_t
     }
 }
 
+// Same sum with the lanes along the POSITIONS: lists of neighbouring cells (the 836 border cells of the edge-fusion branch walk the
+// image border) then issue atomics to consecutive addresses -- one cache-line request per wave and channel instead of one per
+// lane (atomics retire per cache-line request).  Used from 64 positions per image on.
+__global__ void poi_scatter_rows_kernel(const float *__restrict__ gout, const int64_t *__restrict__ index, int C, int HW, int M,
+                                        int64_t total, float *__restrict__ gfeat)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const int64_t bc = i / M;
+        const int c = (int)(bc % C);
+        const int64_t b = bc / C;
+        const int64_t idx = index[b * M + m];
+        if (idx >= 0 && idx < HW) atomicAdd(gfeat + ((size_t)b * C + c) * HW + idx, gout[((size_t)b * M + m) * C + c]);
+    }
+}
+
 
 // ---------------------------------------------------------------------------------------------
 // 3-D IoU of box pairs (logging metric).  DGDE/model/layers/iou_loss.py:99-136 (shapely there):
@@ -747,8 +763,12 @@ int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *ind
     const int64_t total = (int64_t)B * M * C;
     if (total == 0) return DCD_OK;
     if (!grad_out || !index || !grad_feat || B < 0 || C <= 0 || H <= 0 || W <= 0 || M < 0) return DCD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(poi_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M, total,
-                       grad_feat);
+    if (M >= 64)
+        hipLaunchKernelGGL(poi_scatter_rows_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M,
+                           total, grad_feat);
+    else
+        hipLaunchKernelGGL(poi_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M, total,
+                           grad_feat);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -283,7 +283,8 @@ class _HeadOutAndGather(torch.autograd.Function):
         O = weight.shape[0]
         w2 = weight.reshape(O, C)
         out = torch.empty((B, O, H, W), dtype=torch.float32, device=x.device)      # returned as is (not a view: the edge-fusion
-        torch.matmul(w2, x.view(B, C, H * W), out=out.view(B, O, H * W))            # term is added into it in place later)
+        torch.bmm(w2.unsqueeze(0).expand(B, O, C), x.view(B, C, H * W), out=out.view(B, O, H * W))   # term is added into it later)
+        # (bmm with an expanded weight, not matmul(2-D, 3-D): that one folds the batch by transposing -- and copying -- the 251 MB operand)
         if bias is not None:
             out.add_(bias.view(1, O, 1, 1))
         idx = index.to(torch.int64).contiguous()
@@ -303,11 +304,12 @@ class _HeadOutAndGather(torch.autograd.Function):
         B, C, H, W = x.shape
         O = w2.shape[0]
         go = _f32c(gout).view(B, O, H * W)
-        gx = torch.matmul(w2.t(), go)                                                     # (B, C, HW), written once
+        gx = torch.bmm(w2.t().unsqueeze(0).expand(B, C, O), go)                           # (B, C, HW), written once
         gg = _f32c(ggather)
         st = _lib.lib().dcd_poi_scatter_add(_lib.stream_of(x), gg.data_ptr(), idx.data_ptr(), B, C, H, W, idx.shape[1], gx.data_ptr())
         _lib.check(st, "dcd_poi_scatter_add")
-        gw = torch.bmm(go, x.view(B, C, H * W).transpose(1, 2)).sum(0).reshape(ctx.wshape)     # transposed VIEW: no 251 MB copy
+        # the transposed operand is the small one (go^T, 0.7 MB): bmm may copy it, never the 251 MB feature map
+        gw = torch.bmm(x.view(B, C, H * W), go.transpose(1, 2)).sum(0).t().reshape(ctx.wshape)
         gb = go.sum((0, 2)) if ctx.has_bias else None
         return gx.view(B, C, H, W), gw, gb, None
 
