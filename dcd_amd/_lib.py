@@ -44,6 +44,8 @@ SIGNATURES = {
     "dcd_conv3x3_wrw": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t]),
     "dcd_upsample_dw_forward": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "dcd_upsample_dw_forward_add": (c_int, [c_void_p] * 5 + [c_int] * 5),
+    "dcd_maxpool2x2_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int]),
+    "dcd_maxpool2x2_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int]),
     "dcd_upsample_dw_backward": (c_int, [c_void_p] * 6 + [c_int] * 5),
     "dcd_bn_workspace_bytes": (c_size_t, [c_int]),
     "dcd_bn_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),

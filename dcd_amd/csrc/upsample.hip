@@ -8,6 +8,8 @@
 //                  contribution to grad_w (x * patch), reduced per block and added with (2f)^2 atomics per block.
 // All HBM-bound (forward: one write of y; backward: one read of grad_y); NCHW fp32, one (b, c) plane chunk per workgroup.
 #include <hip/hip_runtime.h>
+
+#include <cstdint>
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
@@ -98,9 +100,85 @@ __global__ __launch_bounds__(256) void up_dw_bwd(const float *__restrict__ x, co
         atomicAdd(gw + (size_t)c * K * K + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
 }
 
+// 2x2 / stride-2 max pooling (the `downsample` of every DLA Tree, dla_dcn.py:228).  thread = two outputs = a 2 x 4 input patch
+// (two float4 rows).  The backward re-derives the arg-max from x instead of storing indices: first maximum in scan order wins,
+// a NaN takes over -- the rule of the stock kernel -- and the gradient leaves as two float4 rows (stock: 142 us for the
+// 126 MB map of level 2, index tensor included; this: read x + gy, write gx).  W % 4 == 0, H % 2 == 0.
+__device__ __forceinline__ int argmax4(float a, float b, float c, float d, float &m)
+{
+    int k = 0;
+    m = a;
+    if (b > m || b != b) { m = b; k = 1; }
+    if (c > m || c != c) { m = c; k = 2; }
+    if (d > m || d != d) { m = d; k = 3; }
+    return k;
+}
+
+__global__ __launch_bounds__(256) void maxpool2_fwd(const float *__restrict__ x, float *__restrict__ y, int64_t planes, int H, int W)
+{
+    const int Ho = H / 2, Wq = W / 4;
+    const int64_t n = planes * Ho * Wq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % Wq);
+        const int64_t r = i / Wq;
+        const int oy = (int)(r % Ho);
+        const int64_t pl = r / Ho;
+        const float *p = x + (pl * H + 2 * oy) * W + 4 * q;
+        const float4 t = *reinterpret_cast<const float4 *>(p), b = *reinterpret_cast<const float4 *>(p + W);
+        float m0, m1;
+        argmax4(t.x, t.y, b.x, b.y, m0);
+        argmax4(t.z, t.w, b.z, b.w, m1);
+        *reinterpret_cast<float2 *>(y + (pl * Ho + oy) * (W / 2) + 2 * q) = make_float2(m0, m1);
+    }
+}
+
+__global__ __launch_bounds__(256) void maxpool2_bwd(const float *__restrict__ x, const float *__restrict__ gy, float *__restrict__ gx,
+                                                    int64_t planes, int H, int W)
+{
+    const int Ho = H / 2, Wq = W / 4;
+    const int64_t n = planes * Ho * Wq;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const int q = (int)(i % Wq);
+        const int64_t r = i / Wq;
+        const int oy = (int)(r % Ho);
+        const int64_t pl = r / Ho;
+        const size_t o = (size_t)(pl * H + 2 * oy) * W + 4 * q;
+        const float4 t = *reinterpret_cast<const float4 *>(x + o), b = *reinterpret_cast<const float4 *>(x + o + W);
+        const float2 g = *reinterpret_cast<const float2 *>(gy + (pl * Ho + oy) * (W / 2) + 2 * q);
+        float m;
+        const int k0 = argmax4(t.x, t.y, b.x, b.y, m), k1 = argmax4(t.z, t.w, b.z, b.w, m);
+        const float4 gt = make_float4(k0 == 0 ? g.x : 0.f, k0 == 1 ? g.x : 0.f, k1 == 0 ? g.y : 0.f, k1 == 1 ? g.y : 0.f);
+        const float4 gb = make_float4(k0 == 2 ? g.x : 0.f, k0 == 3 ? g.x : 0.f, k1 == 2 ? g.y : 0.f, k1 == 3 ? g.y : 0.f);
+        *reinterpret_cast<float4 *>(gx + o) = gt;
+        *reinterpret_cast<float4 *>(gx + o + W) = gb;
+    }
+}
+
 }  // namespace
 
 extern "C" {
+
+int dcd_maxpool2x2_forward(void *stream_, const float *x, float *y, int64_t planes, int H, int W)
+{
+    (void)hipGetLastError();
+    if (!x || !y || planes <= 0 || H < 2 || W < 4 || (H & 1) || (W & 3) || (((uintptr_t)x | (uintptr_t)y) & 15)) return DCD_ERR_BAD_ARG;
+    const int64_t n = planes * (H / 2) * (W / 4);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4);
+    hipLaunchKernelGGL(maxpool2_fwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, y, planes, H, W);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_maxpool2x2_backward(void *stream_, const float *x, const float *grad_y, float *grad_x, int64_t planes, int H, int W)
+{
+    (void)hipGetLastError();
+    if (!x || !grad_y || !grad_x || planes <= 0 || H < 2 || W < 4 || (H & 1) || (W & 3) ||
+        (((uintptr_t)x | (uintptr_t)grad_y | (uintptr_t)grad_x) & 15))
+        return DCD_ERR_BAD_ARG;
+    const int64_t n = planes * (H / 2) * (W / 4);
+    const unsigned grid = (unsigned)((n + 255) / 256 < 65535 * 4 ? (n + 255) / 256 : 65535 * 4);
+    hipLaunchKernelGGL(maxpool2_bwd, dim3(grid), dim3(256), 0, (hipStream_t)stream_, x, grad_y, grad_x, planes, H, W);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
 
 static int upsample_forward(hipStream_t stream, const float *x, const float *weight, const float *skip, float *y, int B, int C, int H,
                             int W, int f)

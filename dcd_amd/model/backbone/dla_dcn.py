@@ -14,7 +14,7 @@ from torch import nn
 
 from .DCNv2.dcn_v2 import DCN
 from dcd_amd.model.layers.norm import BatchNorm2d
-from dcd_amd.model.layers.conv import Conv2d, DepthwiseUpsample
+from dcd_amd.model.layers.conv import Conv2d, DepthwiseUpsample, MaxPool2x2
 
 BN_MOMENTUM = 0.1
 
@@ -86,7 +86,7 @@ class Tree(nn.Module):
         self.level_root = level_root
         self.root_dim = root_dim
         self.levels = levels
-        self.downsample = nn.MaxPool2d(stride, stride=stride) if stride > 1 else None
+        self.downsample = MaxPool2x2(stride, stride=stride) if stride > 1 else None
         self.project = None
         if in_channels != out_channels:
             self.project = nn.Sequential(nn.Conv2d(in_channels, out_channels, 1, stride=1, bias=False), _bn(out_channels))

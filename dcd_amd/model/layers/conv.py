@@ -63,3 +63,17 @@ class DepthwiseUpsample(nn.ConvTranspose2d):
                 and self.dilation == (1, 1) and (x.shape[3] * f) % 4 == 0 and x.shape[0] * x.shape[1] <= 65535):
             return ops.upsample_dw(x, self.weight, f)
         return super().forward(x, output_size)
+
+
+class MaxPool2x2(nn.MaxPool2d):
+    """`nn.MaxPool2d(2, stride=2)` of the DLA trees (DGDE/model/backbone/dla_dcn.py:228) on csrc/upsample.hip; anything else the
+    module is configured for, and inputs the kernel does not take, go to the stock op."""
+
+    def forward(self, x):
+        def two(v):
+            return v == 2 or v == (2, 2)
+        if (_ENABLED and x.is_cuda and x.dtype == torch.float32 and x.dim() == 4 and two(self.kernel_size) and two(self.stride)
+                and self.padding in (0, (0, 0)) and self.dilation in (1, (1, 1)) and not self.ceil_mode and not self.return_indices
+                and x.shape[2] % 2 == 0 and x.shape[3] % 4 == 0):
+            return ops.maxpool2x2(x)
+        return super().forward(x)

@@ -790,6 +790,35 @@ class _UpsampleDW(torch.autograd.Function):
         return gx, gw, None, (gy if ctx.has_skip else None)       # the skip's gradient is the incoming one, untouched
 
 
+class _MaxPool2x2(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _lib.require_cuda(x)
+        x = _f32c(x)
+        B, C, H, W = x.shape
+        y = torch.empty((B, C, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        st = _lib.lib().dcd_maxpool2x2_forward(_lib.stream_of(x), x.data_ptr(), y.data_ptr(), B * C, H, W)
+        _lib.check(st, "dcd_maxpool2x2_forward")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        (x,) = ctx.saved_tensors
+        gy = _f32c(gy)
+        gx = torch.empty_like(x)
+        B, C, H, W = x.shape
+        st = _lib.lib().dcd_maxpool2x2_backward(_lib.stream_of(x), x.data_ptr(), gy.data_ptr(), gx.data_ptr(), B * C, H, W)
+        _lib.check(st, "dcd_maxpool2x2_backward")
+        return gx
+
+
+def maxpool2x2(x):
+    """max_pool2d(x, 2, 2) for (B, C, H, W) with H even and W % 4 == 0 (csrc/upsample.hip); no index tensor is kept."""
+    return _MaxPool2x2.apply(x)
+
+
 def upsample_dw(x, weight, f, skip=None):
     """y = conv_transpose2d(x, weight, stride=f, padding=f//2, groups=C) for weight (C,1,2f,2f) (+ skip, in the same pass)."""
     return _UpsampleDW.apply(x, weight, f, skip)

@@ -317,6 +317,12 @@ int dcd_upsample_dw_forward(void *stream, const float *x, const float *weight, f
  * up-sampling kernel directly; skip (B, C, H*f, W*f). */
 int dcd_upsample_dw_forward_add(void *stream, const float *x, const float *weight, const float *skip, float *y, int B, int C, int H,
                                 int W, int f);
+
+/* 2x2 / stride-2 max pooling of (planes, H, W) maps (H even, W % 4 == 0): the `downsample` of every DLA Tree
+ * (`nn.MaxPool2d(stride, stride=stride)`, DGDE/model/backbone/dla_dcn.py:228).  The backward re-derives the arg-max from x
+ * (first maximum in scan order, NaN takes over: the stock kernel's rule) instead of keeping an index tensor. */
+int dcd_maxpool2x2_forward(void *stream, const float *x, float *y, int64_t planes, int H, int W);
+int dcd_maxpool2x2_backward(void *stream, const float *x, const float *grad_y, float *grad_x, int64_t planes, int H, int W);
 int dcd_upsample_dw_backward(void *stream, const float *x, const float *weight, const float *grad_y, float *grad_x,
                              float *grad_weight, int B, int C, int H, int W, int f);
 

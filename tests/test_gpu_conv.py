@@ -106,6 +106,26 @@ def test_depthwise_upsample_with_skip_sum(cuda, B, C, H, W, f):
     _close(up.weight.grad.cpu(), wd.grad, "grad_weight", 2e-5)
 
 
+@pytest.mark.parametrize("shape", [(2, 3, 4, 8), (1, 16, 96, 320), (2, 5, 6, 12)])
+def test_maxpool2x2_matches_stock(cuda, shape):
+    """csrc/upsample.hip max pooling (arg-max re-derived in the backward) against F.max_pool2d: values and gradient exact, ties
+    (first maximum wins) and a NaN included."""
+    from dcd_amd.model.layers.conv import MaxPool2x2
+    g = torch.Generator().manual_seed(11)
+    x = torch.randn(shape, generator=g)
+    x[0, 0, 0:2, 0:2] = 1.5                                  # a four-way tie
+    x[-1, -1, 2:4, 4:6] = torch.tensor([[0.1, float("nan")], [0.3, 0.2]])
+    gy = torch.randn(shape[0], shape[1], shape[2] // 2, shape[3] // 2, generator=g)
+    a = x.clone().to(cuda).requires_grad_()
+    b = x.clone().to(cuda).requires_grad_()
+    ya = MaxPool2x2(2, stride=2)(a)
+    yb = F.max_pool2d(b, 2, 2)
+    assert torch.equal(torch.nan_to_num(ya, nan=7.0), torch.nan_to_num(yb, nan=7.0))
+    ya.backward(gy.to(cuda))
+    yb.backward(gy.to(cuda))
+    assert torch.equal(a.grad, b.grad)
+
+
 def test_depthwise_upsample_module_dispatch(cuda):
     from dcd_amd.model.layers.conv import DepthwiseUpsample
     up = DepthwiseUpsample(16, 16, 4, stride=2, padding=1, output_padding=0, groups=16, bias=False).to(cuda)
