@@ -190,4 +190,7 @@ def make_batch(batch_size, seed=0, n_objects=6, input_size=(1280, 384), device=N
     if device is not None:
         images = images.to(device)
         targets = [t.to(device) for t in targets]
-    return images, targets
+    # collate: one batched tensor per field, the per-image fields are its slices (the loader's job, once per batch; the device
+    # target encoder hands its outputs over the same way) -- stacking them again in the loss is then free
+    from dcd_amd.structures.params_3d import collate_fields
+    return images, collate_fields(targets)

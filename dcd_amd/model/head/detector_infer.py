@@ -8,6 +8,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from dcd_amd.structures.params_3d import stack_field
 from dcd_amd.model.anno_encoder import Anno_Encoder
 from dcd_amd.model.layers.utils import Converter_key2channel, select_point_of_interest, select_topk
 
@@ -45,13 +46,13 @@ class PostProcessor(nn.Module):
                         "extra_kpts_3d", "reg_mask", "Calib_P")
 
     def prepare_targets(self, targets, test):
-        pad_size = torch.stack([t.get_field("pad_size") for t in targets])
+        pad_size = stack_field(targets, "pad_size")
         out = {"calib": [t.get_field("calib") for t in targets], "pad_size": pad_size,
                "size": torch.stack([torch.as_tensor(t.size) for t in targets]).to(pad_size.device)}
         if not test:
             for name in self._OPTIONAL_FIELDS:
                 if all(t.has_field(name) for t in targets):
-                    out[name] = torch.stack([t.get_field(name) for t in targets])
+                    out[name] = stack_field(targets, name)
         return out
 
     # ---- stage 1: which cells are detections ------------------------------------------------------------------------

@@ -17,6 +17,7 @@ import os
 import torch
 from torch.nn import functional as F
 
+from dcd_amd.structures.params_3d import stack_field
 from dcd_amd import ops
 from dcd_amd.model.anno_encoder import Anno_Encoder
 from dcd_amd.model.head.depth_losses import RegWeightedL1Loss, Berhu_Loss, Inverse_Sigmoid_Loss, Log_L1_Loss
@@ -102,7 +103,7 @@ class Loss_Computation():
     def prepare_targets(self, targets):
         """Stack the per-image fields into batch tensors (detector_loss.py:106-146)."""
         def stack(name):
-            return torch.stack([t.get_field(name) for t in targets])
+            return stack_field(targets, name)
         out = {k: stack(f) for k, f in (
             ('cls_ids', 'cls_ids'), ('target_centers', 'target_centers'), ('bboxes', '2d_bboxes'),
             ('keypoints', 'keypoints'), ('extra_kpts_2d', 'extra_kpts_2d'), ('extra_kpts_3d', 'extra_kpts_3d'),

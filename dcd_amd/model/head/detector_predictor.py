@@ -11,6 +11,7 @@ import torch
 from torch import nn
 from torch.nn import functional as F
 
+from dcd_amd.structures.params_3d import stack_field
 from dcd_amd import ops
 from dcd_amd.model import registry
 from dcd_amd.model.layers.utils import select_point_of_interest, sigmoid_hm
@@ -130,10 +131,10 @@ class _predictor(nn.Module):
         """Sample both feature maps along the image border, run the two Conv1d branches and add the result back
         at the border cells (detector_predictor.py:172-196)."""
         b = feature_cls.shape[0]
-        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])          # B x K x 2 (x, y)
-        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)       # B x 1
-        out_w = torch.stack([t.get_field("final_output_w") for t in targets]).float().view(-1, 1, 1)
-        out_h = torch.stack([t.get_field("final_output_h") for t in targets]).float().view(-1, 1, 1)
+        edge_indices = stack_field(targets, "edge_indices")          # B x K x 2 (x, y)
+        edge_lens = stack_field(targets, "edge_len").view(b, 1)       # B x 1
+        out_w = stack_field(targets, "final_output_w").float().view(-1, 1, 1)
+        out_h = stack_field(targets, "final_output_h").float().view(-1, 1, 1)
 
         K = edge_indices.shape[1]
         bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
@@ -195,17 +196,17 @@ class _predictor(nn.Module):
         if (_HEAD_FUSED and self.enable_edge_fusion and feature_cls.is_cuda and feature_cls.dtype == torch.float32 and isinstance(last, nn.Conv2d)
                 and last.kernel_size == (1, 1) and last.stride == (1, 1) and last.padding == (0, 0) and last.groups == 1):
             # the class head's output layer and the edge-fusion gather read the same feature map: one node, one gradient write
-            ei = torch.stack([t.get_field("edge_indices") for t in targets])
+            ei = stack_field(targets, "edge_indices")
             output_cls, edge_cls_feature = ops.head_out_and_gather(feature_cls, last.weight, last.bias,
                                                                    ei[:, :, 1].long() * w + ei[:, :, 0].long())
         else:
             output_cls = last(feature_cls)
-        centers = torch.stack([t.get_field("target_centers") for t in targets])              # B x M x 2 (x, y)
+        centers = stack_field(targets, "target_centers")              # B x M x 2 (x, y)
         centers_lin = centers[:, :, 1].long() * w + centers[:, :, 0].long()                  # B x M
         M = centers_lin.shape[1]
         if self.enable_edge_fusion:
-            edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])      # B x K x 2 (x, y)
-            edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
+            edge_indices = stack_field(targets, "edge_indices")      # B x K x 2 (x, y)
+            edge_lens = stack_field(targets, "edge_len").view(b, 1)
             K = edge_indices.shape[1]
             edge_lin = edge_indices[:, :, 1].long() * w + edge_indices[:, :, 0].long()       # B x K
             edge_valid = torch.arange(K, device=edge_lin.device).view(1, K) < edge_lens      # B x K
@@ -241,8 +242,8 @@ class _predictor(nn.Module):
         """The class-map half of `_edge_fusion` (dense: the focal loss reads every cell).  gathered: feature_cls at the border
         cells (B, K, C) when the caller already has it (ops.head_out_and_gather)."""
         b = feature_cls.shape[0]
-        edge_indices = torch.stack([t.get_field("edge_indices") for t in targets])
-        edge_lens = torch.stack([t.get_field("edge_len") for t in targets]).view(b, 1)
+        edge_indices = stack_field(targets, "edge_indices")
+        edge_lens = stack_field(targets, "edge_len").view(b, 1)
         K = edge_indices.shape[1]
         bi = torch.arange(b, device=edge_indices.device).view(b, 1, 1)
         yi = edge_indices[:, :, 1].long().view(b, 1, K)

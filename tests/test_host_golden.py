@@ -460,3 +460,27 @@ def test_config_tree_equals_the_reference(tmp_path=None):
     assert set(ours) == set(ref), (sorted(set(ours) ^ set(ref))[:10])
     diff = {k: (ours[k], ref[k]) for k in ref if ours[k] != ref[k] and k != "PATHS_CATALOG"}      # a machine-specific path
     assert not diff, diff
+
+
+def test_stack_field_is_zero_copy_for_collated_targets():
+    """structures.params_3d.stack_field: consecutive slices of one batched tensor come back as that tensor (no copy); anything
+    else is stacked as before."""
+    from dcd_amd.structures.params_3d import ParamsList, collate_fields, stack_field
+    ts = []
+    for i in range(3):
+        t = ParamsList((1280, 384))
+        t.add_field("a", torch.full((4, 2), float(i)))
+        t.add_field("n", torch.tensor(i))
+        t.add_field("name", "img%d" % i)
+        ts.append(t)
+    plain = stack_field(ts, "a")
+    assert plain.shape == (3, 4, 2) and plain.data_ptr() != ts[0].get_field("a").data_ptr()
+    collate_fields(ts)
+    for name in ("a", "n"):
+        s1 = stack_field(ts, name)
+        assert s1.data_ptr() == ts[0].get_field(name).data_ptr() and s1.shape[0] == 3
+        assert torch.equal(s1, torch.stack([t.get_field(name) for t in ts]))
+    assert ts[2].get_field("name") == "img2"
+    # a reordered list is not one tensor's consecutive slices: copy
+    rev = stack_field(ts[::-1], "a")
+    assert rev.data_ptr() != ts[2].get_field("a").data_ptr() and torch.equal(rev[0], ts[2].get_field("a"))
