@@ -400,3 +400,27 @@ def test_loss_graph_inside_the_train_loop_equals_eager(cuda):
         DL.Loss_Computation.__call__ = orig
     assert len(lc._graphs) == 1
     assert totals[-1] < totals[0] and max(totals) < 2 * totals[0], totals
+
+
+@pytest.mark.parametrize("size", [(352, 96, 3), (672, 224, 2)])
+def test_train_steps_at_sizes_off_the_alignment_rules(cuda, size):
+    """Input sizes whose deeper maps break the kernels' alignment rules (W % 4 for the pooling / Winograd / tiled DCN kernels,
+    32-pixel tiles, H % 2): every dispatch must fall back cleanly -- three train steps, finite losses and parameters.
+    (tools/check_odd_sizes.py runs the same at 1248x384.)"""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step
+    from dcd_amd.model.detector import KeypointDetector
+    w, h, b = size
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "INPUT.WIDTH_TRAIN", w, "INPUT.HEIGHT_TRAIN", h])
+    torch.manual_seed(0)
+    model = KeypointDetector(cfg).to(cuda).train()
+    init_like_trained(model)
+    opt = build_optimizer(model, cfg)
+    images, targets = make_batch(b, seed=3, n_objects=4, input_size=(w, h), image_size=(w - 10, h - 5), device=cuda)
+    for _ in range(3):
+        ld, _ = train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+        total = getattr(ld, "total", None)
+        v = float((total if total is not None else sum(ld.values())).detach())
+        assert v == v and abs(v) < 1e6
+    assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
