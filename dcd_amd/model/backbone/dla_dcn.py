@@ -7,16 +7,19 @@ stock PyTorch-ROCm (MIOpen); every DeformConv runs the HIP DCNv2 kernels and eve
 runs the fused HIP normalisation kernels (csrc/norm.hip).
 """
 import math
+import os
 
 import numpy as np
 import torch
 from torch import nn
 
 from .DCNv2.dcn_v2 import DCN
+from dcd_amd import ops
 from dcd_amd.model.layers.norm import BatchNorm2d
 from dcd_amd.model.layers.conv import Conv2d, DepthwiseUpsample, MaxPool2x2
 
 BN_MOMENTUM = 0.1
+_ROOT_SPLIT = os.environ.get("DCD_ROOT_SPLIT", "1") != "0"      # 0: torch.cat + stock 1x1 convolution in Root (A/B timing)
 
 
 def _bn(c, relu=False):
@@ -61,7 +64,13 @@ class Root(nn.Module):
         self.residual = residual
 
     def forward(self, *x):
-        return self.bn(self.conv(torch.cat(x, 1)), x[0] if self.residual else None)
+        c = self.conv
+        if (_ROOT_SPLIT and x[0].is_cuda and x[0].dtype == torch.float32 and c.kernel_size == (1, 1) and c.stride == (1, 1)
+                and c.padding == (0, 0) and c.bias is None and c.groups == 1):
+            y = ops.conv1x1_of_cat(x, c.weight)                 # sum_i W_i x_i: the concatenation is never formed
+        else:
+            y = c(torch.cat(x, 1))
+        return self.bn(y, x[0] if self.residual else None)
 
 
 class Tree(nn.Module):

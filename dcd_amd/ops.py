@@ -319,6 +319,60 @@ def head_out_and_gather(x, weight, bias, index):
     return _HeadOutAndGather.apply(x, weight, bias, index)
 
 
+class _Conv1x1OfCat(torch.autograd.Function):
+    """conv1x1(cat(xs, dim=1), weight) without the concatenation: out = sum_i W[:, slice_i] x_i as batched GEMMs on (B, C_i, HW)
+    views (the first writes, the others accumulate), input gradients W_i^T g written contiguously, weight gradient per slice.
+    Replaces `torch.cat` + stock 1x1 convolution in DLA's Root (DGDE/model/backbone/dla_dcn.py:199-205): no concatenated copy in
+    the forward, no strided gradient slices (each re-packed by its consumer) in the backward."""
+
+    @staticmethod
+    def forward(ctx, weight, *xs):
+        _lib.require_cuda(weight, *xs)
+        xs = [_f32c(x) for x in xs]
+        B, _, H, W = xs[0].shape
+        O = weight.shape[0]
+        w2 = weight.reshape(O, -1)
+        out = torch.empty((B, O, H, W), dtype=torch.float32, device=xs[0].device)
+        o3 = out.view(B, O, H * W)
+        c0 = 0
+        for i, x in enumerate(xs):
+            Ci = x.shape[1]
+            wi = w2[:, c0:c0 + Ci].unsqueeze(0).expand(B, O, Ci)
+            if i == 0:
+                torch.bmm(wi, x.view(B, Ci, H * W), out=o3)
+            else:
+                o3.baddbmm_(wi, x.view(B, Ci, H * W))
+            c0 += Ci
+        ctx.save_for_backward(w2, *xs)
+        ctx.wshape = weight.shape
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        w2, *xs = ctx.saved_tensors
+        g = _f32c(g)
+        B, O, H, W = g.shape
+        g3 = g.view(B, O, H * W)
+        gw = torch.empty_like(w2)
+        gxs, c0 = [], 0
+        for i, x in enumerate(xs):
+            Ci = x.shape[1]
+            x3 = x.view(B, Ci, H * W)
+            if ctx.needs_input_grad[1 + i]:
+                gxs.append(torch.bmm(w2[:, c0:c0 + Ci].t().unsqueeze(0).expand(B, Ci, O), g3).view(B, Ci, H, W))
+            else:
+                gxs.append(None)
+            gw[:, c0:c0 + Ci] = torch.bmm(g3, x3.transpose(1, 2)).sum(0)       # transposed VIEW of x: no copy
+            c0 += Ci
+        return (gw.reshape(ctx.wshape),) + tuple(gxs)
+
+
+def conv1x1_of_cat(xs, weight):
+    """conv2d(torch.cat(xs, 1), weight (O, sum C_i, 1, 1)) for (B, C_i, H, W) tensors, without forming the concatenation."""
+    return _Conv1x1OfCat.apply(weight, *xs)
+
+
 def scatter_add_at(fmap, vals, index):
     """fmap (B,C,H,W) += vals (B,M,C) at the linear cell indices index (B,M); returns fmap (updated in place)."""
     return _ScatterAddAt.apply(fmap, vals, index)

@@ -264,3 +264,28 @@ def test_stem_full_size_against_stock_solver(cuda):
         for a, b, what in pairs:
             err = (a - b).abs().max().item()
             assert err <= 1e-4 * b.abs().max().item(), "%dx%d %s: %.3e vs scale %.3e" % (k, k, what, err, b.abs().max().item())
+
+
+def test_conv1x1_of_cat_matches_cat_then_conv(cuda):
+    """ops.conv1x1_of_cat (DLA Root without the concatenation) against conv2d(cat(...)) in fp64: output, every input gradient,
+    the weight gradient; one input that needs no gradient."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(31)
+    B, H, W, O = 2, 12, 20, 48
+    chans = (16, 32, 8)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in chans]
+    w = torch.randn(O, sum(chans), 1, 1, generator=g) * 0.1
+    gy = torch.randn(B, O, H, W, generator=g)
+    xd = [x.double().requires_grad_(i != 2) for i, x in enumerate(xs)]
+    wd = w.double().requires_grad_()
+    ref = F.conv2d(torch.cat(xd, 1), wd)
+    ref.backward(gy.double())
+    xg = [x.to(cuda).requires_grad_(i != 2) for i, x in enumerate(xs)]
+    wg = w.to(cuda).requires_grad_()
+    y = ops.conv1x1_of_cat(xg, wg)
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref.detach(), "forward", 2e-6)
+    for i in (0, 1):
+        _close(xg[i].grad.cpu(), xd[i].grad, "grad_input %d" % i, 1e-5)
+    assert xg[2].grad is None
+    _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
