@@ -778,6 +778,10 @@ struct InvLists {
     float *w;                      // [B][S][INV_CAP][HW]
     int packed;                    // idx holds (py << 16 | px) instead of the flat pixel index (tiled grad_input kernel)
     const unsigned char *blockmax; // [B][S][ceil(Ho/8)][ceil(Wo/8)]: ceil(max |offset|) over an 8x8 block of output pixels (<= 255)
+    unsigned char *tileflag;       // [B][ceil(H/4)][ceil(W/32)] or null: 1 = some cell of the 4 x 32 cell tile searched wider than
+                                   // INV_RTILE, i.e. its lists may leave the tiled grad_input kernel's dY window -> that tile is
+                                   // the register-gather kernel's
+    int flag_tx, flag_ty;          // tiles per row / column of that table
 };
 
 __device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
@@ -882,6 +886,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             }
         if (r0 <= 7 && r0 < rg) rm1 = r0;
     }
+    if (inv.tileflag && rm1 > INV_RTILE) inv.tileflag[((size_t)b * inv.flag_ty + (qy >> 2)) * inv.flag_tx + (qx >> 5)] = 1;
     const int R = rm1 + 1;
     const float rlim = (float)rg;
     const float *oh_p = off + ((size_t)b * S + seg) * 2 * g.HoWo;
@@ -904,7 +909,7 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
             const float dw_ = ((float)(px * g.sw - g.pw + j * g.dw) + ow) - (float)qx;
             if (fabsf(dh_) < 1.f && fabsf(dw_) < 1.f) {
                 if (cnt < INV_CAP) {
-                    inv.idx[base + (size_t)cnt * HW] = (inv.packed && rg <= INV_RTILE) ? ((py << 16) | px) : P;
+                    inv.idx[base + (size_t)cnt * HW] = inv.packed ? ((py << 16) | px) : P;
                     inv.w[base + (size_t)cnt * HW] = (1.f - fabsf(dh_)) * (1.f - fabsf(dw_)) * m_p[P];
                 }
                 ++cnt;
@@ -921,8 +926,9 @@ template <int MB>
 __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict__ gy, const float *__restrict__ wb,
                                                          InvLists inv, float *__restrict__ gin, Geom g, int partner_of_tiled = 0)
 {
-    // launched next to the tiled kernel: exactly one of the two runs, decided by the same device scalar
-    if (partner_of_tiled && inv_radius(inv.absmax_bits) <= INV_RTILE) return;
+    // launched next to the tiled kernel: each 4 x 32 cell tile is done by exactly one of the two, decided by the flag
+    // dcn_build_inverse set for it (or, without the table, by the call-wide radius)
+    if (partner_of_tiled && !inv.tileflag && inv_radius(inv.absmax_bits) <= INV_RTILE) return;
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
     const int HW = g.H * g.W;
@@ -934,8 +940,13 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
     const int nblk = g.cpgp / 32;                 // channel blocks per deformable group
     const int gb0 = blockIdx.z * MB;              // first global channel block of this wave
     const int Q = tile * 32 + p;
-    const bool qv = Q < HW;
+    bool qv = Q < HW;
     const int Qc = qv ? Q : HW - 1;
+    if (partner_of_tiled && inv.tileflag) {
+        const int qy_ = Qc / g.W, qx_ = Qc - qy_ * g.W;
+        qv = qv && inv.tileflag[((size_t)b * inv.flag_ty + (qy_ >> 2)) * inv.flag_tx + (qx_ >> 5)] != 0;
+        if (!__any(qv)) return;                   // wave-uniform: none of these 32 cells lies in a flagged tile
+    }
     const int nsteps = g.Cop / 2;
     const float *gy_b = gy + (size_t)b * g.Co * g.HoWo;
 
@@ -967,6 +978,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict
                 ri = inv.idx[base + (size_t)e * HW];
                 rw_ = inv.w[base + (size_t)e * HW];
             }
+            if (inv.packed) ri = (ri >> 16) * g.Wo + (ri & 0xffff);     // (row, column) as the tiled kernel wants them -> flat pixel
             eoff[e] = e < cnt ? (unsigned)ri * 4u : 0u;
             ew[e] = e < cnt ? rw_ : 0.f;
         }
@@ -1058,7 +1070,8 @@ template <int MB>
 __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float *__restrict__ gy, const float *__restrict__ wb,
                                                                     InvLists inv, float *__restrict__ gin, Geom g, int tiles_x)
 {
-    if (inv_radius(inv.absmax_bits) > INV_RTILE) return;       // listed pixels may lie outside the window: generic kernel runs
+    static_assert(BI_TR == 4, "dcn_build_inverse flags 4 x 32 cell tiles");
+    if (!inv.tileflag && inv_radius(inv.absmax_bits) > INV_RTILE) return;   // listed pixels may lie outside the window
     extern __shared__ __attribute__((aligned(16))) float lds[];       // [BI_OC][BI_PLANE] window | [8 pairs][9][MB][2][32] weights
     float *wsl = lds + BI_OC * BI_PLANE;
     const int tid = threadIdx.x;
@@ -1067,6 +1080,8 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
     int bx = blockIdx.x, b = blockIdx.y;
     xcd_remap(bx, b);
     const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    // some cell of this tile searched wider than the window allows: the register-gather kernel (launched next) owns the tile
+    if (inv.tileflag && inv.tileflag[((size_t)b * inv.flag_ty + ty) * inv.flag_tx + tx]) return;
     const int r0 = ty * BI_TR, c0 = tx * 32;
     const int qy = r0 + wave, qx = c0 + p;
     const bool qv = qy < g.H && qx < g.W;
@@ -2044,13 +2059,13 @@ __global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict_
 
 // One launch instead of up to six hipMemsetAsync calls (each is its own ~5 us kernel on the stream).
 struct ZeroRanges {
-    unsigned *p[6];
-    unsigned n[6];        // dwords
+    unsigned *p[7];
+    unsigned n[7];        // dwords
 };
 __global__ void dcn_zero_ranges(ZeroRanges z)
 {
 #pragma unroll
-    for (int r = 0; r < 6; ++r) {
+    for (int r = 0; r < 7; ++r) {
         unsigned *p = z.p[r];
         const unsigned n = z.n[r];
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
@@ -2144,9 +2159,12 @@ static size_t dw_partial_floats(int Cin, int Cout)
 }
 
 // per (image, tap segment, 8x8 block of output pixels) one byte, after the grad_weight partials
+static size_t tileflag_bytes(const Geom &g) { return ((size_t)g.B * ((g.H + 3) / 4) * ((g.W + 31) / 32) + 255) / 256 * 256; }
+
+// [block maxima | tile flags of the tiled grad_input kernel]
 static size_t blockmax_bytes(const Geom &g)
 {
-    return ((size_t)g.B * g.dg * g.KK * ((g.Ho + 7) / 8) * ((g.Wo + 7) / 8) + 255) / 256 * 256;
+    return ((size_t)g.B * g.dg * g.KK * ((g.Ho + 7) / 8) * ((g.Wo + 7) / 8) + 255) / 256 * 256 + tileflag_bytes(g);
 }
 
 static size_t base_workspace_bytes(const Geom &g)
@@ -2339,11 +2357,15 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     float *dw_part = (float *)(far_list + (ntile + 63) / 64 * 64);
     unsigned char *blockmax = (unsigned char *)workspace + (base_workspace_bytes(g) - blockmax_bytes(g));
     inv.blockmax = blockmax;
+    unsigned char *tileflag = (unsigned char *)workspace + (base_workspace_bytes(g) - tileflag_bytes(g));
+    inv.tileflag = nullptr;                                    // set below when the tiled grad_input kernel is in play
+    inv.flag_tx = (W + 31) / 32;
+    inv.flag_ty = (H + 3) / 4;
     const dim3 bm_grid(((g.Ho + 7) / 8) * ((g.Wo + 7) / 8), dg * g.KK, B);
 
     if (dense_ok(g, true)) {
         ZeroRanges z;
-        for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        for (int r = 0; r < 7; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
@@ -2385,7 +2407,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     const bool bd_tile_ok = tile_shape && (g.Cop == 64 || (g.Cop == 128 && bd128));
     {
         ZeroRanges z;
-        for (int r = 0; r < 6; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        for (int r = 0; r < 7; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;                         // max |offset| bits, far-tile count, overflowed-list count
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
@@ -2394,6 +2416,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             z.p[4] = (unsigned *)grad_offset; z.n[4] = (unsigned)((size_t)B * dg * 2 * g.KK * g.HoWo);
             z.p[5] = (unsigned *)grad_mask; z.n[5] = (unsigned)((size_t)B * dg * g.KK * g.HoWo);
         }
+        z.p[6] = (unsigned *)tileflag; z.n[6] = (unsigned)(tileflag_bytes(g) / 4);
         const size_t most = (size_t)z.n[2] > (size_t)z.n[4] ? z.n[2] : z.n[4];
         hipLaunchKernelGGL(dcn_zero_ranges, dim3((unsigned)(most / 1024 + 1 < 2048 ? most / 1024 + 1 : 2048)), dim3(256), 0, stream, z);
     }
@@ -2421,6 +2444,12 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const bool bi_tile_ok = false;
 #endif
         inv.packed = bi_tile_ok ? 1 : 0;
+        static int bi_hybrid = -1;                               // A/B: DCD_BI_HYBRID=0 -> one kernel per call, chosen by the call-wide radius
+        if (bi_hybrid < 0) {
+            const char *e = getenv("DCD_BI_HYBRID");
+            bi_hybrid = (e && atoi(e) == 0) ? 0 : 1;
+        }
+        inv.tileflag = (bi_tile_ok && bi_hybrid) ? tileflag : nullptr;
         hipLaunchKernelGGL(dcn_offset_blockmax, bm_grid, dim3(64), 0, stream, offset, g, blockmax);
         hipLaunchKernelGGL(dcn_build_inverse, dim3((HWin + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         bool bi_tiled = false;
