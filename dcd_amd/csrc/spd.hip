@@ -47,11 +47,27 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
     const int b = blockIdx.x, tid = threadIdx.x;
     float *Ab = A + (size_t)b * mstride + (size_t)k0 * n + k0;
     if (tid == 0) bad_flag = 0;
-    for (int e = tid; e < SP_NB * SP_NB; e += 256) {
-        const int row = e >> 7, col = e & 127;
-        Ls[row * SP_LS + col] = (row < nb && col <= row) ? Ab[(size_t)row * n + col] : (row == col ? 1.f : 0.f);
+#ifdef SPD_PROFILE
+    long long tc[6];
+    tc[0] = clock64();
+#endif
+    for (int e0 = tid; e0 < SP_NB * SP_NB; e0 += 8 * 256) {       // eight independent loads in flight, then the LDS stores
+        float v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u, row = e >> 7, col = e & 127;
+            v[u] = (row < nb && col <= row) ? Ab[(size_t)row * n + col] : (row == col ? 1.f : 0.f);
+        }
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+            const int e = e0 + 256 * u;
+            Ls[(e >> 7) * SP_LS + (e & 127)] = v[u];
+        }
     }
     __syncthreads();
+#ifdef SPD_PROFILE
+    tc[1] = clock64();
+#endif
     const int ti = tid >> 4, tj = tid & 15;                     // 8 x 8 tiles of the trailing update
     for (int c0 = 0; c0 < SP_NB; c0 += SP_IB) {
         // panel: columns c0 .. c0+31, rows >= the column
@@ -63,7 +79,8 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
             if (tid < SP_NB && tid > j) Ls[tid * SP_LS + j] *= inv;
             if (tid == j) dg[j] = piv * inv;
             __syncthreads();
-            // rank-1 update of the panel's remaining columns: thread = (row i, column parity)
+            // rank-1 update of the panel's remaining columns: thread = (row i, column parity).  (Reading everything into registers
+            // first -- 16 predicated slots per thread -- measured slower: 412k vs 260k cycles for the 128 columns.)
             const int i = tid & 127, par = tid >> 7;
             if (i > j) {
                 const float lij = Ls[i * SP_LS + j];
@@ -101,27 +118,33 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
         }
         __syncthreads();
     }
+#ifdef SPD_PROFILE
+    tc[2] = clock64();
+#endif
     if (tid == 0 && bad_flag && info) atomicMax(info + b, k0 + 1);      // not positive definite (or NaN) somewhere in this block
-    for (int e = tid; e < nb * nb; e += 256) {
-        const int row = e / nb, col = e - row * nb;
-        if (col <= row) Ab[(size_t)row * n + col] = Ls[row * SP_LS + col];
+    for (int e = tid; e < SP_NB * SP_NB; e += 256) {
+        const int row = e >> 7, col = e & 127;
+        if (row < nb && col <= row) Ab[(size_t)row * n + col] = Ls[row * SP_LS + col];
     }
+#ifdef SPD_PROFILE
+    tc[3] = clock64();
+#endif
     // X = L^-1 by block rows
-    const int tr = tid >> 5, tc = tid & 31;                     // 4 x 4 tiles of a 32 x 128 block row
+    const int tr = tid >> 5, tcol = tid & 31;                   // 4 x 4 tiles of a 32 x 128 block row
     for (int r0 = 0; r0 < SP_NB; r0 += SP_IB) {
         {
             float acc[4][4];
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) acc[a][c] = (r0 + 4 * tr + a == 4 * tc + c) ? 1.f : 0.f;
-            if (4 * tc < r0) {                                  // X[k][c] = 0 for c > k: columns >= r0 see no earlier rows
+                for (int c = 0; c < 4; ++c) acc[a][c] = (r0 + 4 * tr + a == 4 * tcol + c) ? 1.f : 0.f;
+            if (4 * tcol < r0) {                                  // X[k][c] = 0 for c > k: columns >= r0 see no earlier rows
                 for (int k = 0; k < r0; ++k) {
                     float lr[4], xc[4];
 #pragma unroll
                     for (int a = 0; a < 4; ++a) lr[a] = Ls[(r0 + 4 * tr + a) * SP_LS + k];
 #pragma unroll
-                    for (int c = 0; c < 4; ++c) xc[c] = Xs[k * SP_LS + 4 * tc + c];
+                    for (int c = 0; c < 4; ++c) xc[c] = Xs[k * SP_LS + 4 * tcol + c];
 #pragma unroll
                     for (int a = 0; a < 4; ++a)
 #pragma unroll
@@ -131,7 +154,7 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
 #pragma unroll
             for (int a = 0; a < 4; ++a)
 #pragma unroll
-                for (int c = 0; c < 4; ++c) Xs[(r0 + 4 * tr + a) * SP_LS + 4 * tc + c] = acc[a][c];
+                for (int c = 0; c < 4; ++c) Xs[(r0 + 4 * tr + a) * SP_LS + 4 * tcol + c] = acc[a][c];
         }
         __syncthreads();
         if (tid < r0 + SP_IB) {                                 // column tid: L_ii x = t (columns beyond the block row are zero)
@@ -148,11 +171,19 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
         }
         __syncthreads();
     }
+#ifdef SPD_PROFILE
+    tc[4] = clock64();
+#endif
     float *D = dinv + ((size_t)b * nblk + blk) * SP_NB * SP_NB;
     for (int e = tid; e < SP_NB * SP_NB; e += 256) {
         const int row = e >> 7, col = e & 127;
         D[e] = (row < nb && col <= row) ? Xs[row * SP_LS + col] : 0.f;
     }
+#ifdef SPD_PROFILE
+    tc[5] = clock64();
+    if (tid == 0 && b == 0 && blk == 1 && info)
+        for (int q = 0; q < 5; ++q) info[8 + q] = (int)(tc[q + 1] - tc[q]);
+#endif
 }
 
 // Backward substitution, one launch per block (from the last one): y_k = D_k^T z_k, then z[0:k0] -= L[k-rows][0:k0]^T y_k.
