@@ -402,6 +402,8 @@ def run_gmw(args):
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
     tb_ms = sum(a.elapsed_time(b) for a, b in pairs) / max(args.steps, 1)
+    if os.environ.get("DCD_BENCH_TRACE"):
+        print("[gmw] elapsed %.2f ms per step, argv %s" % (1e3 * elapsed / args.steps, sys.argv[1:]), file=sys.stderr)
     n = GMW_EDGES
     flops = per_rank * (2.0 * n * (n - 1) * n + n ** 3 / 3.0 + n ** 3 / 3.0)       # S = D2 - B^T D1 B, potrf, inverse of the factor
     out = None

@@ -43,7 +43,7 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
     extern __shared__ float lds[];
     float *Ls = lds, *Xs = lds + SP_NB * SP_LS;
     __shared__ int bad_flag;
-    __shared__ float dg[SP_NB];
+    __shared__ float colbuf[2][SP_IB];
     const int b = blockIdx.x, tid = threadIdx.x;
     float *Ab = A + (size_t)b * mstride + (size_t)k0 * n + k0;
     if (tid == 0) bad_flag = 0;
@@ -70,25 +70,41 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
 #endif
     const int ti = tid >> 4, tj = tid & 15;                     // 8 x 8 tiles of the trailing update
     for (int c0 = 0; c0 < SP_NB; c0 += SP_IB) {
-        // panel: columns c0 .. c0+31, rows >= the column
-        for (int j = c0; j < c0 + SP_IB; ++j) {
-            __syncthreads();                                    // the previous column's update of this column is complete
-            float piv = Ls[j * SP_LS + j];                      // stays in place until the panel is done (read by every thread)
-            if (!(piv > 0.f)) { bad_flag = 1; piv = 1e-30f; }
-            const float inv = __frsqrt_rn(piv);
-            if (tid < SP_NB && tid > j) Ls[tid * SP_LS + j] *= inv;
-            if (tid == j) dg[j] = piv * inv;
+        // panel: columns c0 .. c0+31, rows >= c0.  Thread = row, its 32 panel entries in registers; per column ONE barrier: the
+        // panel's rows publish their (unscaled) entry of column j, everyone reads the pivot and the <= 31 entries it needs as
+        // broadcasts and updates its own registers.  (A version that updated the panel in LDS -- read-modify-write per entry --
+        // serialised on the LDS round trips: 2 000 cycles per column, 260 k for the block.)
+        {
+            const int i = tid;                                   // row (threads 128..255 idle here)
+            float a[SP_IB];
+            if (i < SP_NB) {
+#pragma unroll
+                for (int c = 0; c < SP_IB; ++c) a[c] = Ls[i * SP_LS + c0 + c];
+            }
+#pragma unroll
+            for (int jj = 0; jj < SP_IB; ++jj) {
+                const int j = c0 + jj, cur = jj & 1;
+                if (i >= c0 && i < c0 + SP_IB) colbuf[cur][i - c0] = a[jj];
+                __syncthreads();
+                float piv = colbuf[cur][jj];
+                if (!(piv > 0.f)) { bad_flag = 1; piv = 1e-30f; }
+                const float inv = __frsqrt_rn(piv);
+                if (i < SP_NB && i >= j) {
+                    const float lij = i == j ? piv * inv : a[jj] * inv;
+                    a[jj] = lij;
+                    if (i > j) {
+#pragma unroll
+                        for (int cc = jj + 1; cc < SP_IB; ++cc) a[cc] -= lij * (colbuf[cur][cc] * inv);
+                    }
+                }
+            }
             __syncthreads();
-            // rank-1 update of the panel's remaining columns: thread = (row i, column parity).  (Reading everything into registers
-            // first -- 16 predicated slots per thread -- measured slower: 412k vs 260k cycles for the 128 columns.)
-            const int i = tid & 127, par = tid >> 7;
-            if (i > j) {
-                const float lij = Ls[i * SP_LS + j];
-                for (int c = j + 1 + par; c < c0 + SP_IB && c <= i; c += 2) Ls[i * SP_LS + c] -= lij * Ls[c * SP_LS + j];
+            if (i >= c0 && i < SP_NB) {
+#pragma unroll
+                for (int c = 0; c < SP_IB; ++c) Ls[i * SP_LS + c0 + c] = (c0 + c <= i) ? a[c] : 0.f;
             }
         }
         __syncthreads();
-        if (tid >= c0 && tid < c0 + SP_IB) Ls[tid * SP_LS + tid] = dg[tid];
         // trailing block (rows, columns >= c0+32; lower tiles only): A -= L_panel L_panel^T
         const int t0 = c0 + SP_IB;
         if (t0 < SP_NB && ti * 8 + 7 >= t0 && tj * 8 + 7 >= t0 && tj <= ti) {
