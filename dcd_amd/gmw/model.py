@@ -9,6 +9,8 @@ What differs from the reference is execution only: `edge_expand` gathers the 262
 precomputed index (the reference expands to (B,73,73,C), transposes and `masked_select`s twice, model.py:128-152).
 The regression weights are `1 / diag(M)` of the same M that feeds Sinkhorn (the transport layer needs every entry).
 """
+import os
+
 import torch
 from torch import nn
 from torch.nn import functional as F
@@ -104,9 +106,28 @@ class GMW(nn.Module):
         """(B, n, c) -> (B, n(n-1)/2, 2c): [f_i, f_j] for every pair i < j  (model.py:139-152)."""
         return torch.cat((f.index_select(1, self.pair_i), f.index_select(1, self.pair_j)), dim=-1)
 
+    def _extract(self, which, x):
+        """FeatureExtractor4d / 6d; on the GPU in a single-process training run each one is replayed from HIP graphs (forward and
+        backward captured once per input shape by torch.cuda.make_graphed_callables): 37 Conv1d + 24 context norms and their
+        ~250 backward kernels are launch-bound, and since the transport layer's backward moved to csrc/spd.hip the step waits
+        for the host.  DCD_GMW_GRAPH=0 switches it off; under torch.distributed the plain modules run."""
+        mod = getattr(self, which)
+        if not (x.is_cuda and self.training and torch.is_grad_enabled() and os.environ.get("DCD_GMW_GRAPH", "1") != "0"
+                and not (torch.distributed.is_available() and torch.distributed.is_initialized())
+                and not torch.cuda.is_current_stream_capturing()):
+            return mod(x)
+        key = (which, tuple(x.shape), x.dtype, x.requires_grad)
+        cache = self.__dict__.setdefault("_graphed", {})
+        if key not in cache:
+            if len(cache) >= 4:
+                cache.pop(next(iter(cache)))
+            sample = x.detach().clone().requires_grad_(x.requires_grad)
+            cache[key] = torch.cuda.make_graphed_callables(mod, (sample,))
+        return cache[key](x.contiguous())
+
     def graph_matching(self, f4d, f6d):
-        f4d = self.FeatureExtractor4d(f4d.transpose(-2, -1)).transpose(-2, -1)         # B x m x 128
-        f6d = self.FeatureExtractor6d(f6d.transpose(-2, -1)).transpose(-2, -1)
+        f4d = self._extract("FeatureExtractor4d", f4d.transpose(-2, -1)).transpose(-2, -1)         # B x m x 128
+        f6d = self._extract("FeatureExtractor6d", f6d.transpose(-2, -1)).transpose(-2, -1)
         f4d = F.normalize(f4d, p=2, dim=-1)
         f6d = F.normalize(f6d, p=2, dim=-1)
         M = pairwise_l2_dist(f4d, f6d)
