@@ -500,6 +500,22 @@ __global__ void poi_scatter_kernel(const float *__restrict__ gout, const int64_t
 // Same sum with the lanes along the POSITIONS: lists of neighbouring cells (the 836 border cells of the edge-fusion branch walk the
 // image border) then issue atomics to consecutive addresses -- one cache-line request per wave and channel instead of one per
 // lane (atomics retire per cache-line request).  Used from 64 positions per image on.
+// out[b][c][base[b][m] + tap_off(t)] += g[b][c*9 + t][m] for the nine taps of a 3x3 window in a plane of row pitch `pitch`:
+// the gradient of patches gathered at listed cells (trunk_moments.py), lanes along the positions m.
+__global__ void patch_scatter_kernel(const float *__restrict__ g, const int64_t *__restrict__ base, int C, int64_t L, int pitch, int M,
+                                     int64_t total, float *__restrict__ out)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total; i += (int64_t)gridDim.x * blockDim.x) {
+        const int m = (int)(i % M);
+        const int64_t r = i / M;                   // (b * C + c) * 9 + t
+        const int t = (int)(r % 9);
+        const int64_t bc = r / 9;
+        const int64_t b = bc / C;
+        const int64_t idx = base[b * M + m] + (t / 3) * pitch + (t % 3);
+        if (idx >= 0 && idx < L) atomicAdd(out + bc * L + idx, g[i]);
+    }
+}
+
 __global__ void poi_scatter_rows_kernel(const float *__restrict__ gout, const int64_t *__restrict__ index, int C, int HW, int M,
                                         int64_t total, float *__restrict__ gfeat)
 {
@@ -769,6 +785,19 @@ int dcd_poi_scatter_add(void *stream_, const float *grad_out, const int64_t *ind
     else
         hipLaunchKernelGGL(poi_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_out, index, C, H * W, M, total,
                            grad_feat);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_patch_scatter_add(void *stream_, const float *grad_patches, const int64_t *base, int B, int C, int64_t plane, int pitch,
+                          int M, float *out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    const int64_t total = (int64_t)B * C * 9 * M;
+    if (total == 0) return DCD_OK;
+    if (!grad_patches || !base || !out || B < 0 || C <= 0 || plane <= 0 || pitch <= 0 || M < 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(patch_scatter_kernel, dim3(grid_for(total, 256)), dim3(256), 0, stream, grad_patches, base, C, plane, pitch, M,
+                       total, out);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

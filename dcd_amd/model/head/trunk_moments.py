@@ -129,9 +129,11 @@ class _ShiftCorr(torch.autograd.Function):
             n = pos.shape[1]
             taps = _const(("ptaps", Wp, str(x.device)), lambda: torch.tensor(
                 [(dy + 1) * Wp + dx + 1 for dy in range(3) for dx in range(3)], device=x.device))
-            idx = ((pos // W) * Wp + pos % W).unsqueeze(1) + taps.view(1, 9, 1)                 # (B, 9, n) into the padded plane
+            base = (pos // W) * Wp + pos % W                                                     # (B, n): window's corner - (1, 1)
+            idx = base.unsqueeze(1) + taps.view(1, 9, 1)                                        # (B, 9, n) into the padded plane
             idx = idx.reshape(B, 1, 9 * n)
             ctx.pidx = idx
+            ctx.pbase = (base + Wp + 1).contiguous()                                            # top-left element of the 3x3 window
             outs = outs + (xp.reshape(B, C, Lp).gather(2, idx.expand(B, C, 9 * n)).reshape(B, 9 * C, n),)
         return outs
 
@@ -169,7 +171,14 @@ class _ShiftCorr(torch.autograd.Function):
             dxp[:, :, 2:2 + H, 2:2 + W] = dxi
         if ctx.pidx is not None and dP is not None:
             n9 = ctx.pidx.shape[2]
-            dxp.view(B, C, Lp).scatter_add_(2, ctx.pidx.expand(B, C, n9), dP.reshape(B, C, n9).to(dxp.dtype))
+            if dxp.is_cuda:
+                from dcd_amd import _lib
+                gp = dP.to(dxp.dtype).contiguous()
+                st = _lib.lib().dcd_patch_scatter_add(_lib.stream_of(dxp), gp.data_ptr(), ctx.pbase.data_ptr(), B, C, Lp, Wp, n9 // 9,
+                                                      dxp.data_ptr())
+                _lib.check(st, "dcd_patch_scatter_add")
+            else:
+                dxp.view(B, C, Lp).scatter_add_(2, ctx.pidx.expand(B, C, n9), dP.reshape(B, C, n9).to(dxp.dtype))
         dx = dxp[:, :, 2:2 + H, 2:2 + W].contiguous()
         dx[:, :, 0:3, :] += dT
         dx[:, :, H - 3:H, :] += dBt

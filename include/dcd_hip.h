@@ -142,6 +142,11 @@ int dcd_poi_gather(void *stream, const float *feat, const int64_t *index, int B,
                    float *out);
 int dcd_poi_scatter_add(void *stream, const float *grad_out, const int64_t *index, int B, int C, int H, int W,
                         int M, float *grad_feat);
+/* out (B, C, plane) += the gradient of 3x3 patches gathered at listed cells: grad_patches (B, C*9, M) [row c*9 + tap], base (B, M)
+ * = index of the window's top-left element inside the plane, whose rows are `pitch` apart (head trunks evaluated at the object
+ * centres only, dcd_amd/model/head/trunk_moments.py; no reference counterpart: the reference evaluates the trunks densely). */
+int dcd_patch_scatter_add(void *stream, const float *grad_patches, const int64_t *base, int B, int C, int64_t plane, int pitch, int M,
+                          float *out);
 
 /* ------------------------------------------------------------------------------------------------
  * 3-D IoU of N box pairs (a logging metric of the train step).  Replaces get_iou_3d

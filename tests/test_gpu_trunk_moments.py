@@ -16,15 +16,19 @@ def test_shift_correlations_match_host_float64(cuda, shape):
     outs = []
     for dev, dt in ((cuda, torch.float32), (torch.device("cpu"), torch.float64)):
         xi = x.to(dev, dt).requires_grad_(True)
-        R, total, T, Bt, L, Rr = TM._ShiftCorr.apply(xi)
+        pos = torch.randint(0, H * W, (B, 37), generator=torch.Generator().manual_seed(9))
+        pos[:, 0], pos[:, 1], pos[:, 2] = 0, H * W - 1, W - 1                    # corners: the zero padding is read
+        R, total, T, Bt, L, Rr, P = TM._ShiftCorr.apply(xi, pos.to(dev))
         g = torch.Generator().manual_seed(5)
         wR = torch.randn(R.shape, generator=g, dtype=torch.float64).to(dev)
         wt = torch.randn(total.shape, generator=g, dtype=torch.float64).to(dev)
         wb = [torch.randn(t.shape, generator=g).to(dev, dt) for t in (T, Bt, L, Rr)]
-        loss = (R * wR).sum() + (total * wt).sum() + sum((t * w_).sum().double() for t, w_ in zip((T, Bt, L, Rr), wb))
+        wP = torch.randn(P.shape, generator=g).to(dev, dt)
+        loss = (R * wR).sum() + (total * wt).sum() + sum((t * w_).sum().double() for t, w_ in zip((T, Bt, L, Rr), wb)) + (P * wP).sum().double()
         loss.backward()
-        outs.append((R.detach().cpu().double(), total.detach().cpu().double(), xi.grad.detach().cpu().double()))
-    (R0, t0, g0), (R1, t1, g1) = outs
+        outs.append((R.detach().cpu().double(), total.detach().cpu().double(), xi.grad.detach().cpu().double(), P.detach().cpu().double()))
+    (R0, t0, g0, P0), (R1, t1, g1, P1) = outs
+    assert (P0 - P1).abs().max().item() <= 1e-6 * max(P1.abs().max().item(), 1.0)     # gathered patches (fp32 copy of the input)
     n = B * H * W
     assert (R0 - R1).abs().max().item() <= 2e-6 * n ** 0.5 * max(R1.abs().max().item() / n ** 0.5, 1.0)
     assert (t0 - t1).abs().max().item() <= 1e-5 * n ** 0.5
