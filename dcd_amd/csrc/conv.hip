@@ -20,6 +20,7 @@
 // channel) on the opposite parity.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
 #include "lds_limit.h"
@@ -31,14 +32,28 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int WN_CH = 8;                          // input channels per chunk
-constexpr int WN_ROWS = 10;                       // window rows  r0-1 .. r0+8
-constexpr int WN_RS = 48;                         // window row stride (40 staged columns c0-4 .. c0+35)
-constexpr int WN_PLANE = WN_ROWS * WN_RS + 1;     // 481
-constexpr int WN_IN = WN_CH * WN_PLANE;           // 3848 floats
 constexpr int WN_KS = 64;                         // output channels per workgroup
 constexpr int WN_U = 16 * WN_KS * WN_CH;          // 8192 floats: [pos][k][h][4 steps]
-constexpr int WN_BUF = WN_IN + WN_U;              // 12040 floats per buffer
 constexpr int WN_NT = 512;
+
+// Region geometry: a tile group (4 waves, one per transform row) owns TR x TC Winograd tiles (<= 32: lane & 31 = tile), the
+// workgroup's two groups sit on top of each other, so the region is 4 TR x 2 TC pixels.
+//   <2,16>: 8 x 32 px (the maps whose width is a multiple of 32)
+//   <3,10>: 12 x 20 px, 30 of 32 lanes live: 24x80 and 12x40 maps divide exactly (no padded columns, and 256 workgroups = one
+//           per CU for 256 -> 256 @ 24x80 x 8 images where the 8 x 32 regions give 288 = two rounds)
+// Window row stride RS: 2 RS mod 64 is the bank step between tile rows -- 32 for 16 tile columns (16 even banks each), 20 for
+// 10 (banks 0-18 / 20-38 / 40-58); the plane stride is odd so the other lane half (next channel) takes the odd banks.
+template <int TR, int TC>
+struct WinoGeom {
+    static constexpr int NTILE = TR * TC;
+    static constexpr int ROWS = 4 * TR + 2;                   // window rows r0-1 .. r0+4TR
+    static constexpr int Q = (2 * TC + 8) / 4;                // staged dwordx4 per row: columns c0-4 .. c0+2TC+3
+    static constexpr int RS = TC == 16 ? 48 : 42;
+    static constexpr int PLANE = ROWS * RS + 1;
+    static constexpr int IN = WN_CH * PLANE;
+    static constexpr int BUF = IN + WN_U;
+    static_assert(NTILE <= 32 && 4 * Q <= RS && (ROWS * RS) % 2 == 0 && (2 * TC) % 4 == 0, "region geometry");
+};
 
 // Workgroups are dealt to the 8 XCDs round-robin: walk contiguous runs of regions per XCD (L2 locality of the halos).
 __device__ __forceinline__ void xcd_remap(int &bx, int &by)
@@ -96,11 +111,16 @@ __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict
     }
 }
 
-// grid = (regions, B, K/64); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
+// grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
+// ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
+// partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
+template <int TR, int TC>
 __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restrict__ x, const float *__restrict__ ul,
-                                                          float *__restrict__ y, int Cc, int H, int W, int Kk, int tiles_x,
-                                                          int nchunk)
+                                                          float *__restrict__ y, float *__restrict__ part, int Cc, int H, int W,
+                                                          int Kk, int tiles_x, int nchunk, int nz)
 {
+    using G = WinoGeom<TR, TC>;
+    constexpr int WN_ROWS = G::ROWS, WN_RS = G::RS, WN_PLANE = G::PLANE, WN_IN = G::IN, WN_BUF = G::BUF, WN_Q = G::Q;
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x WN_BUF (epilogue: 8 x 32 x 64 exchange)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -109,32 +129,35 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     int bx = blockIdx.x, b = blockIdx.y;
     xcd_remap(bx, b);
     const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
-    const int r0 = ty * 8, c0 = tx * 32;
-    const int z = blockIdx.z;
+    const int r0 = ty * (4 * TR), c0 = tx * (2 * TC);
+    const int z = blockIdx.z % nz, ks = blockIdx.z / nz, ksplit = gridDim.z / nz;
+    const int ck0 = (int)((int64_t)ks * nchunk / ksplit), ck1 = (int)((int64_t)(ks + 1) * nchunk / ksplit);
     const int HW = H * W;
-    const int tcol = p & 15, trow = p >> 4;
+    const bool live = p < G::NTILE;                       // idle lanes (TR TC < 32) read tile 0's window and store nothing
+    const int pe = live ? p : 0;
+    const int trow = pe / TC, tcol = pe - trow * TC;
 
     // B^T row pair and signs of this wave's xi:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
     const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
     const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
-    const int lanebase = (4 * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
+    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
     const int base1 = lanebase + ra * WN_RS, base2 = lanebase + rb * WN_RS;
 
     const float *x_b = x + (size_t)b * Cc * HW;
     const float *ul_z = ul + (size_t)z * nchunk * WN_U;
 
-    // ---- staging map (chunk invariant): window 8 ch x 10 rows x 10 dwordx4 = 800 items; weight slab 2048 dwordx4
-    constexpr int KIN = (WN_CH * WN_ROWS * 10 + WN_NT - 1) / WN_NT;      // 2
+    // ---- staging map (chunk invariant): window 8 ch x ROWS x Q dwordx4 (800 / 784 items); weight slab 2048 dwordx4
+    constexpr int KIN = (WN_CH * WN_ROWS * WN_Q + WN_NT - 1) / WN_NT;    // 2
     constexpr int KW = WN_U / 4 / WN_NT;                                 // 4
     int sg[KIN], sl[KIN];
     bool sv_[KIN];
 #pragma unroll
     for (int k = 0; k < KIN; ++k) {
         const int e = tid + WN_NT * k;
-        const int ch = e / (WN_ROWS * 10), rem = e - ch * (WN_ROWS * 10);
-        const int row = rem / 10, q = rem - row * 10;
+        const int ch = e / (WN_ROWS * WN_Q), rem = e - ch * (WN_ROWS * WN_Q);
+        const int row = rem / WN_Q, q = rem - row * WN_Q;
         const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * q;
-        sv_[k] = e < WN_CH * WN_ROWS * 10;
+        sv_[k] = e < WN_CH * WN_ROWS * WN_Q;
         sg[k] = (sv_[k] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ch * HW + yy * W + xx : -1;
         sl[k] = ch * WN_PLANE + row * WN_RS + 4 * q;
     }
@@ -146,7 +169,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
         for (int k = 0; k < KIN; ++k) {
             const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
             rin[k] = zero4;
-            if (sv_[k] && sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * 10) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
+            if (sv_[k] && sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * WN_Q) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
         }
         const float *wsrc = ul_z + (size_t)ck * WN_U;
 #pragma unroll
@@ -171,14 +194,14 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.f;
 
-    issue(0);
+    issue(ck0);
     commit(lds);
     __syncthreads();
 
-    for (int ck = 0; ck < nchunk; ++ck) {
-        const float *buf = lds + (ck & 1) * WN_BUF;
+    for (int ck = ck0; ck < ck1; ++ck) {
+        const float *buf = lds + ((ck - ck0) & 1) * WN_BUF;
 #ifndef WN_ABL_NOSTAGE
-        if (ck + 1 < nchunk) issue(ck + 1);
+        if (ck + 1 < ck1) issue(ck + 1);
 #endif
         const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
@@ -220,7 +243,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             }
         }
 #ifndef WN_ABL_NOSTAGE
-        if (ck + 1 < nchunk) commit(lds + ((ck + 1) & 1) * WN_BUF);
+        if (ck + 1 < ck1) commit(lds + ((ck + 1 - ck0) & 1) * WN_BUF);
 #endif
         __syncthreads();
     }
@@ -232,8 +255,8 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     // ex[wave][j*16 + r][lane]; per mb round 8 x 32 x 64 floats = 64 KB.  Every wave finalises four of the sixteen
     // accumulator rows (r = 4 xi .. 4 xi + 3) for both output rows, so the exchange reads and the stores are balanced.
     float *ex = lds;
-    float *y_b = y + (size_t)b * Kk * HW;
-    const int orow0 = r0 + 4 * tg + 2 * trow, ocol = c0 + 2 * tcol;
+    float *y_b = (ks == 0 ? y : part + (size_t)(ks - 1) * gridDim.y * Kk * HW) + (size_t)b * Kk * HW;
+    const int orow0 = r0 + 2 * TR * tg + 2 * trow, ocol = c0 + 2 * tcol;
 #pragma unroll
     for (int mb = 0; mb < 2; ++mb) {
         float *mine = ex + (size_t)wave * 32 * 64 + lane;
@@ -244,7 +267,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
         }
         __syncthreads();
         const float *t0 = ex + (size_t)(tg * 4 + 0) * 32 * 64 + lane, *t1 = t0 + 32 * 64, *t2 = t1 + 32 * 64, *t3 = t2 + 32 * 64;
-        if (ocol < W) {
+        if (live && ocol < W) {
 #pragma unroll
             for (int rr = 0; rr < 4; ++rr) {
                 const int r = 4 * xi + rr;
@@ -262,6 +285,15 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     }
 }
 
+// y += part[0] + part[1] + ... (fixed order), n4 = float4 count of one image set.
+__global__ __launch_bounds__(256) void wino_sum_partials(float *__restrict__ y, const float *__restrict__ part, size_t n4, int np)
+{
+    for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+        f32x4 a = reinterpret_cast<const f32x4 *>(y)[i];
+        for (int k = 0; k < np; ++k) a += reinterpret_cast<const f32x4 *>(part)[(size_t)k * n4 + i];
+        reinterpret_cast<f32x4 *>(y)[i] = a;
+    }
+}
 
 // ---------------------------------------------------------------------------------------------
 // Weight gradient of the same convolution, also in the Winograd domain:
@@ -503,14 +535,76 @@ __global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__
 
 }  // namespace
 
+// Region geometry and contraction split of one call.  The workgroup holds 103 KB of LDS and 8 waves with 128 accumulator
+// registers each, so exactly one sits on a CU: time ~ rounds of `cus` workgroups x chunks per workgroup.
+struct ConvPlan {
+    int geom;          // 0: 8 x 32 px regions, 1: 12 x 20 px
+    int tiles_x, tiles_y, nchunk, nz, ksplit;
+};
+
+static int device_cus()
+{
+    static int cus = 0;
+    if (!cus) {
+        int dev = 0, n = 0;
+        if (hipGetDevice(&dev) != hipSuccess || hipDeviceGetAttribute(&n, hipDeviceAttributeMultiprocessorCount, dev) != hipSuccess || n <= 0)
+            n = 256;
+        cus = n;
+    }
+    return cus;
+}
+
+static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
+{
+    ConvPlan best{};
+    const int cus = device_cus();
+    int64_t best_cost = -1;
+    for (int g = 0; g < 2; ++g) {
+        ConvPlan p;
+        p.geom = g;
+        p.tiles_x = g == 0 ? (W + 31) / 32 : (W + 19) / 20;
+        p.tiles_y = g == 0 ? (H + 7) / 8 : (H + 11) / 12;
+        p.nchunk = (Cc + WN_CH - 1) / WN_CH;
+        p.nz = (Kk + WN_KS - 1) / WN_KS;
+        const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
+        // split the contraction while the launch leaves CUs idle and a split keeps at least 8 chunks (its output transform
+        // and the partial image it writes are not free)
+        int ks = 1;
+        while (ks < 8 && wgs * (ks * 2) <= cus && p.nchunk / (ks * 2) >= 8) ks *= 2;
+        p.ksplit = ks;
+        const int64_t rounds = (wgs * ks + cus - 1) / cus;
+        const int64_t cost = rounds * ((p.nchunk + ks - 1) / ks + 2) * (g == 0 ? 16 : 17);     // 12x20: 30 of 32 lanes, more halo
+        if (best_cost < 0 || cost < best_cost) {
+            best_cost = cost;
+            best = p;
+        }
+    }
+    return best;
+}
+
+template <int TR, int TC>
+static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *input, const float *ul, float *output, float *part, int B,
+                       int Cc, int H, int W, int Kk)
+{
+    static LdsLimit lds_limit;
+    const size_t ldsb = (size_t)2 * WinoGeom<TR, TC>::BUF * sizeof(float);
+    if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32<TR, TC>)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino_conv3x3_f32<TR, TC>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream, input, ul,
+                       output, part, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    return DCD_OK;
+}
+
 extern "C" {
 
-size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout)
+size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 {
-    if (Cin <= 0 || Cout <= 0) return 0;
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     const int cmax = Cin > Cout ? Cin : Cout;
     const size_t nchunk = (size_t)(cmax + WN_CH - 1) / WN_CH, nz = (size_t)(cmax + WN_KS - 1) / WN_KS;
-    return nchunk * nz * WN_U * sizeof(float);
+    // transformed weights + the partial images of a split contraction (either direction of the call)
+    const ConvPlan f = conv_plan(B, Cin, H, W, Cout), d = conv_plan(B, Cout, H, W, Cin);
+    const size_t pf = (size_t)(f.ksplit - 1) * B * Cout * H * W, pd = (size_t)(d.ksplit - 1) * B * Cin * H * W;
+    return (nchunk * nz * WN_U + (pf > pd ? pf : pd)) * sizeof(float);
 }
 
 int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
@@ -522,19 +616,34 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *o
     if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
     // contraction channels Cc and produced channels Kk of this call
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
-    const int nchunk = (Cc + WN_CH - 1) / WN_CH, nz = (Kk + WN_KS - 1) / WN_KS;
-    if (workspace_bytes < (size_t)nchunk * nz * WN_U * sizeof(float)) return DCD_ERR_WORKSPACE;
-    float *ul = (float *)workspace;
-    static LdsLimit lds_limit;
-    const size_t ldsb = (size_t)2 * WN_BUF * sizeof(float);
-    if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32)) return DCD_ERR_LAUNCH;
-    const int nprep = nz * nchunk * WN_KS * WN_CH;
+    ConvPlan pl = conv_plan(B, Cc, H, W, Kk);
+    if (const char *e = getenv("DCD_CONV_GEOM")) {                     // A/B timing: "0" / "1" pins the region shape
+        const int g = atoi(e);
+        if (g == 0 || g == 1) {
+            ConvPlan q = pl;
+            q.geom = g;
+            q.tiles_x = g == 0 ? (W + 31) / 32 : (W + 19) / 20;
+            q.tiles_y = g == 0 ? (H + 7) / 8 : (H + 11) / 12;
+            q.ksplit = 1;
+            pl = q;
+        }
+    }
+    const size_t ul_floats = (size_t)pl.nchunk * pl.nz * WN_U;
+    const size_t img = (size_t)B * Kk * H * W;
+    if (workspace_bytes < (ul_floats + (size_t)(pl.ksplit - 1) * img) * sizeof(float)) return DCD_ERR_WORKSPACE;
+    float *ul = (float *)workspace, *part = ul + ul_floats;
+    const int nprep = pl.nz * pl.nchunk * WN_KS * WN_CH;
     // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
     hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
-                       ul, Cc, Kk, backward_data ? 1 : 0, nchunk, nz);
-    const int tiles_x = (W + 31) / 32, tiles_y = (H + 7) / 8;
-    hipLaunchKernelGGL(wino_conv3x3_f32, dim3(tiles_x * tiles_y, B, nz), dim3(WN_NT), ldsb, stream, input, ul, output, Cc, H, W, Kk,
-                       tiles_x, nchunk);
+                       ul, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz);
+    const int st = pl.geom == 0 ? conv_launch<2, 16>(stream, pl, input, ul, output, part, B, Cc, H, W, Kk)
+                                : conv_launch<3, 10>(stream, pl, input, ul, output, part, B, Cc, H, W, Kk);
+    if (st != DCD_OK) return st;
+    if (pl.ksplit > 1) {
+        const size_t n4 = img / 4;                                      // W % 4 == 0
+        const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wino_sum_partials, dim3(nb), dim3(256), 0, stream, output, (const float *)part, n4, pl.ksplit - 1);
+    }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -547,12 +547,16 @@ def batch_norm_act_eval(x, residual, weight, bias, running_mean, running_var, ep
 # ----------------------------------------------------------------------------------------------
 # 3x3 stride-1 convolution (Winograd F(2x2,3x3) on the matrix pipe): forward + input gradient
 # ----------------------------------------------------------------------------------------------
+_CONV_MIN_MAP = int(os.environ.get("DCD_CONV_MIN_MAP", str(12 * 40)))      # A/B timing: 7680 restores the round-1 dispatch
+
+
 def conv3x3_supported(x, weight):
     """Shapes the HIP kernel is used for: 3x3 weight, W % 4 == 0, H even, at least 64 input and output channels (narrower
-    layers would idle most of a 64-wide output slice), maps of at least 48x160 (measured cross-over, tools/time_conv.py)."""
+    layers would idle most of a 64-wide output slice), maps of at least 12x40 (the 12 x 20 px regions and the split
+    contraction of csrc/conv.hip keep every CU busy there; tools/time_conv.py)."""
     return (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3 and weight.shape[3] == 3
             and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] >= 64 and weight.shape[1] >= 64
-            and x.shape[2] * x.shape[3] >= 48 * 160)      # smaller maps: too few workgroups, the stock solver is as fast
+            and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
 
 
 def _conv3x3_call(inp, weight, out_channels, backward_data):
@@ -560,7 +564,7 @@ def _conv3x3_call(inp, weight, out_channels, backward_data):
     B, _, H, W = inp.shape
     Co, Ci = weight.shape[0], weight.shape[1]
     out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
-    n = L.dcd_conv3x3_workspace_bytes(Ci, Co)
+    n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
     ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
     st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Ci, H, W, Co,
                        1 if backward_data else 0, ws.data_ptr(), n)
@@ -617,11 +621,11 @@ def conv3x3(x, weight):
 
 
 def conv3x3_wrw_only_supported(x, weight):
-    """Maps too small for the Winograd forward kernel (too few workgroups) where the weight-gradient kernel still wins
-    (256->256 @ 24x80: 0.14 vs 0.18 ms incl. the stock path's transposes; at 12x40 they tie, tools/time_conv.py)."""
+    """Maps below the forward kernel's limit (only when DCD_CONV_MIN_MAP raises it) where the weight-gradient kernel still
+    wins (256->256 @ 24x80: 0.14 vs 0.18 ms incl. the stock path's transposes, tools/time_conv.py)."""
     return (_WRW_ENABLED and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3
             and weight.shape[3] == 3 and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[0] >= 64
-            and weight.shape[1] >= 64 and 24 * 80 <= x.shape[2] * x.shape[3] < 48 * 160)
+            and weight.shape[1] >= 64 and 24 * 80 <= x.shape[2] * x.shape[3] < _CONV_MIN_MAP)
 
 
 class _Conv3x3StockFwd(torch.autograd.Function):

@@ -281,10 +281,11 @@ int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const flo
  * i.e. torch's cudnn/MIOpen convolution and its input gradient (weight gradient: dcd_conv3x3_wrw below).
  * weight (Cout,Cin,3,3).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
  *                         backward_data = 1: input = grad_output (B,Cout,H,W) -> output = grad_input (B,Cin,H,W).
- * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(Cin, Cout) bytes
- * (transformed weights), dead after the call's kernels complete.
+ * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(B, Cin, H, W, Cout) bytes
+ * (transformed weights; partial images when few regions make the call split its contraction), dead after the call's
+ * kernels complete.
  * ---------------------------------------------------------------------------------------------- */
-size_t dcd_conv3x3_workspace_bytes(int Cin, int Cout);
+size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int dcd_conv3x3(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
                 int Cout, int backward_data, void *workspace, size_t workspace_bytes);
 

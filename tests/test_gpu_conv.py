@@ -10,7 +10,10 @@ CASES = [  # B, Cin, Cout, H, W
     (2, 64, 64, 16, 32),
     (1, 64, 256, 24, 64),      # head trunk shape, scaled down
     (2, 72, 80, 10, 36),       # ragged: partial regions, partial channel chunk / output slice
-    (1, 256, 64, 8, 32),       # small map: kernel called directly (the dispatcher would pick the stock op)
+    (1, 256, 64, 8, 32),       # small map, few regions: the contraction is split, partial images summed in fixed order
+    (2, 128, 64, 24, 80),      # 12 x 20 px regions (30 of 32 lanes live), exact cover
+    (1, 512, 72, 12, 40),      # one region row, 8-way split contraction, partial output slice
+    (2, 64, 64, 14, 44),       # 12 x 20 regions with ragged rows and columns
     (1, 128, 128, 48, 160),
     (3, 64, 64, 96, 176),      # 5.5 column strips, many splits of the weight-gradient tiles
 ]
@@ -38,6 +41,25 @@ def test_conv3x3_forward_and_input_grad(cuda, B, C, K, H, W):
     _close(y.detach().cpu(), ref.detach(), "forward")
     _close(xg.grad.cpu(), xd.grad, "grad_input")
     _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+
+
+@pytest.mark.parametrize("geom", ["0", "1"])
+@pytest.mark.parametrize("B,C,K,H,W", [(2, 64, 64, 14, 44), (1, 72, 80, 24, 80), (1, 64, 64, 26, 36)])
+def test_conv3x3_region_shapes(cuda, monkeypatch, geom, B, C, K, H, W):
+    """Both region shapes of the forward / input-gradient kernel (8 x 32 and 12 x 20 px) on maps neither divides."""
+    from dcd_amd import ops
+    monkeypatch.setenv("DCD_CONV_GEOM", geom)
+    g = torch.Generator().manual_seed(H * 100 + W)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    gy = torch.randn(B, K, H, W, generator=g)
+    xd, wd = x.double().requires_grad_(), w.double()
+    ref = F.conv2d(xd, wd, padding=1)
+    ref.backward(gy.double())
+    y = ops._conv3x3_call(x.to(cuda), w.to(cuda), K, False)
+    gx = ops._conv3x3_call(gy.to(cuda), w.to(cuda), C, True)
+    _close(y.cpu(), ref.detach(), "forward")
+    _close(gx.cpu(), xd.grad, "grad_input")
 
 
 def test_conv_module_dispatch(cuda):
@@ -205,21 +227,26 @@ def test_stem_dispatch(cuda):
     assert type(base(img.requires_grad_()).grad_fn).__name__ != "_ConvStemBackward"      # no input gradient for the 7x7: stock op
 
 
-def test_small_map_conv_uses_our_weight_gradient(cuda):
+def test_small_map_conv_runs_on_our_kernels(cuda):
+    """24x80 / 12x40 maps (DLA levels 4 and 5): forward, input and weight gradient all on csrc/conv.hip."""
     from dcd_amd.model.layers.conv import Conv2d
     conv = Conv2d(64, 96, 3, padding=1, bias=False).to(cuda)
     x = torch.randn(2, 64, 24, 80, device=cuda, requires_grad=True)
     gy = torch.randn(2, 96, 24, 80, device=cuda)
     y = conv(x)
-    assert type(y.grad_fn).__name__ == "_Conv3x3StockFwdBackward"
+    assert type(y.grad_fn).__name__ == "_Conv3x3Backward"
     y.backward(gy)
     xd, wd = x.detach().double().cpu().requires_grad_(), conv.weight.detach().double().cpu().requires_grad_()
-    F.conv2d(xd, wd, padding=1).backward(gy.double().cpu())
+    ref = F.conv2d(xd, wd, padding=1)
+    ref.backward(gy.double().cpu())
+    _close(y.detach().cpu(), ref.detach(), "forward")
     _close(conv.weight.grad.cpu(), wd.grad, "grad_weight", 2e-5)
-    _close(x.grad.cpu(), xd.grad, "grad_input", 1e-4)
+    _close(x.grad.cpu(), xd.grad, "grad_input")
+    again = conv(x)
+    assert torch.equal(again, y), "split contraction must be reproducible (partials summed in a fixed order)"
 
 
-@pytest.mark.parametrize("C,K,H,W", [(64, 256, 96, 320), (128, 128, 48, 160)])
+@pytest.mark.parametrize("C,K,H,W", [(64, 256, 96, 320), (128, 128, 48, 160), (256, 256, 24, 80), (512, 512, 12, 40)])
 def test_conv3x3_full_size_against_stock_solver(cuda, C, K, H, W):
     """BASELINE size (bs 8): our three Winograd kernels against the stock fp32 solver on the same device tensors.  Both are
     fp32 algorithms of the same class, so the comparison is relative to the result's scale; plus linearity of the weight

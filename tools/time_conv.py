@@ -6,6 +6,8 @@ from torch.nn import functional as F
 from dcd_amd import ops
 
 SHAPES = [(64, 256, 96, 320), (256, 64, 96, 320), (64, 64, 96, 320), (128, 128, 48, 160), (256, 256, 24, 80), (512, 512, 12, 40)]
+if os.environ.get("DCD_TIME_OFFSET_CONVS"):          # the DCN layers' conv_offset_mask shapes (27 outputs)
+    SHAPES = [(64, 27, 96, 320), (128, 27, 48, 160), (256, 27, 24, 80), (512, 27, 12, 40)]
 
 
 def t(fn, iters=10):
