@@ -774,10 +774,15 @@ def fan_out(x, n):
     return _FanOut.apply(x, n)
 
 
+_OFFSET_CONV_BWD = os.environ.get("DCD_OFFSET_CONV_BWD", "1") != "0"       # 0: stock input / weight gradients (A/B timing)
+
+
 class _ConvBias(torch.autograd.Function):
-    """Stock conv2d with a bias; only the bias gradient is ours: ATen's generic reduction sums the (B,27,H,W) gradient
-    of a `conv_offset_mask` at 0.4 TB/s (0.9 ms per step over the 16 layers), the two-stage sums of csrc/norm.hip at HBM
-    speed."""
+    """conv2d with a bias (DCN's `conv_offset_mask`): stock forward; the bias gradient by the two-stage sums of csrc/norm.hip
+    (ATen's generic reduction sums the (B,27,H,W) gradient at 0.4 TB/s: 0.9 ms per step over the 16 layers); for the 3x3 /
+    stride 1 / pad 1 layers the input gradient on csrc/conv.hip (27 -> Cin: 71 vs 97 us at 64 @ 96x320, 37 vs 53 at
+    128 @ 48x160) and, on maps of at least 48x160, the weight gradient too (121 vs 147 us + the stock path's NHWC transposes
+    of both operands); tools/time_conv.py with DCD_TIME_OFFSET_CONVS=1."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
@@ -791,8 +796,21 @@ class _ConvBias(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, padding, dilation = ctx.conf
         gy = _f32c(gy)
-        gx, gw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
-                                                        [ctx.needs_input_grad[0], ctx.needs_input_grad[1], False])
+        ours = (_OFFSET_CONV_BWD and weight.shape[2] == 3 and weight.shape[3] == 3 and stride == [1, 1] and padding == [1, 1]
+                and dilation == [1, 1] and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[1] >= 64
+                and x.is_contiguous() and weight.is_contiguous())
+        ours_w = ours and _WRW_ENABLED and x.shape[2] * x.shape[3] >= 48 * 160
+        gx = gw = None
+        if ours and ctx.needs_input_grad[0]:
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True)
+        if ours_w and ctx.needs_input_grad[1]:
+            gw = _conv3x3_wrw_call(x, gy, weight.shape)
+        need_x, need_w = ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1] and gw is None
+        if need_x or need_w:
+            sx, sw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, False, [0, 0], 1,
+                                                            [need_x, need_w, False])
+            gx = sx if need_x else gx
+            gw = sw if need_w else gw
         gb = None
         if ctx.needs_input_grad[2]:
             L = _lib.lib()

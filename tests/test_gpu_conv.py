@@ -192,6 +192,32 @@ def test_conv_bias_gradient(cuda):
     _close(got[2].cpu(), x.grad.double().cpu(), "input grad", 1e-5)
 
 
+@pytest.mark.parametrize("B,C,H,W", [(2, 64, 48, 160), (1, 128, 24, 80), (2, 256, 12, 40)])
+def test_offset_conv_backward_on_our_kernels(cuda, B, C, H, W):
+    """`conv_offset_mask` (Cin -> 27, 3x3, bias): input gradient (and, from 48x160, weight gradient) on csrc/conv.hip with a
+    27-wide contraction / output slice; against fp64."""
+    from dcd_amd.model.layers.conv import Conv2d
+    g = torch.Generator().manual_seed(C + H)
+    conv = Conv2d(C, 27, 3, padding=1, bias=True)
+    conv.weight.data = torch.randn(27, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    conv.bias.data = torch.randn(27, generator=g)
+    x = torch.randn(B, C, H, W, generator=g)
+    gy = torch.randn(B, 27, H, W, generator=g)
+    xd = x.double().requires_grad_()
+    wd, bd = conv.weight.detach().double().requires_grad_(), conv.bias.detach().double().requires_grad_()
+    ref = F.conv2d(xd, wd, bd, padding=1)
+    ref.backward(gy.double())
+    from dcd_amd import ops
+    conv = conv.to(cuda)
+    xg = x.to(cuda).requires_grad_()
+    y = ops.conv2d_bias(xg, conv.weight, conv.bias, (1, 1), (1, 1), (1, 1))    # what the module dispatches to on large maps
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref.detach(), "forward", 1e-4)                 # stock fp32 solver
+    _close(xg.grad.cpu(), xd.grad, "grad_input")
+    _close(conv.weight.grad.cpu(), wd.grad, "grad_weight", 1e-4 if H * W < 48 * 160 else 2e-5)
+    _close(conv.bias.grad.cpu(), bd.grad, "grad_bias", 1e-5)
+
+
 @pytest.mark.parametrize("B,Ci,k,H,W", [(2, 16, 3, 40, 320), (1, 3, 7, 48, 384), (2, 16, 3, 19, 260), (1, 3, 7, 21, 196)])
 def test_stem_convolutions(cuda, B, Ci, k, H, W):
     """csrc/stem.hip (16x16x4 MFMA direct conv) against torch's conv2d in fp64: forward, input gradient (16->16) and weight

@@ -42,6 +42,26 @@ def main():
         ev[4].record()
         marks.append(ev)
     torch.cuda.synchronize()
+    # the loss section alone (forward graph, backward graph) on fixed predictions
+    heads = model.heads
+    features = model.backbone(to_image_list(images).tensors)
+    predictions = heads.predictor(features, targets)
+    preds = {k: (v.detach().requires_grad_(True) if torch.is_tensor(v) and v.is_floating_point() else v) for k, v in predictions.items()}
+    lf = lb = 0.0
+    for it in range(args.steps + 2):
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        ld, _ = heads.loss_evaluator(preds, targets)
+        total = getattr(ld, "total", None)
+        total = total if total is not None else sum(ld.values())
+        e[1].record()
+        total.backward()
+        e[2].record()
+        torch.cuda.synchronize()
+        if it >= 2:
+            lf += e[0].elapsed_time(e[1]) / args.steps
+            lb += e[1].elapsed_time(e[2]) / args.steps
+    print("loss section alone: forward %.2f ms, backward %.2f ms (GPU, events around the calls; host-bound if eager)" % (lf, lb))
     n = len(marks)
     acc = [sum(e[i].elapsed_time(e[i + 1]) for e in marks) / n for i in range(4)]
     print("batch %d: GPU ms/step  backbone fwd %.2f | heads+loss fwd %.2f | backward %.2f | clip+adam %.2f | sum %.2f" % (
