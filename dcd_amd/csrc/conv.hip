@@ -32,8 +32,7 @@ typedef float f32x2 __attribute__((ext_vector_type(2)));
 namespace {
 
 constexpr int WN_CH = 8;                          // input channels per chunk
-constexpr int WN_KS = 64;                         // output channels per workgroup
-constexpr int WN_U = 16 * WN_KS * WN_CH;          // 8192 floats: [pos][k][h][4 steps]
+// output channels per workgroup: 32 NB (NB = 2; NB = 1 for layers of at most 32 outputs -- DCN's 27-channel offset convs)
 constexpr int WN_NT = 512;
 
 // Region geometry: a tile group (4 waves, one per transform row) owns TR x TC Winograd tiles (<= 32: lane & 31 = tile), the
@@ -43,15 +42,17 @@ constexpr int WN_NT = 512;
 //           per CU for 256 -> 256 @ 24x80 x 8 images where the 8 x 32 regions give 288 = two rounds)
 // Window row stride RS: 2 RS mod 64 is the bank step between tile rows -- 32 for 16 tile columns (16 even banks each), 20 for
 // 10 (banks 0-18 / 20-38 / 40-58); the plane stride is odd so the other lane half (next channel) takes the odd banks.
-template <int TR, int TC>
+template <int TR, int TC, int NB>
 struct WinoGeom {
+    static constexpr int KS = 32 * NB;
+    static constexpr int U = 16 * KS * WN_CH;                 // 8192 / 4096 floats: [pos][k][h][4 steps]
     static constexpr int NTILE = TR * TC;
     static constexpr int ROWS = 4 * TR + 2;                   // window rows r0-1 .. r0+4TR
     static constexpr int Q = (2 * TC + 8) / 4;                // staged dwordx4 per row: columns c0-4 .. c0+2TC+3
     static constexpr int RS = TC == 16 ? 48 : 42;
     static constexpr int PLANE = ROWS * RS + 1;
     static constexpr int IN = WN_CH * PLANE;
-    static constexpr int BUF = IN + WN_U;
+    static constexpr int BUF = IN + U;
     static_assert(NTILE <= 32 && 4 * Q <= RS && (ROWS * RS) % 2 == 0 && (2 * TC) % 4 == 0, "region geometry");
 };
 
@@ -68,12 +69,13 @@ __device__ __forceinline__ void xcd_remap(int &bx, int &by)
 }
 
 // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
-// ul[z][chunk][pos = 4 xi + nu][kk (64)][h (2)][s (4)] for output channel z*64+kk and contraction channel chunk*8 + 2s + h.
+// ul[z][chunk][pos = 4 xi + nu][kk (KS)][h (2)][s (4)] for output channel z*KS+kk and contraction channel chunk*8 + 2s + h.
 // mode 0: forward        (contraction over Cin:  g = w[k][c][a][b])
 // mode 1: backward-data  (contraction over Cout: g = w[c][k][2-a][2-b], i.e. output channel = input channel of w)
-__global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz)
+__global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz,
+                                  int WN_KS)
 {
-    const int n = nz * nchunk * 16 * WN_KS * WN_CH / 16;          // one thread per (z, chunk, kk, h, s): writes 16 positions
+    const int n = nz * nchunk * WN_KS * WN_CH;                    // one thread per (z, chunk, kk, h, s): writes 16 positions
     for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
         int r = idx;
         const int s = r & 3; r >>= 2;
@@ -114,13 +116,16 @@ __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict
 // grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
 // ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
 // partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
-template <int TR, int TC>
+// bias (may be null): added to the output channels by split 0.
+template <int TR, int TC, int NB>
 __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restrict__ x, const float *__restrict__ ul,
-                                                          float *__restrict__ y, float *__restrict__ part, int Cc, int H, int W,
-                                                          int Kk, int tiles_x, int nchunk, int nz)
+                                                          float *__restrict__ y, float *__restrict__ part,
+                                                          const float *__restrict__ bias, int Cc, int H, int W, int Kk,
+                                                          int tiles_x, int nchunk, int nz)
 {
-    using G = WinoGeom<TR, TC>;
+    using G = WinoGeom<TR, TC, NB>;
     constexpr int WN_ROWS = G::ROWS, WN_RS = G::RS, WN_PLANE = G::PLANE, WN_IN = G::IN, WN_BUF = G::BUF, WN_Q = G::Q;
+    constexpr int WN_KS = G::KS, WN_U = G::U;
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x WN_BUF (epilogue: 8 x 32 x 64 exchange)
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -148,7 +153,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 
     // ---- staging map (chunk invariant): window 8 ch x ROWS x Q dwordx4 (800 / 784 items); weight slab 2048 dwordx4
     constexpr int KIN = (WN_CH * WN_ROWS * WN_Q + WN_NT - 1) / WN_NT;    // 2
-    constexpr int KW = WN_U / 4 / WN_NT;                                 // 4
+    constexpr int KW = WN_U / 4 / WN_NT;                                 // 4 (2 with one output block)
     int sg[KIN], sl[KIN];
     bool sv_[KIN];
 #pragma unroll
@@ -186,11 +191,11 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
         for (int k = 0; k < KW; ++k) *reinterpret_cast<f32x4 *>(buf + WN_IN + 4 * (tid + WN_NT * k)) = rw[k];
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NB];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int mb = 0; mb < 2; ++mb)
+        for (int mb = 0; mb < NB; ++mb)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.f;
 
@@ -210,7 +215,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             a0[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
-            a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
+            if (NB == 2) a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
         }
         // software pipeline over the four channel steps: the eight LDS values of step s+1 are requested before the eight
         // MFMAs of step s are issued (in-order issue: otherwise their latency is exposed once the matrix pipe drains)
@@ -239,7 +244,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(a0[nu][s], v[nu], acc[nu][0], 0, 0, 0);
-                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[nu][s], v[nu], acc[nu][1], 0, 0, 0);
+                if (NB == 2) acc[nu][NB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(a1[nu][s], v[nu], acc[nu][NB - 1], 0, 0, 0);
             }
         }
 #ifndef WN_ABL_NOSTAGE
@@ -258,7 +263,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     float *y_b = (ks == 0 ? y : part + (size_t)(ks - 1) * gridDim.y * Kk * HW) + (size_t)b * Kk * HW;
     const int orow0 = r0 + 2 * TR * tg + 2 * trow, ocol = c0 + 2 * tcol;
 #pragma unroll
-    for (int mb = 0; mb < 2; ++mb) {
+    for (int mb = 0; mb < NB; ++mb) {
         float *mine = ex + (size_t)wave * 32 * 64 + lane;
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
@@ -275,9 +280,10 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
                 const float a0 = t0[r * 64], a1 = t1[r * 64], a2 = t2[r * 64], a3 = t3[r * 64];
                 const float b0 = t0[(16 + r) * 64], b1 = t1[(16 + r) * 64], b2 = t2[(16 + r) * 64], b3 = t3[(16 + r) * 64];
                 if (k < Kk) {
+                    const float bk = (bias && ks == 0) ? bias[k] : 0.f;
                     float *dst = y_b + (size_t)k * HW + (size_t)orow0 * W + ocol;
-                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2, b0 + b1 + b2};
-                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3, b1 - b2 - b3};
+                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2 + bk, b0 + b1 + b2 + bk};
+                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3 + bk, b1 - b2 - b3 + bk};
                 }
             }
         }
@@ -313,14 +319,21 @@ constexpr int WW_IROW = 40;                        // staged columns c0-4 .. c0+
 constexpr int WW_IPLANE = 4 * WW_IROW + 2;         // 162 = 2 * 81
 constexpr int WW_DPLANE = 2 * 32 + 2;              // 66 = 2 * 33
 constexpr int WW_IN = 64 * WW_IPLANE;              // 10 368 floats
-constexpr int WW_DY = 64 * WW_DPLANE;              // 4 224 floats
-constexpr int WW_BUF = WW_IN + WW_DY;              // 14 592 floats (58 KB) per buffer
-constexpr int WW_PART = 16 * 64 * 64;              // floats per partial result
+// NOB = 32-channel output blocks per workgroup: 2, or 1 for layers of at most 32 outputs (DCN's 27-channel offset convs)
+template <int NOB>
+struct WrwGeom {
+    static constexpr int KO = 32 * NOB;
+    static constexpr int DY = KO * WW_DPLANE;      // 4 224 / 2 112 floats
+    static constexpr int BUF = WW_IN + DY;         // 14 592 floats (58 KB) per buffer with NOB = 2
+    static constexpr int PART = 16 * KO * 64;      // floats per partial result
+};
 
+template <int NOB>
 __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ part, int Cin, int Cout, int B, int H, int W,
                                                          int strips_x, int S, int ncg, int nblk)
 {
+    constexpr int KO = WrwGeom<NOB>::KO, WW_BUF = WrwGeom<NOB>::BUF, WW_PART = WrwGeom<NOB>::PART;
     extern __shared__ __attribute__((aligned(16))) float lds[];       // 2 x [WW_IN | WW_DY]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wave = tid >> 6;
@@ -352,7 +365,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 
     // ---- staging maps (strip invariant)
     constexpr int KIN = 64 * 4 * 10 / WW_NT;       // 5 dwordx4 per thread
-    constexpr int KDY = 64 * 2 * 8 / WW_NT;        // 2
+    constexpr int KDY = KO * 2 * 8 / WW_NT;        // 2 (1 with one output block)
     int in_ch[KIN], in_row[KIN], in_q[KIN], dy_o[KDY], dy_row[KDY], dy_q[KDY];
 #pragma unroll
     for (int k = 0; k < KIN; ++k) {
@@ -377,7 +390,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         const int ty = rem / strips_x, sx = rem - ty * strips_x;
         const int r0 = 2 * ty, c0 = 32 * sx;
         const float *x_b = x + ((size_t)b * Cin + (size_t)cg * 64) * HW;
-        const float *g_b = gy + ((size_t)b * Cout + (size_t)og * 64) * HW;
+        const float *g_b = gy + ((size_t)b * Cout + (size_t)og * KO) * HW;
         const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
         for (int k = 0; k < KIN; ++k) {
@@ -390,7 +403,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         for (int k = 0; k < KDY; ++k) {
             const int yy = r0 + dy_row[k], xx = c0 + 4 * dy_q[k];
             rdy[k] = zero4;
-            if (og * 64 + dy_o[k] < Cout && xx < W)
+            if (og * KO + dy_o[k] < Cout && xx < W)
                 rdy[k] = *reinterpret_cast<const f32x4 *>(g_b + (size_t)dy_o[k] * HW + yy * W + xx);
         }
     };
@@ -409,11 +422,11 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         }
     };
 
-    f32x16 acc[4][2];
+    f32x16 acc[4][NOB];
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][ob][r] = 0.f;
 
@@ -435,7 +448,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         const float *bw = lds + ((t - t0) & 1) * WW_BUF;
         float *nb = lds + (((t - t0) & 1) ^ 1) * WW_BUF;
         const float *ia = bw + lane_in + ra * WW_IROW, *ib = bw + lane_in + rb * WW_IROW;
-        const float *d0 = bw + WW_IN + lane_dy, *d1 = d0 + 32 * WW_DPLANE;
+        const float *d0 = bw + WW_IN + lane_dy, *d1 = d0 + (NOB - 1) * 32 * WW_DPLANE;        // one block: d1 = d0, unused
         // software pipeline over the eight steps: the raw LDS values of step s+1 are requested before the eight MFMAs of
         // step s are issued (in-order issue: loads placed after them would wait for the matrix pipe to accept all eight)
 #ifdef WW_ABL_NOLDS
@@ -475,7 +488,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) {
                 acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
-                acc[nu][1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][1], 0, 0, 0);
+                if (NOB == 2) acc[nu][NOB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][NOB - 1], 0, 0, 0);
             }
             u0 = u2;
             u1 = u3;
@@ -493,28 +506,29 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 #pragma unroll
     for (int nu = 0; nu < 4; ++nu)
 #pragma unroll
-        for (int ob = 0; ob < 2; ++ob)
+        for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
             for (int r = 0; r < 16; ++r) {
                 const int k = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
-                mine[((xi * 4 + nu) * 64 + k) * 64 + cb * 32 + p] = acc[nu][ob][r];
+                mine[((xi * 4 + nu) * KO + k) * 64 + cb * 32 + p] = acc[nu][ob][r];
             }
 }
 
-// grid = (nblk * 4096 / 16), block = 256 = 16 positions x 16 (k,c) pairs: sums the S partials of its 16 pairs (fixed order:
-// reproducible), exchanges the 16 positions through LDS and writes dw = G^T M G.
+// grid = (nblk * KO * 64 / 16), block = 256 = 16 positions x 16 (k,c) pairs: sums the S partials of its 16 pairs (fixed order:
+// reproducible), exchanges the 16 positions through LDS and writes dw = G^T M G.  KO = output channels per block (64 / 32).
 __global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__ part, float *__restrict__ gw, int Cin, int Cout, int S,
-                                                       int ncg)
+                                                       int ncg, int KO)
 {
     __shared__ float m[16][17];
     const int tid = threadIdx.x;
     const int pos = tid >> 4, l = tid & 15;
     const int gidx = blockIdx.x * 16 + l;           // (blk, k, c)
-    const int blk = gidx >> 12, kc = gidx & 4095;
-    const float *src = part + ((size_t)blk * S * 16 + pos) * 4096 + kc;
+    const int per = KO * 64;
+    const int blk = gidx / per, kc = gidx - blk * per;
+    const float *src = part + ((size_t)blk * S * 16 + pos) * per + kc;
     float sum = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < S; ++sp) sum += src[(size_t)sp * WW_PART];
+    for (int sp = 0; sp < S; ++sp) sum += src[(size_t)sp * 16 * per];
     m[pos][l] = sum;
     __syncthreads();
     if (pos < 9) {
@@ -528,7 +542,7 @@ __global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu) r += ga[xi] * gb[nu] * m[xi * 4 + nu][l];
         const int og = blk / ncg, cg = blk - og * ncg;
-        const int k = og * 64 + (kc >> 6), c = cg * 64 + (kc & 63);
+        const int k = og * KO + (kc >> 6), c = cg * 64 + (kc & 63);
         if (k < Cout && c < Cin) gw[((size_t)k * Cin + c) * 9 + pos] = r;
     }
 }
@@ -539,6 +553,7 @@ __global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__
 // registers each, so exactly one sits on a CU: time ~ rounds of `cus` workgroups x chunks per workgroup.
 struct ConvPlan {
     int geom;          // 0: 8 x 32 px regions, 1: 12 x 20 px
+    int nb;            // 32-channel output blocks per workgroup: 2, or 1 for layers of at most 32 outputs
     int tiles_x, tiles_y, nchunk, nz, ksplit;
 };
 
@@ -565,7 +580,8 @@ static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
         p.tiles_x = g == 0 ? (W + 31) / 32 : (W + 19) / 20;
         p.tiles_y = g == 0 ? (H + 7) / 8 : (H + 11) / 12;
         p.nchunk = (Cc + WN_CH - 1) / WN_CH;
-        p.nz = (Kk + WN_KS - 1) / WN_KS;
+        p.nb = Kk <= 32 ? 1 : 2;
+        p.nz = (Kk + 32 * p.nb - 1) / (32 * p.nb);
         const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
         // split the contraction while the launch leaves CUs idle and a split keeps at least 8 chunks (its output transform
         // and the partial image it writes are not free)
@@ -582,15 +598,16 @@ static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
     return best;
 }
 
-template <int TR, int TC>
-static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *input, const float *ul, float *output, float *part, int B,
-                       int Cc, int H, int W, int Kk)
+template <int TR, int TC, int NB>
+static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *input, const float *ul, float *output, float *part,
+                       const float *bias, int B, int Cc, int H, int W, int Kk)
 {
     static LdsLimit lds_limit;
-    const size_t ldsb = (size_t)2 * WinoGeom<TR, TC>::BUF * sizeof(float);
-    if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32<TR, TC>)) return DCD_ERR_LAUNCH;
-    hipLaunchKernelGGL((wino_conv3x3_f32<TR, TC>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream, input, ul,
-                       output, part, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    size_t ldsb = (size_t)2 * WinoGeom<TR, TC, NB>::BUF * sizeof(float);
+    if (ldsb < (size_t)8 * 32 * 64 * sizeof(float)) ldsb = (size_t)8 * 32 * 64 * sizeof(float);      // the epilogue's exchange
+    if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32<TR, TC, NB>)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino_conv3x3_f32<TR, TC, NB>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream,
+                       input, ul, output, part, bias, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
     return DCD_OK;
 }
 
@@ -600,20 +617,20 @@ size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     const int cmax = Cin > Cout ? Cin : Cout;
-    const size_t nchunk = (size_t)(cmax + WN_CH - 1) / WN_CH, nz = (size_t)(cmax + WN_KS - 1) / WN_KS;
+    const size_t nchunk = (size_t)(cmax + WN_CH - 1) / WN_CH, nz = (size_t)(cmax + 63) / 64;
     // transformed weights + the partial images of a split contraction (either direction of the call)
     const ConvPlan f = conv_plan(B, Cin, H, W, Cout), d = conv_plan(B, Cout, H, W, Cin);
     const size_t pf = (size_t)(f.ksplit - 1) * B * Cout * H * W, pd = (size_t)(d.ksplit - 1) * B * Cin * H * W;
-    return (nchunk * nz * WN_U + (pf > pd ? pf : pd)) * sizeof(float);
+    return (nchunk * nz * 16 * 64 * WN_CH + (pf > pd ? pf : pd)) * sizeof(float);
 }
 
-int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
-                int Cout, int backward_data, void *workspace, size_t workspace_bytes)
+int dcd_conv3x3(void *stream_, const float *input, const float *weight, const float *bias, float *output, int B, int Cin, int H,
+                int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (!input || !weight || !output || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
-    if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31) || (bias && backward_data)) return DCD_ERR_BAD_ARG;
     // contraction channels Cc and produced channels Kk of this call
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
     ConvPlan pl = conv_plan(B, Cc, H, W, Kk);
@@ -628,16 +645,19 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *o
             pl = q;
         }
     }
-    const size_t ul_floats = (size_t)pl.nchunk * pl.nz * WN_U;
+    const int ksz = 32 * pl.nb;
+    const size_t ul_floats = (size_t)pl.nchunk * pl.nz * 16 * ksz * WN_CH;
     const size_t img = (size_t)B * Kk * H * W;
     if (workspace_bytes < (ul_floats + (size_t)(pl.ksplit - 1) * img) * sizeof(float)) return DCD_ERR_WORKSPACE;
     float *ul = (float *)workspace, *part = ul + ul_floats;
-    const int nprep = pl.nz * pl.nchunk * WN_KS * WN_CH;
+    const int nprep = pl.nz * pl.nchunk * ksz * WN_CH;
     // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
     hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
-                       ul, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz);
-    const int st = pl.geom == 0 ? conv_launch<2, 16>(stream, pl, input, ul, output, part, B, Cc, H, W, Kk)
-                                : conv_launch<3, 10>(stream, pl, input, ul, output, part, B, Cc, H, W, Kk);
+                       ul, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz, ksz);
+    const int st = pl.geom == 0 ? (pl.nb == 2 ? conv_launch<2, 16, 2>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk)
+                                              : conv_launch<2, 16, 1>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk))
+                                : (pl.nb == 2 ? conv_launch<3, 10, 2>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk)
+                                              : conv_launch<3, 10, 1>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk));
     if (st != DCD_OK) return st;
     if (pl.ksplit > 1) {
         const size_t n4 = img / 4;                                      // W % 4 == 0
@@ -647,9 +667,10 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, float *o
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
-static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int &ncg, int &S, int &strips_x)
+static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int &ncg, int &S, int &strips_x, int &KO)
 {
-    nog = (Cout + 63) / 64;
+    KO = Cout <= 32 ? 32 : 64;
+    nog = (Cout + KO - 1) / KO;
     ncg = (Cin + 63) / 64;
     strips_x = (W + 31) / 32;
     const int T = B * (H / 2) * strips_x;
@@ -662,9 +683,9 @@ static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int 
 size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 {
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
-    int nog, ncg, S, sx;
-    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, sx);
-    return (size_t)nog * ncg * S * WW_PART * sizeof(float);
+    int nog, ncg, S, sx, KO;
+    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, sx, KO);
+    return (size_t)nog * ncg * S * 16 * KO * 64 * sizeof(float);
 }
 
 int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
@@ -674,17 +695,25 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     (void)hipGetLastError();
     if (!input || !grad_output || !grad_weight || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
     if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
-    int nog, ncg, S, strips_x;
-    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x);
+    int nog, ncg, S, strips_x, KO;
+    wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x, KO);
     const int nblk = nog * ncg;
-    if (workspace_bytes < (size_t)nblk * S * WW_PART * sizeof(float)) return DCD_ERR_WORKSPACE;
-    static LdsLimit lds_limit;
-    const size_t ldsb = (size_t)2 * WW_BUF * sizeof(float);
-    if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32)) return DCD_ERR_LAUNCH;
-    hipLaunchKernelGGL(wino_wrw3x3_f32, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout, B,
-                       H, W, strips_x, S, ncg, nblk);
-    hipLaunchKernelGGL(wino_wrw_reduce, dim3(nblk * 4096 / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout, S,
-                       ncg);
+    if (workspace_bytes < (size_t)nblk * S * 16 * KO * 64 * sizeof(float)) return DCD_ERR_WORKSPACE;
+    if (KO == 64) {
+        static LdsLimit lds_limit;
+        const size_t ldsb = (size_t)2 * WrwGeom<2>::BUF * sizeof(float);
+        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<2>)) return DCD_ERR_LAUNCH;
+        hipLaunchKernelGGL(wino_wrw3x3_f32<2>, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout,
+                           B, H, W, strips_x, S, ncg, nblk);
+    } else {
+        static LdsLimit lds_limit;
+        const size_t ldsb = (size_t)2 * WrwGeom<1>::BUF * sizeof(float);
+        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<1>)) return DCD_ERR_LAUNCH;
+        hipLaunchKernelGGL(wino_wrw3x3_f32<1>, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout,
+                           B, H, W, strips_x, S, ncg, nblk);
+    }
+    hipLaunchKernelGGL(wino_wrw_reduce, dim3(nblk * KO * 64 / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout,
+                       S, ncg, KO);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

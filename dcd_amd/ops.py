@@ -559,14 +559,14 @@ def conv3x3_supported(x, weight):
             and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
 
 
-def _conv3x3_call(inp, weight, out_channels, backward_data):
+def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None):
     L = _lib.lib()
     B, _, H, W = inp.shape
     Co, Ci = weight.shape[0], weight.shape[1]
     out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
     n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
     ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
-    st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), out.data_ptr(), B, Ci, H, W, Co,
+    st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr(), B, Ci, H, W, Co,
                        1 if backward_data else 0, ws.data_ptr(), n)
     _lib.check(st, "dcd_conv3x3")
     return out
@@ -775,19 +775,28 @@ def fan_out(x, n):
 
 
 _OFFSET_CONV_BWD = os.environ.get("DCD_OFFSET_CONV_BWD", "1") != "0"       # 0: stock input / weight gradients (A/B timing)
+_OFFSET_CONV_FWD = os.environ.get("DCD_OFFSET_CONV_FWD", "1") != "0"       # 0: stock forward
 
 
 class _ConvBias(torch.autograd.Function):
-    """conv2d with a bias (DCN's `conv_offset_mask`): stock forward; the bias gradient by the two-stage sums of csrc/norm.hip
-    (ATen's generic reduction sums the (B,27,H,W) gradient at 0.4 TB/s: 0.9 ms per step over the 16 layers); for the 3x3 /
-    stride 1 / pad 1 layers the input gradient on csrc/conv.hip (27 -> Cin: 71 vs 97 us at 64 @ 96x320, 37 vs 53 at
-    128 @ 48x160) and, on maps of at least 48x160, the weight gradient too (121 vs 147 us + the stock path's NHWC transposes
-    of both operands); tools/time_conv.py with DCD_TIME_OFFSET_CONVS=1."""
+    """conv2d with a bias (DCN's `conv_offset_mask`, Cin -> 27).  The 3x3 / stride 1 / pad 1 layers with at least 64 inputs run
+    on csrc/conv.hip: forward with the bias added in the output transform, input gradient and weight gradient, all on the
+    kernels' one-output-block variants (a 64-wide output slice would be 58 % padding).  bs 8, ours vs stock (tools/time_conv.py
+    with DCD_TIME_OFFSET_CONVS=1): 64 @ 96x320 forward 76 vs 101 us, input gradient 71-80 vs 100, weight gradient 80 vs 147 +
+    the stock path's NHWC transposes of both operands; 128 @ 48x160: 37 / 40 / 48 vs 51 / 55 / 80.
+    The bias gradient comes from the two-stage sums of csrc/norm.hip (ATen's generic reduction sums the (B,27,H,W) gradient at
+    0.4 TB/s: 0.9 ms per step over the 16 layers).  Everything else: stock op."""
 
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
-        ctx.save_for_backward(x, weight)
         ctx.conf = (list(stride), list(padding), list(dilation))
+        ctx.ours = (_OFFSET_CONV_BWD and x.is_cuda and x.dtype == torch.float32 and weight.shape[2] == 3 and weight.shape[3] == 3
+                    and ctx.conf == ([1, 1], [1, 1], [1, 1]) and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[1] >= 64)
+        if ctx.ours:
+            x, weight = _f32c(x), _f32c(weight)
+        ctx.save_for_backward(x, weight)
+        if ctx.ours and _OFFSET_CONV_FWD:
+            return _conv3x3_call(x, weight, weight.shape[0], False, _f32c(bias))
         return torch.nn.functional.conv2d(x, weight, bias, stride, padding, dilation)
 
     @staticmethod
@@ -796,10 +805,8 @@ class _ConvBias(torch.autograd.Function):
         x, weight = ctx.saved_tensors
         stride, padding, dilation = ctx.conf
         gy = _f32c(gy)
-        ours = (_OFFSET_CONV_BWD and weight.shape[2] == 3 and weight.shape[3] == 3 and stride == [1, 1] and padding == [1, 1]
-                and dilation == [1, 1] and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[1] >= 64
-                and x.is_contiguous() and weight.is_contiguous())
-        ours_w = ours and _WRW_ENABLED and x.shape[2] * x.shape[3] >= 48 * 160
+        ours = ctx.ours
+        ours_w = ours and _WRW_ENABLED
         gx = gw = None
         if ours and ctx.needs_input_grad[0]:
             gx = _conv3x3_call(gy, weight, weight.shape[1], True)

@@ -274,20 +274,21 @@ int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const flo
                     size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
- * 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution without bias: forward and backward-data (Winograd
+ * 3x3 / stride 1 / pad 1 / dilation 1 / groups 1 convolution: forward and backward-data (Winograd
  * F(2x2,3x3) on the fp32 matrix pipe).  Replaces the stock `nn.Conv2d(.., 3, padding=1, bias=False)` calls of
  *   DGDE/model/backbone/dla_dcn.py:76-82 (BasicBlock.conv1/conv2 at stride 1) and
- *   DGDE/model/head/detector_predictor.py:52-58,112-118 (the 64->256 trunks of the class / regression heads),
+ *   DGDE/model/head/detector_predictor.py:52-58,112-118 (the 64->256 trunks of the class / regression heads) and
+ *   DGDE/model/backbone/DCNv2/dcn_v2.py:107-116 (DCN's `conv_offset_mask`, Cin -> 27 with a bias),
  * i.e. torch's cudnn/MIOpen convolution and its input gradient (weight gradient: dcd_conv3x3_wrw below).
- * weight (Cout,Cin,3,3).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
+ * weight (Cout,Cin,3,3), bias (Cout) or NULL (forward only).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
  *                         backward_data = 1: input = grad_output (B,Cout,H,W) -> output = grad_input (B,Cin,H,W).
  * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(B, Cin, H, W, Cout) bytes
  * (transformed weights; partial images when few regions make the call split its contraction), dead after the call's
  * kernels complete.
  * ---------------------------------------------------------------------------------------------- */
 size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout);
-int dcd_conv3x3(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W,
-                int Cout, int backward_data, void *workspace, size_t workspace_bytes);
+int dcd_conv3x3(void *stream, const float *input, const float *weight, const float *bias, float *output, int B, int Cin, int H,
+                int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes);
 
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
