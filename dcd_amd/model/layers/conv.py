@@ -1,5 +1,6 @@
-"""nn.Conv2d whose 3x3 / stride 1 / pad 1 / no-bias case runs on the Winograd MFMA kernel (csrc/conv.hip); with a bias
-(DCN's `conv_offset_mask`, DGDE/model/backbone/DCNv2/dcn_v2.py:107-116) the stock op keeps everything but the bias gradient.
+"""nn.Conv2d whose 3x3 / stride 1 / pad 1 case runs on the Winograd MFMA kernels (csrc/conv.hip), with or without a bias
+(with: DCN's `conv_offset_mask`, DGDE/model/backbone/DCNv2/dcn_v2.py:107-116; other biased layers keep the stock op for
+everything but the bias gradient).
 
 Same parameters and state-dict keys as `torch.nn.Conv2d`; every other configuration (and CPU tensors -- the CPU test
 suite) takes the stock op, which is what the reference uses everywhere (DGDE/model/backbone/dla_dcn.py:76-82,
@@ -31,7 +32,9 @@ class Conv2d(nn.Conv2d):
             return ops.conv_stem(x, self.weight)
         if (_ENABLED and self.bias is not None and x.is_cuda and x.dtype == torch.float32 and self.groups == 1
                 and self.padding_mode == "zeros" and not isinstance(self.padding, str) and torch.is_grad_enabled()
-                and self.bias.requires_grad and x.shape[0] * x.shape[2] * x.shape[3] >= 1 << 16):
+                and self.bias.requires_grad
+                and (x.shape[0] * x.shape[2] * x.shape[3] >= 1 << 16
+                     or ops.conv3x3_bias_supported(x, self.weight, self.stride, self.padding, self.dilation))):
             return ops.conv2d_bias(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
         return super().forward(x)
 

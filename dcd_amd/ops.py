@@ -778,6 +778,13 @@ _OFFSET_CONV_BWD = os.environ.get("DCD_OFFSET_CONV_BWD", "1") != "0"       # 0: 
 _OFFSET_CONV_FWD = os.environ.get("DCD_OFFSET_CONV_FWD", "1") != "0"       # 0: stock forward
 
 
+def conv3x3_bias_supported(x, weight, stride, padding, dilation):
+    """Biased 3x3 / stride 1 / pad 1 layers that run on csrc/conv.hip end to end (see _ConvBias)."""
+    return (_OFFSET_CONV_BWD and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3
+            and weight.shape[3] == 3 and (list(stride), list(padding), list(dilation)) == ([1, 1], [1, 1], [1, 1])
+            and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[1] >= 64 and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
+
+
 class _ConvBias(torch.autograd.Function):
     """conv2d with a bias (DCN's `conv_offset_mask`, Cin -> 27).  The 3x3 / stride 1 / pad 1 layers with at least 64 inputs run
     on csrc/conv.hip: forward with the bias added in the output transform, input gradient and weight gradient, all on the
@@ -790,8 +797,7 @@ class _ConvBias(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight, bias, stride, padding, dilation):
         ctx.conf = (list(stride), list(padding), list(dilation))
-        ctx.ours = (_OFFSET_CONV_BWD and x.is_cuda and x.dtype == torch.float32 and weight.shape[2] == 3 and weight.shape[3] == 3
-                    and ctx.conf == ([1, 1], [1, 1], [1, 1]) and x.shape[3] % 4 == 0 and x.shape[2] % 2 == 0 and weight.shape[1] >= 64)
+        ctx.ours = conv3x3_bias_supported(x, weight, stride, padding, dilation)
         if ctx.ours:
             x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
