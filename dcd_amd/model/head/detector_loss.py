@@ -37,6 +37,24 @@ def _total(x):
     return x.reshape(x.shape[0], -1).sum(dim=1).sum() if x.dim() > 1 else x.sum()
 
 
+class _MaskedSums:
+    """Collects per-object columns and reduces them together: one stack, one product with the stacked masks, one column sum
+    instead of (mask product, sum, weight, division) per loss term -- the terms are ~4 tiny launches each in the forward and
+    as many in the backward, and a dependent launch costs ~2 us however small it is.  2-D terms enter as their
+    row sums (the first stage of `_total`); the column sum over the B*M slots is its second stage."""
+
+    def __init__(self):
+        self.cols, self.masks = [], []
+
+    def add(self, vec, mask):
+        self.cols.append(vec.reshape(-1))
+        self.masks.append(mask.reshape(-1))
+        return len(self.cols) - 1
+
+    def reduce(self):
+        return (torch.stack(self.cols, dim=1) * torch.stack(self.masks, dim=1)).sum(dim=0)
+
+
 def make_loss_evaluator(cfg):
     return Loss_Computation(cfg=cfg)
 
@@ -97,6 +115,7 @@ class Loss_Computation():
 
         self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
         self._graphs = {}                      # input-shape key -> (graphed callable, {'loss_keys', 'log_names'})
+        self._wcache = (None, None)
         self.gen_data = {k: [] for k in ('kpts_2d', 'kpts_3d', 'pred_rot', 'gt_location', 'pred_location', 'weight_img', 'img_idx')}
 
     # ------------------------------------------------------------------------------------------
@@ -148,37 +167,38 @@ class Loss_Computation():
         self.gen_data['pred_location'].append(body[:, nk * 5 + 4:nk * 5 + 7].tolist())
 
     # ------------------------------------------------------------------------------------------
-    def compute_pairs_kpts_loss(self, preds, pred_targets, batch_weight):
-        """Dense-keypoint L1 terms and the pair-depth term (detector_loss.py:176-215), with masked sums."""
+    def compute_pairs_kpts_loss(self, preds, pred_targets, acc, one):
+        """Dense-keypoint L1 terms and the pair-depth term (detector_loss.py:176-215) as row sums in `acc` (all masks are
+        already inside the rows, so their column mask is `one`); `finish_pairs_kpts_loss` forms the reference's ratios."""
         m2d = pred_targets['extra_kpts_2d_mask'].float()
         m3d = pred_targets['extra_kpts_3d_mask'].float()
-        instance_num = pred_targets['obj_valid'].sum()          # number of annotated objects (device scalar)
-        scale = instance_num / batch_weight
-        l2d = self.loss_weights['extra_kpts_2d_loss'] * self.extra_kpts_2d_loss_fnc(
-            preds['extra_kpts_2d'], pred_targets['extra_kpts_2d'], pred_targets['depth_3D']) * m2d
-        l3d = self.loss_weights['extra_kpts_3d_loss'] * self.extra_kpts_3d_loss_fnc(
-            preds['extra_kpts_3d'], pred_targets['extra_kpts_3d'], reduction='none').sum(dim=2) * m3d
-        extra_kpts_2d_loss = _total(l2d) / torch.clamp(_total(m2d), min=1) * scale
-        extra_kpts_3d_loss = _total(l3d) / torch.clamp(_total(m3d), min=1) * scale
-
+        l2d = self.extra_kpts_2d_loss_fnc(preds['extra_kpts_2d'], pred_targets['extra_kpts_2d'], pred_targets['depth_3D']) * m2d
+        l3d = self.extra_kpts_3d_loss_fnc(preds['extra_kpts_3d'], pred_targets['extra_kpts_3d'], reduction='none').sum(dim=2) * m3d
         pred = preds['pairs_kpt_depths_all']
         pmask = preds['pairs_kpt_depths_mask'] > 0
         found = pred_targets['find_pcl'].bool().unsqueeze(-1)
         valid = (pmask & found).float()
         invalid = ((~pmask) & found).float()
         target = pred_targets['depth_3D'].unsqueeze(-1).expand_as(pred)
-        w = self.loss_weights['pairs_kpts_depth_loss']
-        valid_l = w * self.reg_loss_fnc(pred, target, reduction='none') * valid
-        invalid_l = w * self.reg_loss_fnc(pred.detach(), target, reduction='none') * invalid
-        n_valid, n_invalid = _total(valid), _total(invalid)
-        log_valid = _total(valid_l.detach()) / n_valid          # mean over the valid set (nan if empty, as the reference)
-        valid_total = _total(valid_l) / torch.clamp(n_valid, min=1) * scale
-        invalid_total = _total(invalid_l) / torch.clamp(n_invalid, min=1) * scale
-        pairs_loss = valid_total + invalid_total if self.modify_invalid_keypoint_depths else valid_total
+        reg = self.reg_loss_fnc(pred, target, reduction='none')
+        mae = ((pred.detach() - target).abs() / target) * valid
+        cols = {'l2d': l2d, 'm2d': m2d, 'l3d': l3d, 'm3d': m3d, 'valid_l': reg * valid, 'invalid_l': reg.detach() * invalid,
+                'n_valid': valid, 'n_invalid': invalid, 'mae': mae}
+        return {k: acc.add(v.sum(dim=1), one) for k, v in cols.items()}, mae
 
-        pairs_mae = ((pred.detach() - target).abs() / target) * valid
-        pairs_all_mae = _total(pairs_mae) / torch.clamp(n_valid, min=1)
-        return extra_kpts_2d_loss, extra_kpts_3d_loss, pairs_loss, pairs_mae, pairs_all_mae, log_valid
+    def finish_pairs_kpts_loss(self, S, ix, instance_num, batch_weight):
+        lw = self.loss_weights
+        scale = instance_num / batch_weight
+        extra_kpts_2d_loss = lw['extra_kpts_2d_loss'] * S[ix['l2d']] / torch.clamp(S[ix['m2d']], min=1) * scale
+        extra_kpts_3d_loss = lw['extra_kpts_3d_loss'] * S[ix['l3d']] / torch.clamp(S[ix['m3d']], min=1) * scale
+        w = lw['pairs_kpts_depth_loss']
+        n_valid, n_invalid = S[ix['n_valid']], S[ix['n_invalid']]
+        log_valid = w * S[ix['valid_l']].detach() / n_valid      # mean over the valid set (nan if empty, as the reference)
+        valid_total = w * S[ix['valid_l']] / torch.clamp(n_valid, min=1) * scale
+        invalid_total = w * S[ix['invalid_l']] / torch.clamp(n_invalid, min=1) * scale
+        pairs_loss = valid_total + invalid_total if self.modify_invalid_keypoint_depths else valid_total
+        pairs_all_mae = S[ix['mae']] / torch.clamp(n_valid, min=1)
+        return extra_kpts_2d_loss, extra_kpts_3d_loss, pairs_loss, pairs_all_mae, log_valid
 
     # ------------------------------------------------------------------------------------------
     def prepare_predictions(self, targets_variables, predictions):
@@ -372,6 +392,14 @@ class Loss_Computation():
         loss_dict.total = total                  # the sum, formed inside the graph: `total.backward()` needs no eager adds
         return loss_dict, LazyLogDict(meta['log_names'], packed.clone(), list(loss_dict))
 
+    def _column_weights(self, W, n, device):
+        """(n,) constants `weight / batch_weight` of the columns; built on the host once per (values, device) -- inside a
+        graph capture a host->device copy is not allowed, and the eager warm-up calls have filled the cache by then."""
+        key = (tuple(float(W.get(i, 1.0)) for i in range(n)), str(device))
+        if self._wcache[0] != key:
+            self._wcache = (key, torch.tensor(key[0], dtype=torch.float32, device=device))
+        return self._wcache[1]
+
     def _core(self, predictions, targets_heatmap, targets_variables):
         pred_heatmap = predictions['cls']
         pt, preds, reg_nums, weights = self.prepare_predictions(targets_variables, predictions)
@@ -383,88 +411,109 @@ class Loss_Computation():
         hm_loss, num_hm_pos = self.cls_loss_fnc(pred_heatmap, targets_heatmap)
         hm_loss = lw['hm_loss'] * hm_loss / batch_weight
 
+        # Every other term is a masked sum over the B*M object slots: the per-object columns are collected in `acc` and
+        # reduced together (see _MaskedSums); `W` holds weight / batch_weight per column.
+        acc = _MaskedSums()
+        W = {}
+
+        def term(vec, mask, weight=1.0):
+            i = acc.add(vec, mask)
+            W[i] = weight
+            return i
+
+        ov = pt['obj_valid'].float()                             # 1 for annotated objects, 0 for the padded slots
+        one = torch.ones_like(ov)
+        trunc = pt['trunc_mask_3D'].bool().float()
+        i_ov = term(one, ov)
+
         # 2-D box: GIoU on the objects with a non-degenerate box
         m2 = pt['reg_2D_mask']
         safe_target = torch.where(m2.unsqueeze(1), pt['reg_2D'], torch.ones_like(pt['reg_2D']))
         giou_l, iou = self.iou_loss(preds['reg_2D'], safe_target)
         m2f = m2.float()
-        reg_2D_loss = lw['bbox_loss'] * (giou_l * m2f).sum() / batch_weight
-        iou_2D = (iou * m2f).sum() / torch.clamp(m2f.sum(), min=1)
-
-        ov = pt['obj_valid'].float()                             # 1 for annotated objects, 0 for the padded slots
-        trunc = pt['trunc_mask_3D'].bool().float()
+        i_giou = term(giou_l, m2f, lw['bbox_loss'] / batch_weight)
+        i_iou, i_m2 = term(iou.detach(), m2f), term(one, m2f)
 
         # direct depth (+ aleatoric uncertainty)
         depth_3D_loss = lw['depth_loss'] * self.depth_loss(preds['depth_3D'], pt['depth_3D'], reduction='none')
-        real_depth_3D_loss = (depth_3D_loss.detach() * ov).sum() / batch_weight
+        i_depth_real = term(depth_3D_loss.detach(), ov, 1.0 / batch_weight)
         if self.depth_with_uncertainty:
             depth_3D_loss = depth_3D_loss * torch.exp(-preds['depth_uncertainty']) + preds['depth_uncertainty'] * lw['depth_loss']
-        depth_3D_loss = (depth_3D_loss * ov).sum() / batch_weight
+        i_depth = term(depth_3D_loss, ov, 1.0 / batch_weight)
 
         # projected-centre offset; truncated objects use the log form
         off_l = self.reg_loss_fnc(preds['offset_3D'], pt['offset_3D'], reduction='none').sum(dim=1)
         if self.separate_trunc_offset:
             t_l = off_l if self.trunc_offset_loss_type == 'L1' else torch.log(1 + off_l)
-            trunc_offset_loss = lw['trunc_offset_loss'] * (t_l * trunc * ov).sum() / batch_weight
-            offset_3D_loss = lw['offset_loss'] * (off_l * (1 - trunc) * ov).sum() / batch_weight
+            tv = trunc * ov
+            i_trunc = term(t_l, tv, lw['trunc_offset_loss'] / batch_weight)
+            i_off = term(off_l, ov - tv, lw['offset_loss'] / batch_weight)
         else:
-            offset_3D_loss = lw['offset_loss'] * (off_l * ov).sum() / batch_weight
+            i_off = term(off_l, ov, lw['offset_loss'] / batch_weight)
 
         if self.multibin:
-            orien_3D_loss = lw['orien_loss'] * Real_MultiBin_loss(preds['orien_3D'], pt['orien_3D'],
-                                                                  num_bin=self.orien_bin_size,
-                                                                  row_mask=pt['ori_mask'].bool() & pt['obj_valid']) / batch_weight
+            ori_rows = Real_MultiBin_loss(preds['orien_3D'], pt['orien_3D'], num_bin=self.orien_bin_size, per_row_only=True)
+            i_ori = term(ori_rows, (pt['ori_mask'].bool() & pt['obj_valid']).float(), lw['orien_loss'] / batch_weight)
         else:
             raise NotImplementedError("only INPUT.ORIENTATION == 'multi-bin' is on the DGDE path")
 
         if self.dim_weight.device != preds['dims_3D'].device:      # one host->device copy, ever (a per-step copy from
             self.dim_weight = self.dim_weight.to(preds['dims_3D'])  # pageable memory synchronises the stream)
-        dims_3D_loss = self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * self.dim_weight
-        dims_3D_loss = lw['dims_loss'] * (dims_3D_loss.sum(dim=1) * ov).sum() / batch_weight
+        dims_rows = (self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * self.dim_weight).sum(dim=1)
+        i_dims = term(dims_rows, ov, lw['dims_loss'] / batch_weight)
 
         with torch.no_grad():
-            pred_IoU_3D = (get_iou_3d(preds['corners_3D'], pt['corners_3D']) * ov).sum() / ov.sum()   # mean over the objects
+            i_iou3d = term(get_iou_3d(preds['corners_3D'], pt['corners_3D']), ov)
 
-        loss_dict = {'hm_loss': hm_loss, 'bbox_loss': reg_2D_loss, 'dims_loss': dims_3D_loss, 'orien_loss': orien_3D_loss,
-                     'offset_loss': offset_3D_loss}
-        log_tensors = {'2D_IoU': iou_2D.detach(), '3D_IoU': pred_IoU_3D}
-        if self.separate_trunc_offset:
-            loss_dict['trunc_offset_loss'] = trunc_offset_loss
         if self.compute_corner_loss:
-            loss_dict['corner_loss'] = lw['corner_loss'] * (self.reg_loss_fnc(
-                preds['corners_3D'], pt['corners_3D'], reduction='none').sum(dim=(1, 2)) * ov).sum() / batch_weight
-        if self.pred_direct_depth:
-            loss_dict['depth_loss'] = depth_3D_loss
-            log_tensors['depth_loss'] = real_depth_3D_loss
-
+            i_corner = term(self.reg_loss_fnc(preds['corners_3D'], pt['corners_3D'], reduction='none').sum(dim=(1, 2)), ov,
+                            lw['corner_loss'] / batch_weight)
         if self.compute_keypoint_corner:
-            kl = lw['keypoint_loss'] * self.keypoint_loss_fnc(preds['keypoints'], pt['keypoints'],
-                                                              reduction='none').sum(dim=2) * pt['keypoints_mask'] * ov[:, None]
-            loss_dict['keypoint_loss'] = _total(kl) / batch_weight
-
+            kl = self.keypoint_loss_fnc(preds['keypoints'], pt['keypoints'], reduction='none').sum(dim=2) * pt['keypoints_mask']
+            i_kp = term(kl.sum(dim=1), ov, lw['keypoint_loss'] / batch_weight)
         if self.compute_extra_kpts_corner:
-            e2d, e3d, edepth, _mae, all_mae, log_edepth = self.compute_pairs_kpts_loss(preds, pt, batch_weight)
+            ix_pairs, _mae = self.compute_pairs_kpts_loss(preds, pt, acc, one)
+        if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
+            kd = preds['keypoints_depths']
+            km = pt['keypoints_depth_mask'].bool().float()
+            tgt = pt['depth_3D'].unsqueeze(-1).expand_as(kd)
+            w = lw['keypoint_depth_loss']
+            v_l = self.reg_loss_fnc(kd, tgt, reduction='none')
+            i_kd_log = term((v_l.detach() * km).sum(dim=1), ov, w / batch_weight)
+            i_l = v_l.detach()
+            if self.corner_with_uncertainty:
+                cu = preds['corner_offset_uncertainty']
+                ecu = torch.exp(-cu)
+                v_l = v_l * ecu + cu
+                i_l = i_l * ecu
+            i_kd_v = term((v_l * km).sum(dim=1), ov, w / batch_weight)
+            i_kd_i = term((i_l * (1 - km)).sum(dim=1), ov, w / batch_weight)
+
+        S = acc.reduce() * self._column_weights(W, len(acc.cols), pred_heatmap.device)
+
+        iou_2D = S[i_iou] / torch.clamp(S[i_m2], min=1)
+        pred_IoU_3D = S[i_iou3d] / S[i_ov]                        # mean over the objects
+        loss_dict = {'hm_loss': hm_loss, 'bbox_loss': S[i_giou], 'dims_loss': S[i_dims], 'orien_loss': S[i_ori],
+                     'offset_loss': S[i_off]}
+        log_tensors = {'2D_IoU': iou_2D.detach(), '3D_IoU': pred_IoU_3D.detach()}
+        if self.separate_trunc_offset:
+            loss_dict['trunc_offset_loss'] = S[i_trunc]
+        if self.compute_corner_loss:
+            loss_dict['corner_loss'] = S[i_corner]
+        if self.pred_direct_depth:
+            loss_dict['depth_loss'] = S[i_depth]
+            log_tensors['depth_loss'] = S[i_depth_real].detach()
+        if self.compute_keypoint_corner:
+            loss_dict['keypoint_loss'] = S[i_kp]
+        if self.compute_extra_kpts_corner:
+            e2d, e3d, edepth, all_mae, log_edepth = self.finish_pairs_kpts_loss(S, ix_pairs, S[i_ov].detach(), batch_weight)
             loss_dict['extra_kpts_2d_loss'] = e2d
             loss_dict['extra_kpts_3d_loss'] = e3d
             loss_dict['extra_kpts_depth_loss'] = edepth
             log_tensors['extra_kpts_depth_loss'] = log_edepth
-
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
-            kd = preds['keypoints_depths']
-            km = pt['keypoints_depth_mask'].bool().float()
-            ovk = ov[:, None]
-            tgt = pt['depth_3D'].unsqueeze(-1).expand_as(kd)
-            w = lw['keypoint_depth_loss']
-            v_l = w * self.reg_loss_fnc(kd, tgt, reduction='none')
-            i_l = w * self.reg_loss_fnc(kd.detach(), tgt, reduction='none')
-            log_tensors['keypoint_depth_loss'] = _total(v_l.detach() * km * ovk) / batch_weight
-            if self.corner_with_uncertainty:
-                cu = preds['corner_offset_uncertainty']
-                v_l = v_l * torch.exp(-cu) + w * cu
-                i_l = i_l * torch.exp(-cu)
-            v_sum = _total(v_l * km * ovk) / batch_weight
-            i_sum = _total(i_l * (1 - km) * ovk) / batch_weight
-            loss_dict['keypoint_depth_loss'] = v_sum + i_sum if self.modify_invalid_keypoint_depths else v_sum
+            log_tensors['keypoint_depth_loss'] = S[i_kd_log].detach()
+            loss_dict['keypoint_depth_loss'] = S[i_kd_v] + S[i_kd_i] if self.modify_invalid_keypoint_depths else S[i_kd_v]
 
         # ---- logging: one device->host copy for every scalar, made only when somebody reads the log dict (the reference
         # calls .item() twenty times inside the forward, detector_loss.py:589-630).  Reading forces the sync and the
@@ -537,20 +586,22 @@ class LazyLogDict(dict):
         return super().__repr__()
 
 
-def Real_MultiBin_loss(vector_ori, gt_ori, num_bin=4, row_mask=None):
+def Real_MultiBin_loss(vector_ori, gt_ori, num_bin=4, row_mask=None, per_row_only=False):
     """Multi-bin orientation loss (detector_loss.py:644-666): per-bin 2-way cross entropy + L1 on the
     normalised (sin, cos) offsets of the bins that contain the angle.  `row_mask` replaces the
-    boolean row selection of the caller (:473-477) with a masked sum."""
+    boolean row selection of the caller (:473-477) with a masked sum.
+    All bins at once on (N, num_bin, 2) views -- the reference's loop over the bins is ~22 launches per bin and as many in
+    the backward; the sums are the same sums in a different order."""
     gt_ori = gt_ori.view(-1, gt_ori.shape[-1])
-    rows = torch.ones_like(gt_ori[:, 0]) if row_mask is None else row_mask.to(gt_ori.dtype)
-    cls_losses = 0
-    reg_losses = 0
-    for i in range(num_bin):
-        ce = F.cross_entropy(vector_ori[:, 2 * i: 2 * i + 2], gt_ori[:, i].long(), reduction='none')
-        cls_losses = cls_losses + (ce * rows).sum()
-        in_bin = (gt_ori[:, i] == 1).to(gt_ori.dtype) * rows
-        s = num_bin * 2 + 2 * i
-        off = F.normalize(vector_ori[:, s: s + 2])
-        reg = (off[:, 0] - torch.sin(gt_ori[:, num_bin + i])).abs() + (off[:, 1] - torch.cos(gt_ori[:, num_bin + i])).abs()
-        reg_losses = reg_losses + (reg * in_bin).sum()
-    return cls_losses / num_bin + reg_losses
+    n = gt_ori.shape[0]
+    bins = gt_ori[:, :num_bin]
+    logp = F.log_softmax(vector_ori[:, :2 * num_bin].reshape(n, num_bin, 2), dim=2)
+    ce = -logp.gather(2, bins.long().unsqueeze(-1)).squeeze(-1)                       # (N, num_bin)
+    off = F.normalize(vector_ori[:, 2 * num_bin:4 * num_bin].reshape(n, num_bin, 2), dim=2)
+    ang = gt_ori[:, num_bin:2 * num_bin]
+    target = torch.stack((torch.sin(ang), torch.cos(ang)), dim=2)
+    reg = (off - target).abs().sum(dim=2)
+    per_row = (ce * (1.0 / num_bin) + reg * (bins == 1).to(gt_ori.dtype)).sum(dim=1)
+    if per_row_only:
+        return per_row
+    return per_row.sum() if row_mask is None else (per_row * row_mask.to(gt_ori.dtype)).sum()

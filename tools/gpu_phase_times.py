@@ -13,6 +13,8 @@ def main():
     ap.add_argument("--precision", default="f32")
     ap.add_argument("--scaling", default="weak")
     ap.add_argument("--amp", action="store_true")
+    ap.add_argument("--presleep-ms", type=float, default=0.0,
+                    help="spin the GPU this long before every step, so the host runs ahead: phases become pure GPU time")
     args = ap.parse_args()
     import torch
     import bench
@@ -27,6 +29,8 @@ def main():
     marks = []
     for _ in range(args.steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
+        if args.presleep_ms > 0:
+            torch.cuda._sleep(int(args.presleep_ms * 2.4e6))
         ev[0].record()
         features = model.backbone(to_image_list(images).tensors)
         ev[1].record()
