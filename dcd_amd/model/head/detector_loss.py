@@ -116,6 +116,7 @@ class Loss_Computation():
         self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
         self._graphs = {}                      # input-shape key -> (graphed callable, {'loss_keys', 'log_names'})
         self._wcache = (None, None)
+        self._mcache = (None, None)
         self.gen_data = {k: [] for k in ('kpts_2d', 'kpts_3d', 'pred_rot', 'gt_location', 'pred_location', 'weight_img', 'img_idx')}
 
     # ------------------------------------------------------------------------------------------
@@ -169,7 +170,7 @@ class Loss_Computation():
     # ------------------------------------------------------------------------------------------
     def compute_pairs_kpts_loss(self, preds, pred_targets, acc, one):
         """Dense-keypoint L1 terms and the pair-depth term (detector_loss.py:176-215) as row sums in `acc` (all masks are
-        already inside the rows, so their column mask is `one`); `finish_pairs_kpts_loss` forms the reference's ratios."""
+        already inside the rows, so their column mask is `one`); `_core` forms the reference's ratios from the column sums."""
         m2d = pred_targets['extra_kpts_2d_mask'].float()
         m3d = pred_targets['extra_kpts_3d_mask'].float()
         l2d = self.extra_kpts_2d_loss_fnc(preds['extra_kpts_2d'], pred_targets['extra_kpts_2d'], pred_targets['depth_3D']) * m2d
@@ -185,20 +186,6 @@ class Loss_Computation():
         cols = {'l2d': l2d, 'm2d': m2d, 'l3d': l3d, 'm3d': m3d, 'valid_l': reg * valid, 'invalid_l': reg.detach() * invalid,
                 'n_valid': valid, 'n_invalid': invalid, 'mae': mae}
         return {k: acc.add(v.sum(dim=1), one) for k, v in cols.items()}, mae
-
-    def finish_pairs_kpts_loss(self, S, ix, instance_num, batch_weight):
-        lw = self.loss_weights
-        scale = instance_num / batch_weight
-        extra_kpts_2d_loss = lw['extra_kpts_2d_loss'] * S[ix['l2d']] / torch.clamp(S[ix['m2d']], min=1) * scale
-        extra_kpts_3d_loss = lw['extra_kpts_3d_loss'] * S[ix['l3d']] / torch.clamp(S[ix['m3d']], min=1) * scale
-        w = lw['pairs_kpts_depth_loss']
-        n_valid, n_invalid = S[ix['n_valid']], S[ix['n_invalid']]
-        log_valid = w * S[ix['valid_l']].detach() / n_valid      # mean over the valid set (nan if empty, as the reference)
-        valid_total = w * S[ix['valid_l']] / torch.clamp(n_valid, min=1) * scale
-        invalid_total = w * S[ix['invalid_l']] / torch.clamp(n_invalid, min=1) * scale
-        pairs_loss = valid_total + invalid_total if self.modify_invalid_keypoint_depths else valid_total
-        pairs_all_mae = S[ix['mae']] / torch.clamp(n_valid, min=1)
-        return extra_kpts_2d_loss, extra_kpts_3d_loss, pairs_loss, pairs_all_mae, log_valid
 
     # ------------------------------------------------------------------------------------------
     def prepare_predictions(self, targets_variables, predictions):
@@ -376,10 +363,9 @@ class Loss_Computation():
             def core_flat(cls, pois, hm, *fl):
                 loss_dict, log_names, packed = self._core({'cls': cls, 'reg': None, 'reg_pois': pois}, hm, dict(zip(names, fl)))
                 meta['loss_keys'], meta['log_names'] = list(loss_dict), log_names
-                stacked = torch.stack([v.reshape(()) for v in loss_dict.values()])
                 # three outputs instead of fifteen: the graphed backward copies one gradient per output into its static
                 # buffers before it replays, and those launches sit in the one gap where the GPU waits for the host
-                return stacked, stacked.sum(), packed
+                return loss_dict.stacked, loss_dict.total, packed
             sample = (pred_heatmap.detach().clone().requires_grad_(True), reg_pois.detach().clone().requires_grad_(True),
                       targets_heatmap.detach().clone()) + tuple(t.detach().clone() for t in flat)
             if len(self._graphs) >= 4:                       # a few input shapes at most (e.g. the last, smaller batch)
@@ -399,6 +385,19 @@ class Loss_Computation():
         if self._wcache[0] != key:
             self._wcache = (key, torch.tensor(key[0], dtype=torch.float32, device=device))
         return self._wcache[1]
+
+    def _loss_matrix(self, spec, n, ratio_cols, device):
+        """(M (len(spec), n) with M[l, c] = 1 for the columns c of loss l; ones (n,); ratio column indices) -- constants,
+        built once per structure (see _column_weights for why not per call)."""
+        key = (tuple((k, tuple(c)) for k, c in spec), n, tuple(ratio_cols), str(device))
+        if self._mcache[0] != key:
+            M = torch.zeros((len(spec), n), dtype=torch.float32)
+            for r, (_, cols) in enumerate(spec):
+                for c in cols:
+                    M[r, c] = 1.0
+            self._mcache = (key, (M.to(device), torch.ones(n, dtype=torch.float32, device=device),
+                                  torch.tensor(list(ratio_cols), dtype=torch.long, device=device)))
+        return self._mcache[1]
 
     def _core(self, predictions, targets_heatmap, targets_variables):
         pred_heatmap = predictions['cls']
@@ -473,6 +472,8 @@ class Loss_Computation():
             i_kp = term(kl.sum(dim=1), ov, lw['keypoint_loss'] / batch_weight)
         if self.compute_extra_kpts_corner:
             ix_pairs, _mae = self.compute_pairs_kpts_loss(preds, pt, acc, one)
+            W[ix_pairs['l2d']], W[ix_pairs['l3d']] = lw['extra_kpts_2d_loss'], lw['extra_kpts_3d_loss']
+            W[ix_pairs['valid_l']] = W[ix_pairs['invalid_l']] = lw['pairs_kpts_depth_loss']
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
             kd = preds['keypoints_depths']
             km = pt['keypoints_depth_mask'].bool().float()
@@ -489,31 +490,47 @@ class Loss_Computation():
             i_kd_v = term((v_l * km).sum(dim=1), ov, w / batch_weight)
             i_kd_i = term((i_l * (1 - km)).sum(dim=1), ov, w / batch_weight)
 
-        S = acc.reduce() * self._column_weights(W, len(acc.cols), pred_heatmap.device)
-
-        iou_2D = S[i_iou] / torch.clamp(S[i_m2], min=1)
-        pred_IoU_3D = S[i_iou3d] / S[i_ov]                        # mean over the objects
-        loss_dict = {'hm_loss': hm_loss, 'bbox_loss': S[i_giou], 'dims_loss': S[i_dims], 'orien_loss': S[i_ori],
-                     'offset_loss': S[i_off]}
-        log_tensors = {'2D_IoU': iou_2D.detach(), '3D_IoU': pred_IoU_3D.detach()}
+        # Column sums -> the 13 losses as ONE vector: `stacked = M (rc * [S, hm_loss])`, M a constant 0/1 matrix (which columns
+        # make up which loss), rc = 1 except for the four columns the reference divides by a mask count (no gradient through
+        # the counts).  Selecting the losses one by one out of S would cost a zero-filled vector + a copy + an accumulation per
+        # loss in the backward.
+        n_cols = len(acc.cols)
+        S = acc.reduce() * self._column_weights(W, n_cols, pred_heatmap.device)
+        Sd = S.detach()
+        spec = [('hm_loss', [n_cols]), ('bbox_loss', [i_giou]), ('dims_loss', [i_dims]), ('orien_loss', [i_ori]), ('offset_loss', [i_off])]
+        log_tensors = {'2D_IoU': Sd[i_iou] / torch.clamp(Sd[i_m2], min=1), '3D_IoU': Sd[i_iou3d] / Sd[i_ov]}   # means over the objects
         if self.separate_trunc_offset:
-            loss_dict['trunc_offset_loss'] = S[i_trunc]
+            spec.append(('trunc_offset_loss', [i_trunc]))
         if self.compute_corner_loss:
-            loss_dict['corner_loss'] = S[i_corner]
+            spec.append(('corner_loss', [i_corner]))
         if self.pred_direct_depth:
-            loss_dict['depth_loss'] = S[i_depth]
-            log_tensors['depth_loss'] = S[i_depth_real].detach()
+            spec.append(('depth_loss', [i_depth]))
+            log_tensors['depth_loss'] = Sd[i_depth_real]
         if self.compute_keypoint_corner:
-            loss_dict['keypoint_loss'] = S[i_kp]
+            spec.append(('keypoint_loss', [i_kp]))
+        ratio_cols, ratios = [], []
         if self.compute_extra_kpts_corner:
-            e2d, e3d, edepth, all_mae, log_edepth = self.finish_pairs_kpts_loss(S, ix_pairs, S[i_ov].detach(), batch_weight)
-            loss_dict['extra_kpts_2d_loss'] = e2d
-            loss_dict['extra_kpts_3d_loss'] = e3d
-            loss_dict['extra_kpts_depth_loss'] = edepth
-            log_tensors['extra_kpts_depth_loss'] = log_edepth
+            ix = ix_pairs
+            scale = Sd[i_ov] / batch_weight                       # number of annotated objects / batch weight
+            n_valid = Sd[ix['n_valid']]
+            den = torch.clamp(torch.stack((Sd[ix['m2d']], Sd[ix['m3d']], n_valid, Sd[ix['n_invalid']])), min=1)
+            ratio_cols, ratios = [ix['l2d'], ix['l3d'], ix['valid_l'], ix['invalid_l']], scale / den
+            spec.append(('extra_kpts_2d_loss', [ix['l2d']]))
+            spec.append(('extra_kpts_3d_loss', [ix['l3d']]))
+            spec.append(('extra_kpts_depth_loss', [ix['valid_l'], ix['invalid_l']] if self.modify_invalid_keypoint_depths
+                         else [ix['valid_l']]))
+            log_tensors['extra_kpts_depth_loss'] = Sd[ix['valid_l']] / n_valid   # mean over the valid set (nan if empty, as the reference)
+            all_mae = Sd[ix['mae']] / den[2]
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
-            log_tensors['keypoint_depth_loss'] = S[i_kd_log].detach()
-            loss_dict['keypoint_depth_loss'] = S[i_kd_v] + S[i_kd_i] if self.modify_invalid_keypoint_depths else S[i_kd_v]
+            log_tensors['keypoint_depth_loss'] = Sd[i_kd_log]
+            spec.append(('keypoint_depth_loss', [i_kd_v, i_kd_i] if self.modify_invalid_keypoint_depths else [i_kd_v]))
+        M, rc_one, rc_idx = self._loss_matrix(spec, n_cols + 1, ratio_cols, pred_heatmap.device)
+        cols = torch.cat((S, hm_loss.reshape(1).to(S.dtype)))
+        if ratio_cols:
+            cols = cols * rc_one.index_copy(0, rc_idx, ratios.to(S.dtype))
+        stacked = torch.mv(M, cols)
+        loss_dict = LossDict(zip([k for k, _ in spec], stacked.unbind(0)))
+        loss_dict.stacked, loss_dict.total = stacked, stacked.sum()
 
         # ---- logging: one device->host copy for every scalar, made only when somebody reads the log dict (the reference
         # calls .item() twenty times inside the forward, detector_loss.py:589-630).  Reading forces the sync and the
@@ -531,6 +548,7 @@ class LossDict(dict):
     """The 13-entry loss dict of the reference (detector_loss.py:582-623) plus `total`, the sum of its values when that sum
     was already formed on the device (graph path); `engine.trainer.train_step` back-propagates `total` when present."""
     total = None
+    stacked = None         # the values as one vector, in key order (what `total` sums)
 
 
 class LazyLogDict(dict):

@@ -164,8 +164,8 @@ def test_graphed_loss_equals_eager_loss_on_changing_targets(cuda):
                 total = loss_dict.total
                 assert abs(float(total) - sum(float(v) for v in loss_dict.values())) <= 1e-5 * abs(float(total))
                 total.backward()
-            else:
-                assert getattr(loss_dict, "total", None) is None
+            else:                              # eager: back-propagate the dict's values one by one (the other way in)
+                assert abs(float(loss_dict.total) - sum(float(v) for v in loss_dict.values())) <= 1e-5 * abs(float(loss_dict.total))
                 sum(loss_dict.values()).backward()
             res.append(({k: float(v) for k, v in loss_dict.items()}, c.grad.clone(), p.grad.clone(), dict(log)))
         (l0, gc0, gp0, log0), (l1, gc1, gp1, log1) = res
