@@ -53,6 +53,7 @@ class Anno_Encoder():
                                           [1, 1, 1, 1, -1, -1, -1, -1],
                                           [-1, 1, 1, -1, -1, 1, 1, -1]], dtype=torch.float32)
         self._calib_cache = (None, None)
+        self._kp_idx = (None, None, None)
 
     # ------------------------------------------------------------------------------------------
     def _calib_table(self, calibs, device):
@@ -118,12 +119,12 @@ class Anno_Encoder():
         """Back-project (centre + offset) at the given depth with each object's own image calibration
         (anno_encoder.py:147-161; project_image_to_rect, data/datasets/kitti_utils.py:399-418)."""
         batch_idxs = batch_idxs.long()
-        tab = self._calib_table(calibs, points.device)[batch_idxs]
+        tab = self._calib_table(calibs, points.device)[batch_idxs]          # (n, 6): c_u, c_v, f_u, f_v, b_x, b_y
         pts = (points + offsets) * self.down_ratio - pad_size[batch_idxs]
         depths = depths.float()
-        x = ((pts[:, 0] - tab[:, 0]) * depths) / tab[:, 2] + tab[:, 4]
-        y = ((pts[:, 1] - tab[:, 1]) * depths) / tab[:, 3] + tab[:, 5]
-        return torch.stack((x, y, depths), dim=1)
+        # x and y together: ((u - c) * z) / f + b
+        xy = ((pts - tab[:, 0:2]) * depths.unsqueeze(1)) / tab[:, 2:4] + tab[:, 4:6]
+        return torch.cat((xy, depths.unsqueeze(1)), dim=1)
 
     def decode_depth_from_keypoints_batch(self, pred_keypoints, pred_dimensions, calibs, batch_idxs=None):
         """Depth from the projected height of the centre line and the two corner groups (anno_encoder.py:193-224).
@@ -139,15 +140,18 @@ class Anno_Encoder():
             present = torch.zeros(n_img, dtype=torch.long, device=bi.device).index_fill_(0, bi, 1)
             rank = torch.cumsum(present, 0) - 1
             f_u = tab[rank[bi], 2]
-        center_height = pred_keypoints[:, -2, 1] - pred_keypoints[:, -1, 1]
-        # strided slices, not index lists: a Python list index becomes a host->device copy on every call
-        corner_02_height = pred_keypoints[:, 0:3:2, 1] - pred_keypoints[:, 4:7:2, 1]
-        corner_13_height = pred_keypoints[:, 1:4:2, 1] - pred_keypoints[:, 5:8:2, 1]
+        # heights of the centre line (keypoints 8-9) and of the corner pairs 0-4, 2-6 | 1-5, 3-7 in one (n, 5) tensor; the
+        # index tensors live on the device (a Python list index would be a host->device copy on every call)
+        nk = pred_keypoints.shape[1]
+        key = (nk, str(pred_keypoints.device))
+        if self._kp_idx[0] != key:
+            self._kp_idx = (key, torch.tensor([nk - 2, 0, 2, 1, 3], device=pred_keypoints.device),
+                            torch.tensor([nk - 1, 4, 6, 5, 7], device=pred_keypoints.device))
+        ky = pred_keypoints[:, :, 1]
+        heights = ky.index_select(1, self._kp_idx[1]) - ky.index_select(1, self._kp_idx[2])
         fh = f_u * pred_height_3D
-        center_depth = fh / (F.relu(center_height) * self.down_ratio + self.EPS)
-        corner_02_depth = (fh.unsqueeze(-1) / (F.relu(corner_02_height) * self.down_ratio + self.EPS)).mean(dim=1)
-        corner_13_depth = (fh.unsqueeze(-1) / (F.relu(corner_13_height) * self.down_ratio + self.EPS)).mean(dim=1)
-        depths = torch.stack((center_depth, corner_02_depth, corner_13_depth), dim=1)
+        d = fh.unsqueeze(-1) / (F.relu(heights) * self.down_ratio + self.EPS)
+        depths = torch.cat((d[:, :1], d[:, 1:].reshape(-1, 2, 2).mean(dim=2)), dim=1)      # centre, corners 0/2, corners 1/3
         return torch.clamp(depths, min=self.depth_range[0], max=self.depth_range[1])
 
     def decode_dimension(self, cls_id, dims_offset):
