@@ -116,12 +116,13 @@ __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict
 // grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
 // ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
 // partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
-// bias (may be null): added to the output channels by split 0.
+// bias (may be null): added to the output channels by split 0; residual (may be null, may be y itself): a (B, Kk, H, W) image
+// added to the result by split 0 (a gradient that is already there: the caller's accumulation without a separate pass).
 template <int TR, int TC, int NB>
-__global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restrict__ x, const float *__restrict__ ul,
-                                                          float *__restrict__ y, float *__restrict__ part,
-                                                          const float *__restrict__ bias, int Cc, int H, int W, int Kk,
-                                                          int tiles_x, int nchunk, int nz)
+__global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restrict__ x, const float *__restrict__ ul, float *y,
+                                                          float *__restrict__ part, const float *__restrict__ bias,
+                                                          const float *residual, int Cc, int H, int W, int Kk, int tiles_x,
+                                                          int nchunk, int nz)
 {
     using G = WinoGeom<TR, TC, NB>;
     constexpr int WN_ROWS = G::ROWS, WN_RS = G::RS, WN_PLANE = G::PLANE, WN_IN = G::IN, WN_BUF = G::BUF, WN_Q = G::Q;
@@ -261,6 +262,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     // accumulator rows (r = 4 xi .. 4 xi + 3) for both output rows, so the exchange reads and the stores are balanced.
     float *ex = lds;
     float *y_b = (ks == 0 ? y : part + (size_t)(ks - 1) * gridDim.y * Kk * HW) + (size_t)b * Kk * HW;
+    const float *r_b = (residual && ks == 0) ? residual + (size_t)b * Kk * HW : nullptr;
     const int orow0 = r0 + 2 * TR * tg + 2 * trow, ocol = c0 + 2 * tcol;
 #pragma unroll
     for (int mb = 0; mb < NB; ++mb) {
@@ -281,9 +283,15 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
                 const float b0 = t0[(16 + r) * 64], b1 = t1[(16 + r) * 64], b2 = t2[(16 + r) * 64], b3 = t3[(16 + r) * 64];
                 if (k < Kk) {
                     const float bk = (bias && ks == 0) ? bias[k] : 0.f;
-                    float *dst = y_b + (size_t)k * HW + (size_t)orow0 * W + ocol;
-                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2 + bk, b0 + b1 + b2 + bk};
-                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3 + bk, b1 - b2 - b3 + bk};
+                    const size_t o = (size_t)k * HW + (size_t)orow0 * W + ocol;
+                    float *dst = y_b + o;
+                    f32x2 r0 = {bk, bk}, r1 = {bk, bk};
+                    if (r_b) {                                       // same thread reads and writes the element: y may alias
+                        if (orow0 < H) r0 += *reinterpret_cast<const f32x2 *>(r_b + o);
+                        if (orow0 + 1 < H) r1 += *reinterpret_cast<const f32x2 *>(r_b + o + W);
+                    }
+                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2 + r0.x, b0 + b1 + b2 + r0.y};
+                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3 + r1.x, b1 - b2 - b3 + r1.y};
                 }
             }
         }
@@ -600,14 +608,14 @@ static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
 
 template <int TR, int TC, int NB>
 static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *input, const float *ul, float *output, float *part,
-                       const float *bias, int B, int Cc, int H, int W, int Kk)
+                       const float *bias, const float *residual, int B, int Cc, int H, int W, int Kk)
 {
     static LdsLimit lds_limit;
     size_t ldsb = (size_t)2 * WinoGeom<TR, TC, NB>::BUF * sizeof(float);
     if (ldsb < (size_t)8 * 32 * 64 * sizeof(float)) ldsb = (size_t)8 * 32 * 64 * sizeof(float);      // the epilogue's exchange
     if (!lds_limit.raise((int)ldsb, wino_conv3x3_f32<TR, TC, NB>)) return DCD_ERR_LAUNCH;
     hipLaunchKernelGGL((wino_conv3x3_f32<TR, TC, NB>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream,
-                       input, ul, output, part, bias, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+                       input, ul, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
     return DCD_OK;
 }
 
@@ -624,8 +632,8 @@ size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout)
     return (nchunk * nz * 16 * 64 * WN_CH + (pf > pd ? pf : pd)) * sizeof(float);
 }
 
-int dcd_conv3x3(void *stream_, const float *input, const float *weight, const float *bias, float *output, int B, int Cin, int H,
-                int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes)
+int dcd_conv3x3(void *stream_, const float *input, const float *weight, const float *bias, const float *residual, float *output,
+                int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
@@ -654,10 +662,10 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, const fl
     // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
     hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
                        ul, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz, ksz);
-    const int st = pl.geom == 0 ? (pl.nb == 2 ? conv_launch<2, 16, 2>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk)
-                                              : conv_launch<2, 16, 1>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk))
-                                : (pl.nb == 2 ? conv_launch<3, 10, 2>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk)
-                                              : conv_launch<3, 10, 1>(stream, pl, input, ul, output, part, bias, B, Cc, H, W, Kk));
+    const int st = pl.geom == 0 ? (pl.nb == 2 ? conv_launch<2, 16, 2>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk)
+                                              : conv_launch<2, 16, 1>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk))
+                                : (pl.nb == 2 ? conv_launch<3, 10, 2>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk)
+                                              : conv_launch<3, 10, 1>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk));
     if (st != DCD_OK) return st;
     if (pl.ksplit > 1) {
         const size_t n4 = img / 4;                                      // W % 4 == 0

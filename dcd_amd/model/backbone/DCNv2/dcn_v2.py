@@ -42,34 +42,78 @@ class _DCNv2(Function):
 _FUSED_GLUE = os.environ.get("DCD_OFFSET_MASK_FUSED", "1") != "0"      # 0: slice + sigmoid through stock ops (A/B timing)
 
 
+def _offset_mask_split(out):
+    from dcd_amd import _lib
+    B, C3, H, W = out.shape
+    T = C3 // 3
+    offset = torch.empty((B, 2 * T, H, W), dtype=out.dtype, device=out.device)
+    mask = torch.empty((B, T, H, W), dtype=out.dtype, device=out.device)
+    st = _lib.lib().dcd_dcn_offset_mask_split(_lib.stream_of(out), out.data_ptr(), offset.data_ptr(), mask.data_ptr(), B, T, H * W)
+    _lib.check(st, "dcd_dcn_offset_mask_split")
+    return offset, mask
+
+
+def _offset_mask_merge(goff, gmask, mask):
+    from dcd_amd import _lib
+    B, T, H, W = mask.shape
+    goff, gmask = goff.contiguous(), gmask.contiguous()
+    gout = torch.empty((B, 3 * T, H, W), dtype=mask.dtype, device=mask.device)
+    st = _lib.lib().dcd_dcn_offset_mask_merge(_lib.stream_of(mask), goff.data_ptr(), gmask.data_ptr(), mask.data_ptr(),
+                                              gout.data_ptr(), B, T, H * W)
+    _lib.check(st, "dcd_dcn_offset_mask_merge")
+    return gout
+
+
 class _OffsetMask(torch.autograd.Function):
     """out (B, 3T, H, W) of `conv_offset_mask` -> (offset (B, 2T, H, W) contiguous, mask = sigmoid(last T channels)); the backward
     assembles grad_out in one pass (csrc/dcn_v2.hip: dcn_offset_mask_split / _merge)."""
 
     @staticmethod
     def forward(ctx, out):
-        from dcd_amd import _lib
-        B, C3, H, W = out.shape
-        T = C3 // 3
-        offset = torch.empty((B, 2 * T, H, W), dtype=out.dtype, device=out.device)
-        mask = torch.empty((B, T, H, W), dtype=out.dtype, device=out.device)
-        st = _lib.lib().dcd_dcn_offset_mask_split(_lib.stream_of(out), out.data_ptr(), offset.data_ptr(), mask.data_ptr(), B, T, H * W)
-        _lib.check(st, "dcd_dcn_offset_mask_split")
+        offset, mask = _offset_mask_split(out)
         ctx.save_for_backward(mask)
         return offset, mask
 
     @staticmethod
     @torch.autograd.function.once_differentiable
     def backward(ctx, goff, gmask):
-        from dcd_amd import _lib
         (mask,) = ctx.saved_tensors
-        B, T, H, W = mask.shape
-        goff, gmask = goff.contiguous(), gmask.contiguous()
-        gout = torch.empty((B, 3 * T, H, W), dtype=mask.dtype, device=mask.device)
-        st = _lib.lib().dcd_dcn_offset_mask_merge(_lib.stream_of(mask), goff.data_ptr(), gmask.data_ptr(), mask.data_ptr(),
-                                                  gout.data_ptr(), B, T, H * W)
-        _lib.check(st, "dcd_dcn_offset_mask_merge")
-        return gout
+        return _offset_mask_merge(goff, gmask, mask)
+
+
+_ONE_NODE = os.environ.get("DCD_DCN_NODE", "1") != "0"                 # 0: offset conv, split and DCN as three nodes (A/B timing)
+
+
+class _DCNWithOffsets(Function):
+    """`DCN.forward` (dcn_v2.py:117-128) as ONE autograd node: offset conv -> split / sigmoid -> deformable conv.  The input feeds
+    both the offset conv and the deformable conv, so as separate nodes autograd adds two full-size input gradients per layer
+    (16 additions per step, 30 us each on the 64-channel 96x320 maps); here the offset conv's input gradient is accumulated into
+    the deformable conv's by the Winograd kernel's output transform (`dcd_conv3x3(..., residual = output)`).  Same kernels, same
+    arithmetic otherwise (the one addition happens in the other order)."""
+
+    @staticmethod
+    def forward(ctx, input, w_off, b_off, weight, bias, geometry):
+        from dcd_amd import ops
+        input, w_off, weight = input.contiguous(), w_off.contiguous(), weight.contiguous()
+        out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous())
+        offset, mask = _offset_mask_split(out)
+        ctx.geometry = geometry
+        ctx.save_for_backward(input, offset, mask, weight, bias, w_off)
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *geometry)
+
+    @staticmethod
+    @once_differentiable
+    def backward(ctx, grad_output):
+        from dcd_amd import ops
+        input, offset, mask, weight, bias, w_off = ctx.saved_tensors
+        grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
+            input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry)
+        gout = _offset_mask_merge(grad_offset, grad_mask, mask)
+        if ctx.needs_input_grad[0]:
+            grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous())
+        gw_off = ops._conv3x3_wrw_call(input, gout, w_off.shape) if ctx.needs_input_grad[1] else None
+        gb_off = ops.channel_sums(gout) if ctx.needs_input_grad[2] else None
+        return grad_input, gw_off, gb_off, grad_weight, grad_bias, None
 
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
@@ -130,7 +174,15 @@ class DCN(DCNv2):
         self.conv_offset_mask.bias.data.zero_()
 
     def forward(self, input):
-        out = self.conv_offset_mask(input)
+        from dcd_amd import ops
+        com = self.conv_offset_mask
+        if (_ONE_NODE and _FUSED_GLUE and input.dtype == torch.float32 and not torch.is_autocast_enabled(input.device.type)
+                and com.bias is not None and com.groups == 1 and com.padding_mode == "zeros" and not isinstance(com.padding, str)
+                and ops.conv3x3_bias_supported(input, com.weight, com.stride, com.padding, com.dilation)
+                and ops._WRW_ENABLED and ops._OFFSET_CONV_FWD):
+            geometry = (*self.kernel_size, *self.stride, *self.padding, *self.dilation, int(self.deformable_groups))
+            return _DCNWithOffsets.apply(input, com.weight, com.bias, self.weight, self.bias, geometry)
+        out = com(input)
         taps2 = out.shape[1] // 3 * 2
         # chunk(3) then cat(o1, o2) is the identity on the first 2/3 of the channels (dcn_v2.py:120-121)
         if out.is_cuda and out.dtype == torch.float32 and out.is_contiguous() and _FUSED_GLUE:

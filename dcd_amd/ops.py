@@ -559,14 +559,21 @@ def conv3x3_supported(x, weight):
             and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
 
 
-def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None):
+def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None):
+    """residual: a tensor of the output's shape that the result is added to IN PLACE (and returned)."""
     L = _lib.lib()
     B, _, H, W = inp.shape
     Co, Ci = weight.shape[0], weight.shape[1]
-    out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
+    if residual is not None:
+        if tuple(residual.shape) != (B, out_channels, H, W) or residual.dtype != torch.float32 or not residual.is_contiguous():
+            raise RuntimeError("conv3x3: residual must be a contiguous fp32 tensor of the output's shape")
+        out = residual
+    else:
+        out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
     n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
     ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
-    st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), out.data_ptr(), B, Ci, H, W, Co,
+    st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), out.data_ptr(),
+                       B, Ci, H, W, Co,
                        1 if backward_data else 0, ws.data_ptr(), n)
     _lib.check(st, "dcd_conv3x3")
     return out
@@ -778,6 +785,18 @@ _OFFSET_CONV_BWD = os.environ.get("DCD_OFFSET_CONV_BWD", "1") != "0"       # 0: 
 _OFFSET_CONV_FWD = os.environ.get("DCD_OFFSET_CONV_FWD", "1") != "0"       # 0: stock forward
 
 
+def channel_sums(gy):
+    """Per-channel sums of a (B, C, ...) fp32 tensor (a bias gradient) by the two-stage fp64 sums of csrc/norm.hip."""
+    L = _lib.lib()
+    gy = _f32c(gy)
+    B, C = gy.shape[0], gy.shape[1]
+    HW = gy.numel() // (B * C)
+    stats = torch.empty((C, 2), dtype=torch.float64, device=gy.device)
+    ws = _bn_ws(C, gy.device)
+    _lib.check(L.dcd_bn_stats(_lib.stream_of(gy), gy.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
+    return stats[:, 0].float()
+
+
 def conv3x3_bias_supported(x, weight, stride, padding, dilation):
     """Biased 3x3 / stride 1 / pad 1 layers that run on csrc/conv.hip end to end (see _ConvBias)."""
     return (_OFFSET_CONV_BWD and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and weight.shape[2] == 3
@@ -824,16 +843,7 @@ class _ConvBias(torch.autograd.Function):
                                                             [need_x, need_w, False])
             gx = sx if need_x else gx
             gw = sw if need_w else gw
-        gb = None
-        if ctx.needs_input_grad[2]:
-            L = _lib.lib()
-            B, C = gy.shape[0], gy.shape[1]
-            HW = gy.numel() // (B * C)
-            stats = torch.empty((C, 2), dtype=torch.float64, device=gy.device)
-            ws = _bn_ws(C, gy.device)
-            _lib.check(L.dcd_bn_stats(_lib.stream_of(gy), gy.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()),
-                       "dcd_bn_stats")
-            gb = stats[:, 0].float()
+        gb = channel_sums(gy) if ctx.needs_input_grad[2] else None
         return gx, gw, gb, None, None, None
 
 

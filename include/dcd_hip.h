@@ -280,15 +280,17 @@ int dcd_bn_backward(void *stream, const float *grad_y, const float *y, const flo
  *   DGDE/model/head/detector_predictor.py:52-58,112-118 (the 64->256 trunks of the class / regression heads) and
  *   DGDE/model/backbone/DCNv2/dcn_v2.py:107-116 (DCN's `conv_offset_mask`, Cin -> 27 with a bias),
  * i.e. torch's cudnn/MIOpen convolution and its input gradient (weight gradient: dcd_conv3x3_wrw below).
- * weight (Cout,Cin,3,3), bias (Cout) or NULL (forward only).  backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
+ * weight (Cout,Cin,3,3), bias (Cout) or NULL (forward only); residual: NULL or an image of the output's shape that is added to the
+ * result (it may BE the output buffer: a gradient accumulated in place, what autograd's separate addition would do).
+ *                         backward_data = 0: input (B,Cin,H,W) -> output (B,Cout,H,W);
  *                         backward_data = 1: input = grad_output (B,Cout,H,W) -> output = grad_input (B,Cin,H,W).
  * Requires W % 4 == 0 and H even (bad-argument otherwise).  workspace: dcd_conv3x3_workspace_bytes(B, Cin, H, W, Cout) bytes
  * (transformed weights; partial images when few regions make the call split its contraction), dead after the call's
  * kernels complete.
  * ---------------------------------------------------------------------------------------------- */
 size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout);
-int dcd_conv3x3(void *stream, const float *input, const float *weight, const float *bias, float *output, int B, int Cin, int H,
-                int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes);
+int dcd_conv3x3(void *stream, const float *input, const float *weight, const float *bias, const float *residual, float *output,
+                int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes);
 
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).

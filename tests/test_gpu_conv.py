@@ -79,10 +79,10 @@ def test_conv3x3_bad_arguments(cuda):
     from dcd_amd import _lib
     L = _lib.lib()
     x = torch.randn(1, 64, 9, 30, device=cuda)
-    assert L.dcd_conv3x3(_lib.stream_of(x), x.data_ptr(), x.data_ptr(), None, x.data_ptr(), 1, 64, 9, 30, 64, 0, x.data_ptr(), 1 << 30) == 1
+    assert L.dcd_conv3x3(_lib.stream_of(x), x.data_ptr(), x.data_ptr(), None, None, x.data_ptr(), 1, 64, 9, 30, 64, 0, x.data_ptr(), 1 << 30) == 1
     x2 = torch.randn(1, 64, 8, 32, device=cuda)
-    assert L.dcd_conv3x3(_lib.stream_of(x2), x2.data_ptr(), x2.data_ptr(), None, x2.data_ptr(), 1, 64, 8, 32, 64, 0, x2.data_ptr(), 16) == 2
-    assert L.dcd_conv3x3(_lib.stream_of(x2), x2.data_ptr(), x2.data_ptr(), x2.data_ptr(), x2.data_ptr(), 1, 64, 8, 32, 64, 1, x2.data_ptr(), 1 << 30) == 1      # bias with backward_data
+    assert L.dcd_conv3x3(_lib.stream_of(x2), x2.data_ptr(), x2.data_ptr(), None, None, x2.data_ptr(), 1, 64, 8, 32, 64, 0, x2.data_ptr(), 16) == 2
+    assert L.dcd_conv3x3(_lib.stream_of(x2), x2.data_ptr(), x2.data_ptr(), x2.data_ptr(), None, x2.data_ptr(), 1, 64, 8, 32, 64, 1, x2.data_ptr(), 1 << 30) == 1      # bias with backward_data
 
 
 @pytest.mark.parametrize("B,C,H,W,f", [(2, 8, 5, 6, 2), (1, 64, 24, 80, 4), (2, 16, 12, 40, 2), (1, 3, 4, 2, 8)])

@@ -405,3 +405,28 @@ def test_errors_raise(cuda):
         _ext.dcn_v2_forward(x.cpu(), w, b, off, m, 3, 3, 1, 1, 1, 1, 1, 1, 1)
     with pytest.raises(RuntimeError):
         _ext.dcn_v2_backward(x.transpose(2, 3), w, b, off, m, gy, 3, 3, 1, 1, 1, 1, 1, 1, 1)
+
+
+@pytest.mark.parametrize("B,C,Co,H,W", [(2, 64, 64, 24, 80), (1, 128, 64, 12, 40), (2, 64, 72, 14, 44)])
+def test_dcn_module_as_one_node_equals_three_nodes(cuda, monkeypatch, B, C, Co, H, W):
+    """`DCN.forward` as one autograd node (offset conv + split + deformable conv, the offset conv's input gradient accumulated
+    into the deformable conv's inside the Winograd kernel) against the three separate nodes: same output, same gradients."""
+    from dcd_amd.model.backbone.DCNv2 import dcn_v2
+    torch.manual_seed(C + H)
+    m = dcn_v2.DCN(C, Co, (3, 3), 1, 1).to(cuda)
+    m.conv_offset_mask.weight.data.normal_(0, 0.02)
+    m.conv_offset_mask.bias.data.normal_(0, 0.3)
+    x = torch.randn(B, C, H, W, device=cuda)
+    gy = torch.randn(B, Co, H, W, device=cuda)
+    res = []
+    for one in (True, False):
+        monkeypatch.setattr(dcn_v2, "_ONE_NODE", one)
+        xi = x.clone().requires_grad_()
+        m.zero_grad()
+        y = m(xi)
+        assert (type(y.grad_fn).__name__ == "_DCNWithOffsetsBackward") == one
+        y.backward(gy)
+        res.append([y.detach(), xi.grad] + [p.grad.clone() for p in (m.weight, m.bias, m.conv_offset_mask.weight, m.conv_offset_mask.bias)])
+    for a, b, what in zip(res[0], res[1], ("output", "grad_input", "grad_weight", "grad_bias", "grad_offset_weight", "grad_offset_bias")):
+        scale = max(b.abs().max().item(), 1e-6)
+        assert (a - b).abs().max().item() <= 2e-6 * scale, what
