@@ -8,6 +8,7 @@
 //                  contribution to grad_w (x * patch), reduced per block and added with (2f)^2 atomics per block.
 // All HBM-bound (forward: one write of y; backward: one read of grad_y); NCHW fp32, one (b, c) plane chunk per workgroup.
 #include <hip/hip_runtime.h>
+#include <stdlib.h>
 
 #include <cstdint>
 #include <stdint.h>
@@ -95,6 +96,60 @@ __global__ __launch_bounds__(256) void up_dw_bwd(const float *__restrict__ x, co
         }
     }
     if (qv) gx[(size_t)plane * H * W + q] = dx;
+    __syncthreads();
+    for (int i = threadIdx.x; i < K * K; i += 256)
+        atomicAdd(gw + (size_t)c * K * K + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
+}
+
+// F = 2, 4: grid = (row chunks, B*C); a workgroup walks `rows` input rows of one plane, one input element per thread and trip, and
+// keeps its share of grad_w[c] (K*K = 16 / 64 values) in registers: ONE wave reduction and K*K atomics per workgroup at the end,
+// where up_dw_bwd pays a six-step shuffle reduction per tap and element (96 shuffles per element at F = 2) and K*K atomics per
+// 256 elements.  Same sums; the order of the additions into grad_w differs (atomics: it was not fixed before either).
+template <int F>
+__global__ __launch_bounds__(256) void up_dw_bwd_rows(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gy,
+                                                      float *__restrict__ gx, float *__restrict__ gw, int C, int H, int W, int rows)
+{
+    constexpr int K = 2 * F, P = F / 2;
+    __shared__ float ws[K * K];
+    __shared__ float red[4][K * K];
+    const int plane = blockIdx.y, c = plane % C;
+    for (int i = threadIdx.x; i < K * K; i += 256) ws[i] = w[(size_t)c * K * K + i];
+    __syncthreads();
+    const int Ho = H * F, Wo = W * F;
+    const int r0 = blockIdx.x * rows, r1 = r0 + rows < H ? r0 + rows : H;
+    const float *gp = gy + (size_t)plane * Ho * Wo;
+    const float *xp = x + (size_t)plane * H * W;
+    float *gxp = gx + (size_t)plane * H * W;
+    float acc[K * K];
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) acc[i] = 0.f;
+    for (int q = r0 * W + threadIdx.x; q < r1 * W; q += 256) {
+        const int iy = q / W, ix = q - iy * W;
+        const float xv = xp[q];
+        const int Y0 = iy * F - P, X0 = ix * F - P;
+        float dx = 0.f;
+#pragma unroll
+        for (int ky = 0; ky < K; ++ky) {
+            const int Y = Y0 + ky;
+            const bool yv = Y >= 0 && Y < Ho;
+#pragma unroll
+            for (int kx = 0; kx < K; ++kx) {
+                const int X = X0 + kx;
+                const float g = (yv && X >= 0 && X < Wo) ? gp[(size_t)Y * Wo + X] : 0.f;
+                dx += g * ws[ky * K + kx];
+                acc[ky * K + kx] += g * xv;
+            }
+        }
+        gxp[q] = dx;
+    }
+    const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+#pragma unroll
+    for (int i = 0; i < K * K; ++i) {
+        float s = acc[i];
+#pragma unroll
+        for (int o = 32; o > 0; o >>= 1) s += __shfl_xor(s, o);
+        if (lane == 0) red[wave][i] = s;
+    }
     __syncthreads();
     for (int i = threadIdx.x; i < K * K; i += 256)
         atomicAdd(gw + (size_t)c * K * K + i, red[0][i] + red[1][i] + red[2][i] + red[3][i]);
@@ -216,7 +271,17 @@ int dcd_upsample_dw_backward(void *stream_, const float *x, const float *weight,
     if (f != 2 && f != 4 && f != 8) return DCD_ERR_BAD_ARG;
     if (!dcd_zero_fill(stream, grad_weight, (size_t)C * 4 * f * f)) return DCD_ERR_LAUNCH;   // a launch, not a memset node: zero_fill.h
     dim3 grid((H * W + 255) / 256, B * C), block(256);
-    if (f == 2) hipLaunchKernelGGL(up_dw_bwd<2>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
+    // f = 2, 4: row-chunk kernel, about 2048 workgroups (8 per CU) or at least four trips per thread
+    int chunks = (2048 + B * C - 1) / (B * C);
+    const int max_chunks = (H * W + 1023) / 1024;
+    if (chunks > max_chunks) chunks = max_chunks;
+    if (chunks < 1) chunks = 1;
+    const int rows = (H + chunks - 1) / chunks;
+    dim3 rgrid((H + rows - 1) / rows, B * C);
+    static const bool old_kernel = getenv("DCD_UP_BWD_OLD") != nullptr;                       // A/B timing
+    if (f == 2 && !old_kernel) hipLaunchKernelGGL(up_dw_bwd_rows<2>, rgrid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W, rows);
+    else if (f == 4 && !old_kernel) hipLaunchKernelGGL(up_dw_bwd_rows<4>, rgrid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W, rows);
+    else if (f == 2) hipLaunchKernelGGL(up_dw_bwd<2>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
     else if (f == 4) hipLaunchKernelGGL(up_dw_bwd<4>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
     else hipLaunchKernelGGL(up_dw_bwd<8>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;

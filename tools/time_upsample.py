@@ -1,4 +1,5 @@
-"""Depthwise ConvTranspose2d (IDAUp.up_*: kernel 2f, stride f, padding f/2, groups = channels) forward + backward, stock op."""
+"""Depthwise ConvTranspose2d (IDAUp.up_*: kernel 2f, stride f, padding f/2, groups = channels) forward + backward: the stock op,
+or with `ours` as first argument csrc/upsample.hip (DCD_UP_BWD_OLD=1: its first backward kernel)."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import torch
@@ -7,7 +8,11 @@ SHAPES = [(256, 12, 40, 2), (128, 24, 80, 2), (128, 24, 80, 2), (64, 48, 160, 2)
 dev = torch.device("cuda:0")
 tot = 0
 for C, H, W, f in SHAPES:
-    up = nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False).to(dev)
+    if len(sys.argv) > 1 and sys.argv[1] == "ours":
+        from dcd_amd.model.layers.conv import DepthwiseUpsample
+        up = DepthwiseUpsample(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False).to(dev)
+    else:
+        up = nn.ConvTranspose2d(C, C, f * 2, stride=f, padding=f // 2, groups=C, bias=False).to(dev)
     x = torch.randn(8, C, H, W, device=dev, requires_grad=True)
     def step():
         y = up(x)
