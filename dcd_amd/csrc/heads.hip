@@ -637,6 +637,79 @@ __global__ __launch_bounds__(256) void context_norm_bwd(const float *__restrict_
     for (int i = lane; i < K; i += 64) dr[i] = inv * (gr[i] - mean_g - yr[i] * c);
 }
 
+// Row-per-workgroup forms for K % 4 == 0, K <= 4096 (GMW: K = 2628): the row lives in registers (up to four float4 per thread), so
+// it is read once and written once -- the wave-per-row kernels above make three dependent passes with four waves per CU (22 us for
+// the 10.8 MB of an (8, 128, 2628) tensor; this form is launch- and HBM-bound).
+__device__ __forceinline__ float block_sum256(float v, float *sh)
+{
+    v = wave_sum64(v);
+    __syncthreads();                                        // sh may still be read from the previous reduction
+    if ((threadIdx.x & 63) == 0) sh[threadIdx.x >> 6] = v;
+    __syncthreads();
+    return sh[0] + sh[1] + sh[2] + sh[3];
+}
+
+__global__ __launch_bounds__(256) void context_norm_fwd_row(const float *__restrict__ x, float *__restrict__ y, float *__restrict__ inv_out,
+                                                            int K, float eps)
+{
+    __shared__ float sh[4];
+    const int row = blockIdx.x, K4 = K >> 2;
+    const float4 *xr = reinterpret_cast<const float4 *>(x + (size_t)row * K);
+    float4 v[4];
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        v[j] = i < K4 ? xr[i] : make_float4(0.f, 0.f, 0.f, 0.f);
+        s += (v[j].x + v[j].y) + (v[j].z + v[j].w);
+    }
+    const float m = block_sum256(s, sh) / (float)K;
+    float q = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+        if (threadIdx.x + 256 * j < K4) {
+            v[j].x -= m; v[j].y -= m; v[j].z -= m; v[j].w -= m;
+            q += (v[j].x * v[j].x + v[j].y * v[j].y) + (v[j].z * v[j].z + v[j].w * v[j].w);
+        }
+    const float inv = 1.f / sqrtf(block_sum256(q, sh) / (float)(K - 1) + eps);
+    float4 *yr = reinterpret_cast<float4 *>(y + (size_t)row * K);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < K4) yr[i] = make_float4(v[j].x * inv, v[j].y * inv, v[j].z * inv, v[j].w * inv);
+    }
+    if (threadIdx.x == 0) inv_out[row] = inv;
+}
+
+__global__ __launch_bounds__(256) void context_norm_bwd_row(const float *__restrict__ dy, const float *__restrict__ y,
+                                                            const float *__restrict__ inv_in, float *__restrict__ dx, int K)
+{
+    __shared__ float sh[4];
+    const int row = blockIdx.x, K4 = K >> 2;
+    const float4 *gr = reinterpret_cast<const float4 *>(dy + (size_t)row * K), *yr = reinterpret_cast<const float4 *>(y + (size_t)row * K);
+    float4 g[4], v[4];
+    float s0 = 0.f, s1 = 0.f;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        g[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        if (i < K4) { g[j] = gr[i]; v[j] = yr[i]; }
+        s0 += (g[j].x + g[j].y) + (g[j].z + g[j].w);
+        s1 += (g[j].x * v[j].x + g[j].y * v[j].y) + (g[j].z * v[j].z + g[j].w * v[j].w);
+    }
+    const float mean_g = block_sum256(s0, sh) / (float)K;
+    const float c = block_sum256(s1, sh) / (float)(K - 1);
+    const float inv = inv_in[row];
+    float4 *dr = reinterpret_cast<float4 *>(dx + (size_t)row * K);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        const int i = threadIdx.x + 256 * j;
+        if (i < K4)
+            dr[i] = make_float4(inv * (g[j].x - mean_g - v[j].x * c), inv * (g[j].y - mean_g - v[j].y * c),
+                                inv * (g[j].z - mean_g - v[j].z * c), inv * (g[j].w - mean_g - v[j].w * c));
+    }
+}
+
 // out = sum of n tensors (n <= 16) in one pass: the gradient of a feature map that fans out to the head trunks.
 struct SumSrcs {
     const float *p[16];
@@ -817,7 +890,10 @@ int dcd_context_norm_forward(void *stream_, const float *x, float *y, float *inv
     (void)hipGetLastError();
     if (rows == 0) return DCD_OK;
     if (!x || !y || !inv || rows < 0 || K < 2) return DCD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(context_norm_fwd, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, inv, rows, K, eps);
+    if ((K & 3) == 0 && K <= 4096 && (((uintptr_t)x | (uintptr_t)y) & 15) == 0)
+        hipLaunchKernelGGL(context_norm_fwd_row, dim3(rows), dim3(256), 0, stream, x, y, inv, K, eps);
+    else
+        hipLaunchKernelGGL(context_norm_fwd, dim3((rows + 3) / 4), dim3(256), 0, stream, x, y, inv, rows, K, eps);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
@@ -827,7 +903,10 @@ int dcd_context_norm_backward(void *stream_, const float *grad_y, const float *y
     (void)hipGetLastError();
     if (rows == 0) return DCD_OK;
     if (!grad_y || !y || !inv || !grad_x || rows < 0 || K < 2) return DCD_ERR_BAD_ARG;
-    hipLaunchKernelGGL(context_norm_bwd, dim3((rows + 3) / 4), dim3(256), 0, stream, grad_y, y, inv, grad_x, rows, K);
+    if ((K & 3) == 0 && K <= 4096 && (((uintptr_t)grad_y | (uintptr_t)y | (uintptr_t)grad_x) & 15) == 0)
+        hipLaunchKernelGGL(context_norm_bwd_row, dim3(rows), dim3(256), 0, stream, grad_y, y, inv, grad_x, K);
+    else
+        hipLaunchKernelGGL(context_norm_bwd, dim3((rows + 3) / 4), dim3(256), 0, stream, grad_y, y, inv, grad_x, rows, K);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

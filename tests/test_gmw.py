@@ -117,7 +117,7 @@ def test_context_norm_kernel_against_stock_formula(cuda):
     """csrc/heads.hip context normalisation (forward + backward) against the reference's formula in fp64."""
     from dcd_amd import ops
     g = torch.Generator().manual_seed(3)
-    for B, C, K in ((2, 128, 2628), (3, 5, 37)):
+    for B, C, K in ((2, 128, 2628), (3, 5, 37), (1, 7, 4096), (2, 3, 100), (1, 2, 4100)):      # row-in-registers kernel: K % 4 == 0, K <= 4096
         x = torch.randn(B, C, K, generator=g) * 2 + 0.5
         gy = torch.randn(B, C, K, generator=g)
         xd = x.double().requires_grad_()
