@@ -6,9 +6,11 @@ import torch
 def correspondence_loss(P, C_gt=None):
     """mean over the batch of sum((1 - 2 C) P)  (GMW/lib/losses.py:22-26,115-119).  C_gt = None means the identity the
     train loop uses (main.py:456): sum(P) - 2 trace(P), without materialising a (B, 2628, 2628) identity."""
+    # sums over the (2628, 2628) plans in two stages (rows, then the row sums): reducing both axes in one call makes ATen sum
+    # 6.9 M contiguous values per output with a handful of workgroups -- 1.6 ms for the 221 MB of eight plans (0.14 TB/s)
     if C_gt is None:
-        return (P.sum(dim=(-2, -1)) - 2.0 * P.diagonal(dim1=-2, dim2=-1).sum(-1)).mean()
-    return ((1.0 - 2.0 * C_gt) * P).sum(dim=(-2, -1)).mean()
+        return (P.sum(dim=-1).sum(dim=-1) - 2.0 * P.diagonal(dim1=-2, dim2=-1).sum(-1)).mean()
+    return ((1.0 - 2.0 * C_gt) * P).sum(dim=-1).sum(dim=-1).mean()
 
 
 def compute_reg_loss(pre_depths, edge_weight, gt_depth, good_idx):
