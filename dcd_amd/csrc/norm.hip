@@ -13,6 +13,7 @@
 // All kernels are HBM-bound; layout NCHW, one (b, c) plane chunk per workgroup so scale/shift are scalars.
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
 
@@ -276,6 +277,140 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
     }
 }
 
+// ---- small channels: one launch per direction ---------------------------------------------------------------------------
+// When a channel has at most SM_MAX values (B * HW <= 16384: the 24x80 and 12x40 maps of DLA levels 4 / 5 and of the first DCN
+// up-sampling stages at 8 images) one workgroup per channel keeps them in registers (<= 16 float4 per thread): statistics and
+// normalisation are ONE launch and one read instead of two launches (partial sums + apply) that each cost a dispatch whatever
+// their size.  Same fp64 sums, other order of the additions.
+constexpr int SM_V = 16;                     // float4 per thread
+constexpr int SM_MAX = SM_V * 4 * BT;        // 16384 values per channel
+
+__device__ inline void block_bcast2(double &a, double &b)
+{
+    __shared__ double bc[2];
+    block_sum2(a, b);
+    if (threadIdx.x == 0) { bc[0] = a; bc[1] = b; }
+    __syncthreads();
+    a = bc[0];
+    b = bc[1];
+}
+
+__global__ __launch_bounds__(BT) void bn_small_fwd(const float *__restrict__ x, const float *__restrict__ residual,
+                                                   const float *__restrict__ weight, const float *__restrict__ bias,
+                                                   float *__restrict__ running_mean, float *__restrict__ running_var,
+                                                   long long *__restrict__ num_batches_tracked, float momentum, float eps, int relu,
+                                                   float *__restrict__ y, float *__restrict__ save_mean,
+                                                   float *__restrict__ save_invstd, int B, int C, int HW4)
+{
+    const int c = blockIdx.x;
+    const int total = B * HW4;
+    float4 v[SM_V];
+    long off[SM_V];
+    double ds = 0.0, dq = 0.0;
+#pragma unroll
+    for (int j = 0; j < SM_V; ++j) {
+        const int e = threadIdx.x + BT * j;
+        v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        off[j] = -1;
+        if (e < total) {
+            const int b = e / HW4, q = e - b * HW4;
+            off[j] = ((long)b * C + c) * (4L * HW4) + 4L * q;
+            v[j] = *reinterpret_cast<const float4 *>(x + off[j]);
+            ds += (double)((v[j].x + v[j].y) + (v[j].z + v[j].w));
+            dq += (double)fmaf(v[j].x, v[j].x, fmaf(v[j].y, v[j].y, fmaf(v[j].z, v[j].z, v[j].w * v[j].w)));
+        }
+    }
+    block_bcast2(ds, dq);
+    const double count = (double)total * 4.0;
+    const double m = ds / count;
+    double var = dq / count - m * m;
+    var = var < 0.0 ? 0.0 : var;
+    const float mean = (float)m, invstd = (float)(1.0 / sqrt(var + (double)eps));
+    if (threadIdx.x == 0) {
+        save_mean[c] = mean;
+        save_invstd[c] = invstd;
+        if (running_mean) {
+            const double unbiased = count > 1.0 ? var * (count / (count - 1.0)) : var;
+            running_mean[c] = (1.f - momentum) * running_mean[c] + momentum * mean;
+            running_var[c] = (1.f - momentum) * running_var[c] + momentum * (float)unbiased;
+        }
+        if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
+    }
+    const float scale = invstd * (weight ? weight[c] : 1.f);
+    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+#pragma unroll
+    for (int j = 0; j < SM_V; ++j) {
+        if (off[j] < 0) continue;
+        float4 r = v[j];
+        r.x = fmaf(r.x, scale, shift); r.y = fmaf(r.y, scale, shift); r.z = fmaf(r.z, scale, shift); r.w = fmaf(r.w, scale, shift);
+        if (residual) {
+            const float4 t = *reinterpret_cast<const float4 *>(residual + off[j]);
+            r.x += t.x; r.y += t.y; r.z += t.z; r.w += t.w;
+        }
+        if (relu) {          // NaN-propagating, like clamp_min
+            r.x = r.x < 0.f ? 0.f : r.x; r.y = r.y < 0.f ? 0.f : r.y; r.z = r.z < 0.f ? 0.f : r.z; r.w = r.w < 0.f ? 0.f : r.w;
+        }
+        *reinterpret_cast<float4 *>(y + off[j]) = r;
+    }
+}
+
+__global__ __launch_bounds__(BT) void bn_small_bwd(const float *__restrict__ dy, const float *__restrict__ y,
+                                                   const float *__restrict__ x, const float *__restrict__ weight,
+                                                   const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
+                                                   float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dweight,
+                                                   float *__restrict__ dbias, int B, int C, int HW4)
+{
+    const int c = blockIdx.x;
+    const int total = B * HW4;
+    const float mean = save_mean[c], invstd = save_invstd[c];
+    float4 d[SM_V], v[SM_V];
+    long off[SM_V];
+    double d0 = 0.0, d1 = 0.0;
+#pragma unroll
+    for (int j = 0; j < SM_V; ++j) {
+        const int e = threadIdx.x + BT * j;
+        d[j] = v[j] = make_float4(0.f, 0.f, 0.f, 0.f);
+        off[j] = -1;
+        if (e < total) {
+            const int b = e / HW4, q = e - b * HW4;
+            off[j] = ((long)b * C + c) * (4L * HW4) + 4L * q;
+            d[j] = *reinterpret_cast<const float4 *>(dy + off[j]);
+            v[j] = *reinterpret_cast<const float4 *>(x + off[j]);
+            if (y) {
+                const float4 o = *reinterpret_cast<const float4 *>(y + off[j]);
+                d[j].x = o.x <= 0.f ? 0.f : d[j].x; d[j].y = o.y <= 0.f ? 0.f : d[j].y;
+                d[j].z = o.z <= 0.f ? 0.f : d[j].z; d[j].w = o.w <= 0.f ? 0.f : d[j].w;
+            }
+            d0 += (double)((d[j].x + d[j].y) + (d[j].z + d[j].w));
+            d1 += (double)fmaf(d[j].x, v[j].x - mean, fmaf(d[j].y, v[j].y - mean, fmaf(d[j].z, v[j].z - mean, d[j].w * (v[j].w - mean))));
+        }
+    }
+    block_bcast2(d0, d1);
+    if (threadIdx.x == 0) {
+        if (dweight) dweight[c] = (float)(d1 * (double)invstd);
+        if (dbias) dbias[c] = (float)d0;
+    }
+    const double count = (double)total * 4.0;
+    const float k1 = invstd * (weight ? weight[c] : 1.f);
+    const float a = (float)(d0 / count);
+    const float bq = (float)(d1 / count * (double)invstd * (double)invstd);
+#pragma unroll
+    for (int j = 0; j < SM_V; ++j) {
+        if (off[j] < 0) continue;
+        if (dres) *reinterpret_cast<float4 *>(dres + off[j]) = d[j];
+        float4 r;
+        r.x = (d[j].x - a - (v[j].x - mean) * bq) * k1; r.y = (d[j].y - a - (v[j].y - mean) * bq) * k1;
+        r.z = (d[j].z - a - (v[j].z - mean) * bq) * k1; r.w = (d[j].w - a - (v[j].w - mean) * bq) * k1;
+        *reinterpret_cast<float4 *>(dx + off[j]) = r;
+    }
+}
+
+inline bool small_channels(int B, int C, int64_t HW)
+{
+    static const bool off = getenv("DCD_BN_SMALL") && atoi(getenv("DCD_BN_SMALL")) == 0;      // A/B timing
+    return !off && (HW & 3) == 0 && (int64_t)B * HW <= SM_MAX && C >= 64;
+}
+
 // ---- BN (+ReLU) evaluated at a list of positions only (training forward of the regression-head trunks: the loss reads the
 // normalised features at <= 40 object centres per image, plus the 832 border cells for the edge-fusion branch).
 // grid = (C); block c finalises its channel (mean / invstd from the stats partials or combined sums, running statistics)
@@ -448,6 +583,11 @@ int dcd_bn_train_forward(void *stream_, const float *x, const float *residual, c
     if (!x || !y || !save_mean || !save_invstd || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
     if ((running_mean == nullptr) != (running_var == nullptr)) return DCD_ERR_BAD_ARG;
     if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    if (small_channels(B, C, HW)) {
+        hipLaunchKernelGGL(bn_small_fwd, dim3(C), dim3(BT), 0, stream, x, residual, weight, bias, running_mean, running_var,
+                           (long long *)num_batches_tracked, momentum, eps, relu, y, save_mean, save_invstd, B, C, (int)(HW / 4));
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     const Plane g = make_plane(B, C, HW);
     const int S = slices(g);
     hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
@@ -466,6 +606,11 @@ int dcd_bn_backward(void *stream_, const float *grad_y, const float *y, const fl
     (void)hipGetLastError();
     if (!grad_y || !x || !save_mean || !save_invstd || !grad_x || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
     if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    if (small_channels(B, C, HW)) {
+        hipLaunchKernelGGL(bn_small_bwd, dim3(C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd, grad_x,
+                           grad_residual, grad_weight, grad_bias, B, C, (int)(HW / 4));
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     const Plane g = make_plane(B, C, HW);
     const int S = slices(g);
     hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws);

@@ -15,7 +15,10 @@ CASES = [  # B, C, H, W, residual, relu
     (2, 5, 7, 9, True, True),          # HW not a multiple of 4 -> scalar path
     (1, 1, 3, 5, False, False),
     (3, 33, 12, 40, True, False),
-    (2, 512, 12, 40, False, True),
+    (2, 512, 12, 40, False, True),     # small channels: one launch per direction (B*HW <= 16384, C >= 64)
+    (8, 256, 24, 80, True, False),     # ... at the size of DLA level 4 (15360 values per channel)
+    (1, 64, 128, 128, False, True),    # ... exactly 16384 values per channel
+    (1, 64, 128, 132, True, True),     # just above: two-launch path
     (1, 16, 384, 1280, False, True),   # the full-resolution base layer (one image)
 ]
 
