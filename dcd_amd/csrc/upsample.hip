@@ -60,6 +60,57 @@ __global__ __launch_bounds__(256) void up_dw_fwd(const float *__restrict__ x, co
     *reinterpret_cast<float4 *>(yp + o0) = make_float4(out[0], out[1], out[2], out[3]);
 }
 
+// F = 2 (seven of IDAUp's eight layers): a thread writes a 2 x 4 block of outputs (rows 2a, 2a+1; columns 4m .. 4m+3), which read
+// the same 3 x 4 inputs (rows a-1 .. a+1, columns 2m-1 .. 2m+2): nine loads per eight outputs where up_dw_fwd issues sixteen per four.
+// Kernel taps (ky = Y + 1 - 2 iy, kx = X + 1 - 2 ix): row 2a <- (a, 1), (a-1, 3); row 2a+1 <- (a+1, 0), (a, 2); column 4m+u <-
+// u = 0: (2m, 1), (2m-1, 3);  1: (2m+1, 0), (2m, 2);  2: (2m+1, 1), (2m, 3);  3: (2m+2, 0), (2m+1, 2).   W even (Wo % 4 == 0).
+__global__ __launch_bounds__(256) void up_dw_fwd2_block(const float *__restrict__ x, const float *__restrict__ w, float *__restrict__ y,
+                                                        int C, int H, int W, const float *__restrict__ skip)
+{
+    const int plane = blockIdx.y, c = plane % C;
+    float k[4][4];
+#pragma unroll
+    for (int i = 0; i < 16; ++i) k[i >> 2][i & 3] = w[(size_t)c * 16 + i];      // uniform address: scalar loads
+    const int W2 = W >> 1;
+    const int t = blockIdx.x * 256 + threadIdx.x;
+    if (t >= H * W2) return;
+    const int a = t / W2, m = t - a * W2;
+    const float *xp = x + (size_t)plane * H * W;
+    float v[3][4];
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+        const int iy = a - 1 + r;
+        const bool rv = iy >= 0 && iy < H;
+        const float *row = xp + (size_t)(rv ? iy : 0) * W;
+        const float2 mid = rv ? *reinterpret_cast<const float2 *>(row + 2 * m) : make_float2(0.f, 0.f);      // columns 2m, 2m+1
+        v[r][0] = (rv && m > 0) ? row[2 * m - 1] : 0.f;
+        v[r][1] = mid.x;
+        v[r][2] = mid.y;
+        v[r][3] = (rv && 2 * m + 2 < W) ? row[2 * m + 2] : 0.f;
+    }
+    const int Wo = 2 * W;
+    const size_t o0 = (size_t)plane * (4 * (size_t)H * W) + (size_t)(2 * a) * Wo + 4 * m;
+    float out[2][4];
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        // (input row index into v, kernel row) pairs of this output row
+        const int r1 = rr == 0 ? 1 : 2, ky1 = rr == 0 ? 1 : 0, r0 = rr == 0 ? 0 : 1, ky0 = rr == 0 ? 3 : 2;
+        out[rr][0] = v[r1][1] * k[ky1][1] + v[r1][0] * k[ky1][3] + v[r0][1] * k[ky0][1] + v[r0][0] * k[ky0][3];
+        out[rr][1] = v[r1][2] * k[ky1][0] + v[r1][1] * k[ky1][2] + v[r0][2] * k[ky0][0] + v[r0][1] * k[ky0][2];
+        out[rr][2] = v[r1][2] * k[ky1][1] + v[r1][1] * k[ky1][3] + v[r0][2] * k[ky0][1] + v[r0][1] * k[ky0][3];
+        out[rr][3] = v[r1][3] * k[ky1][0] + v[r1][2] * k[ky1][2] + v[r0][3] * k[ky0][0] + v[r0][2] * k[ky0][2];
+    }
+#pragma unroll
+    for (int rr = 0; rr < 2; ++rr) {
+        float4 o = make_float4(out[rr][0], out[rr][1], out[rr][2], out[rr][3]);
+        if (skip) {                                           // IDAUp: node(up(x) + skip) -- the sum leaves this kernel
+            const float4 sk = *reinterpret_cast<const float4 *>(skip + o0 + (size_t)rr * Wo);
+            o.x += sk.x; o.y += sk.y; o.z += sk.z; o.w += sk.w;
+        }
+        *reinterpret_cast<float4 *>(y + o0 + (size_t)rr * Wo) = o;
+    }
+}
+
 // grid = (ceil(H*W / 256), B*C); one input element per thread
 template <int F>
 __global__ __launch_bounds__(256) void up_dw_bwd(const float *__restrict__ x, const float *__restrict__ w, const float *__restrict__ gy,
@@ -243,7 +294,10 @@ static int upsample_forward(hipStream_t stream, const float *x, const float *wei
     if ((f != 2 && f != 4 && f != 8) || ((W * f) & 3)) return DCD_ERR_BAD_ARG;
     const int no = H * f * W * f;
     dim3 grid((no / 4 + 255) / 256, B * C), block(256);
-    if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
+    static const bool old_fwd = getenv("DCD_UP_FWD_OLD") != nullptr;                          // A/B timing
+    if (f == 2 && !old_fwd)
+        hipLaunchKernelGGL(up_dw_fwd2_block, dim3((H * (W / 2) + 255) / 256, B * C), block, 0, stream, x, weight, y, C, H, W, skip);
+    else if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
     else if (f == 4) hipLaunchKernelGGL(up_dw_fwd<4>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
     else hipLaunchKernelGGL(up_dw_fwd<8>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
