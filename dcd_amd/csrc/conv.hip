@@ -591,10 +591,11 @@ static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
         p.nb = Kk <= 32 ? 1 : 2;
         p.nz = (Kk + 32 * p.nb - 1) / (32 * p.nb);
         const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
-        // split the contraction while the launch leaves CUs idle and a split keeps at least 8 chunks (its output transform
-        // and the partial image it writes are not free)
+        // split the contraction while the launch leaves CUs idle and a split keeps at least 4 chunks (its output transform
+        // and the partial image it writes are not free; 4 vs 8: one image per GPU, 256 -> 256 @ 24x80 39 -> 32 us)
+        static const int min_chunks = getenv("DCD_CONV_MINCHUNK") ? atoi(getenv("DCD_CONV_MINCHUNK")) : 4;
         int ks = 1;
-        while (ks < 8 && wgs * (ks * 2) <= cus && p.nchunk / (ks * 2) >= 8) ks *= 2;
+        while (ks < 8 && wgs * (ks * 2) <= cus && p.nchunk / (ks * 2) >= min_chunks) ks *= 2;
         p.ksplit = ks;
         const int64_t rounds = (wgs * ks + cus - 1) / cus;
         const int64_t cost = rounds * ((p.nchunk + ks - 1) / ks + 2) * (g == 0 ? 16 : 17);     // 12x20: 30 of 32 lanes, more halo
