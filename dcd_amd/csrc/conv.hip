@@ -684,6 +684,9 @@ static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int 
     strips_x = (W + 31) / 32;
     const int T = B * (H / 2) * strips_x;
     S = 256 / (nog * ncg);                        // about one workgroup per CU
+    // ... but at least four strips per workgroup: every split writes a 16 x 64 x 64 partial (67 MB for 256 of them) that the
+    // reduce kernel reads back, which at one image per GPU cost more than the product itself (29 + 17 us at 64 -> 64 @ 96x320)
+    if (S > T / 4) S = T / 4;
     if (S >= 8) S &= ~7;
     if (S < 1) S = 1;
     if (S > T) S = T;
