@@ -116,6 +116,55 @@ __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict
 // grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
 // ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
 // partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
+// Both directions of one layer in one launch (blockIdx.y = mode): the forward call of a training step prepares the weights of its
+// own backward-data call as well -- they do not change in between, and a prep launch costs a dispatch however small it is.
+struct PrepBoth {
+    float *ul[2];
+    int Cc[2], Kk[2], nchunk[2], nz[2], ks[2];
+};
+
+__global__ void wino_prep_weights_both(const float *__restrict__ w, PrepBoth p)
+{
+    const int mode = blockIdx.y;
+    if (!p.ul[mode]) return;
+    const int WN_KS = p.ks[mode], nchunk = p.nchunk[mode], Cc = p.Cc[mode], Kk = p.Kk[mode];
+    float *ul = p.ul[mode];
+    const int n = p.nz[mode] * nchunk * WN_KS * WN_CH;
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int s = r & 3; r >>= 2;
+        const int h = r & 1; r >>= 1;
+        const int kk = r % WN_KS; r /= WN_KS;
+        const int ck = r % nchunk, z = r / nchunk;
+        const int k = z * WN_KS + kk, c = ck * WN_CH + 2 * s + h;
+        float g[3][3];
+#pragma unroll
+        for (int a = 0; a < 3; ++a)
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                float v = 0.f;
+                if (k < Kk && c < Cc)
+                    v = mode == 0 ? w[(((size_t)k * Cc + c) * 3 + a) * 3 + b] : w[(((size_t)c * Kk + k) * 3 + (2 - a)) * 3 + (2 - b)];
+                g[a][b] = v;
+            }
+        float t[4][3];                       // G g
+#pragma unroll
+        for (int b = 0; b < 3; ++b) {
+            t[0][b] = g[0][b];
+            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+            t[3][b] = g[2][b];
+        }
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), t[xi][2]};
+#pragma unroll
+            for (int nu = 0; nu < 4; ++nu)
+                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * WN_KS + kk) * 2 + h) * 4 + s] = u[nu];
+        }
+    }
+}
+
 // bias (may be null): added to the output channels by split 0; residual (may be null, may be y itself): a (B, Kk, H, W) image
 // added to the result by split 0 (a gradient that is already there: the caller's accumulation without a separate pass).
 template <int TR, int TC, int NB>
@@ -633,12 +682,14 @@ size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout)
     return (nchunk * nz * 16 * 64 * WN_CH + (pf > pd ? pf : pd)) * sizeof(float);
 }
 
-int dcd_conv3x3(void *stream_, const float *input, const float *weight, const float *bias, const float *residual, float *output,
-                int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes)
+// weights: raw (Cout, Cin, 3, 3) when !prepared (transformed into the head of the workspace first), else the transformed weights
+// of this direction from dcd_conv3x3_transform_weights.
+static int conv3x3_run(hipStream_t stream, const float *input, const float *weights, int prepared, const float *bias,
+                       const float *residual, float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                       size_t workspace_bytes)
 {
-    hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
-    if (!input || !weight || !output || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if (!input || !weights || !output || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
     if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31) || (bias && backward_data)) return DCD_ERR_BAD_ARG;
     // contraction channels Cc and produced channels Kk of this call
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
@@ -655,14 +706,19 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, const fl
         }
     }
     const int ksz = 32 * pl.nb;
-    const size_t ul_floats = (size_t)pl.nchunk * pl.nz * 16 * ksz * WN_CH;
+    const size_t ul_floats = prepared ? 0 : (size_t)pl.nchunk * pl.nz * 16 * ksz * WN_CH;
     const size_t img = (size_t)B * Kk * H * W;
-    if (workspace_bytes < (ul_floats + (size_t)(pl.ksplit - 1) * img) * sizeof(float)) return DCD_ERR_WORKSPACE;
-    float *ul = (float *)workspace, *part = ul + ul_floats;
-    const int nprep = pl.nz * pl.nchunk * ksz * WN_CH;
-    // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
-    hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weight,
-                       ul, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz, ksz);
+    const size_t need = (ul_floats + (size_t)(pl.ksplit - 1) * img) * sizeof(float);
+    if (need && (!workspace || workspace_bytes < need)) return DCD_ERR_WORKSPACE;
+    float *part = (float *)workspace + ul_floats;
+    const float *ul = weights;
+    if (!prepared) {
+        const int nprep = pl.nz * pl.nchunk * ksz * WN_CH;
+        // forward: w is (Cout, Cin, 3, 3) = (Kk, Cc); backward-data: w is (Cout, Cin) = (Cc, Kk), read transposed + flipped
+        hipLaunchKernelGGL(wino_prep_weights, dim3((nprep + 255) / 256 < 4096 ? (nprep + 255) / 256 : 4096), dim3(256), 0, stream, weights,
+                           (float *)workspace, Cc, Kk, backward_data ? 1 : 0, pl.nchunk, pl.nz, ksz);
+        ul = (const float *)workspace;
+    }
     const int st = pl.geom == 0 ? (pl.nb == 2 ? conv_launch<2, 16, 2>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk)
                                               : conv_launch<2, 16, 1>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk))
                                 : (pl.nb == 2 ? conv_launch<3, 10, 2>(stream, pl, input, ul, output, part, bias, residual, B, Cc, H, W, Kk)
@@ -674,6 +730,57 @@ int dcd_conv3x3(void *stream_, const float *input, const float *weight, const fl
         hipLaunchKernelGGL(wino_sum_partials, dim3(nb), dim3(256), 0, stream, output, (const float *)part, n4, pl.ksplit - 1);
     }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3(void *stream_, const float *input, const float *weight, const float *bias, const float *residual, float *output,
+                int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes)
+{
+    if (!workspace) return DCD_ERR_BAD_ARG;
+    return conv3x3_run((hipStream_t)stream_, input, weight, 0, bias, residual, output, B, Cin, H, W, Cout, backward_data, workspace,
+                       workspace_bytes);
+}
+
+// floats of the transformed weights of one direction (layout: the kernels' weight slab per (output slice, chunk))
+static size_t tw_floats(int Cin, int Cout, int backward_data)
+{
+    const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
+    const int nb = Kk <= 32 ? 1 : 2, ks = 32 * nb;
+    return (size_t)((Cc + WN_CH - 1) / WN_CH) * ((Kk + ks - 1) / ks) * 16 * ks * WN_CH;
+}
+
+size_t dcd_conv3x3_weights_bytes(int Cin, int Cout, int backward_data)
+{
+    return Cin > 0 && Cout > 0 ? tw_floats(Cin, Cout, backward_data) * sizeof(float) : 0;
+}
+
+int dcd_conv3x3_transform_weights(void *stream_, const float *weight, int Cin, int Cout, float *forward_out, float *backward_out)
+{
+    (void)hipGetLastError();
+    if (!weight || Cin <= 0 || Cout <= 0 || (!forward_out && !backward_out)) return DCD_ERR_BAD_ARG;
+    PrepBoth p;
+    int nmax = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        const int Cc = mode ? Cout : Cin, Kk = mode ? Cin : Cout;
+        p.ul[mode] = mode ? backward_out : forward_out;
+        p.Cc[mode] = Cc;
+        p.Kk[mode] = Kk;
+        p.ks[mode] = Kk <= 32 ? 32 : 64;
+        p.nchunk[mode] = (Cc + WN_CH - 1) / WN_CH;
+        p.nz[mode] = (Kk + p.ks[mode] - 1) / p.ks[mode];
+        const int n = p.nz[mode] * p.nchunk[mode] * p.ks[mode] * WN_CH;
+        if (p.ul[mode] && n > nmax) nmax = n;
+    }
+    const int nb = (nmax + 255) / 256 < 4096 ? (nmax + 255) / 256 : 4096;
+    hipLaunchKernelGGL(wino_prep_weights_both, dim3(nb, 2), dim3(256), 0, (hipStream_t)stream_, weight, p);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3_prepared(void *stream_, const float *input, const float *transformed, const float *bias, const float *residual,
+                         float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                         size_t workspace_bytes)
+{
+    return conv3x3_run((hipStream_t)stream_, input, transformed, 1, bias, residual, output, B, Cin, H, W, Cout, backward_data, workspace,
+                       workspace_bytes);
 }
 
 static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int &ncg, int &S, int &strips_x, int &KO)

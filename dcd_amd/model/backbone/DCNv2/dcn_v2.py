@@ -95,7 +95,8 @@ class _DCNWithOffsets(Function):
     def forward(ctx, input, w_off, b_off, weight, bias, geometry):
         from dcd_amd import ops
         input, w_off, weight = input.contiguous(), w_off.contiguous(), weight.contiguous()
-        out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous())
+        tw, ctx.tw_back = (ops.conv3x3_transform_weights(w_off) if ops._PREP_BOTH and ctx.needs_input_grad[0] else (None, None))
+        out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous(), transformed=tw)
         offset, mask = _offset_mask_split(out)
         ctx.geometry = geometry
         ctx.save_for_backward(input, offset, mask, weight, bias, w_off)
@@ -110,7 +111,7 @@ class _DCNWithOffsets(Function):
             input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry)
         gout = _offset_mask_merge(grad_offset, grad_mask, mask)
         if ctx.needs_input_grad[0]:
-            grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous())
+            grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous(), transformed=ctx.tw_back)
         gw_off = ops._conv3x3_wrw_call(input, gout, w_off.shape) if ctx.needs_input_grad[1] else None
         gb_off = ops.channel_sums(gout) if ctx.needs_input_grad[2] else None
         return grad_input, gw_off, gb_off, grad_weight, grad_bias, None

@@ -559,8 +559,20 @@ def conv3x3_supported(x, weight):
             and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
 
 
-def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None):
-    """residual: a tensor of the output's shape that the result is added to IN PLACE (and returned)."""
+def conv3x3_transform_weights(weight, forward=True, backward=True):
+    """Winograd-domain weights of a (Cout, Cin, 3, 3) filter for the forward and / or the backward-data call, ONE launch."""
+    L = _lib.lib()
+    Co, Ci = weight.shape[0], weight.shape[1]
+    tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device) if forward else None
+    tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device) if backward else None
+    _lib.check(L.dcd_conv3x3_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
+               "dcd_conv3x3_transform_weights")
+    return tf, tb
+
+
+def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None, transformed=None):
+    """residual: a tensor of the output's shape that the result is added to IN PLACE (and returned).
+    transformed: this direction's weights from conv3x3_transform_weights (else they are transformed inside the call)."""
     L = _lib.lib()
     B, _, H, W = inp.shape
     Co, Ci = weight.shape[0], weight.shape[1]
@@ -571,6 +583,13 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
     else:
         out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
     n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
+    if transformed is not None:
+        n = max(n - min(L.dcd_conv3x3_weights_bytes(Ci, Co, 0), L.dcd_conv3x3_weights_bytes(Ci, Co, 1)), 0)   # partial images only (upper bound)
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=inp.device)
+        st = L.dcd_conv3x3_prepared(_lib.stream_of(inp), inp.data_ptr(), transformed.data_ptr(), _lib.ptr(bias), _lib.ptr(residual),
+                                    out.data_ptr(), B, Ci, H, W, Co, 1 if backward_data else 0, ws.data_ptr(), n)
+        _lib.check(st, "dcd_conv3x3_prepared")
+        return out
     ws = torch.empty(n, dtype=torch.uint8, device=inp.device)
     st = L.dcd_conv3x3(_lib.stream_of(inp), inp.data_ptr(), weight.data_ptr(), _lib.ptr(bias), _lib.ptr(residual), out.data_ptr(),
                        B, Ci, H, W, Co,
@@ -579,6 +598,7 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
     return out
 
 
+_PREP_BOTH = os.environ.get("DCD_CONV_PREP_BOTH", "1") != "0"      # 0: every call transforms its own weights (A/B timing)
 _WRW_ENABLED = os.environ.get("DCD_CONV_WRW", "1") != "0"        # 0: weight gradient on the stock op (A/B timing)
 
 
@@ -604,6 +624,11 @@ class _Conv3x3(torch.autograd.Function):
         _lib.require_cuda(x, weight)
         x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
+        ctx.tw_back = None
+        if _PREP_BOTH and ctx.needs_input_grad[0]:
+            # the weights of this call and of its backward-data call in one launch (they do not change in between)
+            tw, ctx.tw_back = conv3x3_transform_weights(weight)
+            return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw)
         return _conv3x3_call(x, weight, weight.shape[0], False)
 
     @staticmethod
@@ -613,7 +638,7 @@ class _Conv3x3(torch.autograd.Function):
         gy = _f32c(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv3x3_call(gy, weight, weight.shape[1], True)
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True, transformed=ctx.tw_back)
         if ctx.needs_input_grad[1]:
             if _WRW_ENABLED:
                 gw = _conv3x3_wrw_call(x, gy, weight.shape)

@@ -292,6 +292,18 @@ size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int dcd_conv3x3(void *stream, const float *input, const float *weight, const float *bias, const float *residual, float *output,
                 int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace, size_t workspace_bytes);
 
+/* The same convolution with its Winograd-domain weights prepared ahead: dcd_conv3x3 transforms the weights on every call (one
+ * small launch); a training step can prepare both directions in ONE launch during the forward call and hand the backward-data
+ * call its weights (they do not change in between).  transform_weights writes dcd_conv3x3_weights_bytes(Cin, Cout, direction)
+ * bytes per requested direction (either output may be NULL); dcd_conv3x3_prepared is dcd_conv3x3 with `transformed` (the
+ * buffer of ITS direction) in place of `weight`; its workspace (dcd_conv3x3_workspace_bytes, may then be smaller) only holds the
+ * partial images of a split contraction. */
+size_t dcd_conv3x3_weights_bytes(int Cin, int Cout, int backward_data);
+int dcd_conv3x3_transform_weights(void *stream, const float *weight, int Cin, int Cout, float *forward_out, float *backward_out);
+int dcd_conv3x3_prepared(void *stream, const float *input, const float *transformed, const float *bias, const float *residual,
+                         float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                         size_t workspace_bytes);
+
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).

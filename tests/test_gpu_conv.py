@@ -62,6 +62,21 @@ def test_conv3x3_region_shapes(cuda, monkeypatch, geom, B, C, K, H, W):
     _close(gx.cpu(), xd.grad, "grad_input")
 
 
+def test_conv3x3_prepared_weights_equal_per_call_transform(cuda):
+    """dcd_conv3x3_transform_weights (both directions, one launch) + dcd_conv3x3_prepared against dcd_conv3x3: bitwise equal."""
+    from dcd_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(11)
+    for B, C, K, H, W in ((2, 64, 96, 24, 80), (1, 128, 27, 12, 40), (1, 256, 64, 8, 32)):
+        x = torch.randn(B, C, H, W, device=cuda, generator=g)
+        w = torch.randn(K, C, 3, 3, device=cuda, generator=g) / (C * 9) ** 0.5
+        gy = torch.randn(B, K, H, W, device=cuda, generator=g)
+        tf, tb = ops.conv3x3_transform_weights(w)
+        assert torch.equal(ops._conv3x3_call(x, w, K, False, transformed=tf), ops._conv3x3_call(x, w, K, False))
+        assert torch.equal(ops._conv3x3_call(gy, w, C, True, transformed=tb), ops._conv3x3_call(gy, w, C, True))
+        only_b = ops.conv3x3_transform_weights(w, forward=False)[1]
+        assert torch.equal(only_b, tb)
+
+
 def test_conv_module_dispatch(cuda):
     from dcd_amd.model.layers.conv import Conv2d
     conv = Conv2d(64, 64, 3, padding=1, bias=False).to(cuda)
