@@ -837,8 +837,11 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
 // window as wide as the offsets NEAR a cell require instead of as wide as the call's largest offset (learned offset fields
 // are smooth: the local bound is typically 1-2 px where the global one is 3-8, and the search costs (2R+1)^2 reads).
 // grid = (blocks_x * blocks_y, S, B), one wave per block.
-__global__ __launch_bounds__(64) void dcn_offset_blockmax(const float *__restrict__ off, Geom g, unsigned char *__restrict__ blockmax)
+__global__ __launch_bounds__(64) void dcn_offset_blockmax(const float *__restrict__ off, Geom g, unsigned char *__restrict__ blockmax,
+                                                          const unsigned *__restrict__ only_if_far = nullptr)
 {
+    // one-pass backward (dcn_bwd_sweep.inc): the inverse lists are needed only when the generic kernels take over the call
+    if (only_if_far && !far_dominated(only_if_far, g.B * ((g.HoWo + 31) / 32))) return;
     const int nbx = (g.Wo + 7) >> 3, nby = (g.Ho + 7) >> 3;
     const int blk = blockIdx.x, seg = blockIdx.y, b = blockIdx.z;
     const int by = blk / nbx, bx = blk - by * nbx;
@@ -858,8 +861,9 @@ __global__ __launch_bounds__(64) void dcn_offset_blockmax(const float *__restric
 
 // one thread per (input cell q, tap segment, image)
 __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict__ off, const float *__restrict__ msk,
-                                                         InvLists inv, Geom g)
+                                                         InvLists inv, Geom g, const unsigned *__restrict__ only_if_far = nullptr)
 {
+    if (only_if_far && !far_dominated(only_if_far, g.B * ((g.HoWo + 31) / 32))) return;
     const int HW = g.H * g.W;
     const int q = blockIdx.x * 256 + threadIdx.x;
     if (q >= HW) return;
@@ -924,8 +928,10 @@ __global__ __launch_bounds__(256) void dcn_build_inverse(const float *__restrict
 // grid = (ceil(in_tiles/4), B, ceil(total_channel_blocks/MB)); lane = (input cell l&31, output-channel parity l>>5)
 template <int MB>
 __global__ __launch_bounds__(256) void dcn_bwd_input_f32(const float *__restrict__ gy, const float *__restrict__ wb,
-                                                         InvLists inv, float *__restrict__ gin, Geom g, int partner_of_tiled = 0)
+                                                         InvLists inv, float *__restrict__ gin, Geom g, int partner_of_tiled = 0,
+                                                         const unsigned *__restrict__ only_if_far = nullptr)
 {
+    if (only_if_far && !far_dominated(only_if_far, g.B * ((g.HoWo + 31) / 32))) return;
     // launched next to the tiled kernel: each 4 x 32 cell tile is done by exactly one of the two, decided by the flag
     // dcn_build_inverse set for it (or, without the table, by the call-wide radius)
     if (partner_of_tiled && !inv.tileflag && inv_radius(inv.absmax_bits) <= INV_RTILE) return;
@@ -1283,7 +1289,8 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
                                                         const float *__restrict__ gy, float *__restrict__ gin,
                                                         float *__restrict__ goff, float *__restrict__ gmsk,
                                                         float *__restrict__ gbias, Geom g, int nsplit, InvLists inv,
-                                                        const unsigned *__restrict__ far_scal, const int *__restrict__ far_list)
+                                                        const unsigned *__restrict__ far_scal, const int *__restrict__ far_list,
+                                                        int no_lists = 0)
 {
     const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
     const int p = lane & 31, h = lane >> 5;
@@ -1342,7 +1349,9 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
             float s_m = 0.f, s_h = 0.f, s_w = 0.f;
             // grad_input normally comes from dcn_bwd_input_f32; this kernel scatters only what the inverse lists do
             // not cover: samples farther than the search radius, and corners that fell into an overflowed cell.
-            const bool far = !(fabsf(s.oh) <= rlim && fabsf(s.ow) <= rlim);
+            // no_lists (one-pass backward, dcn_bwd_sweep.inc): in far-only mode there are no inverse lists at all, every sample
+            // this launch owns scatters its grad_input here
+            const bool far = (far_mode && no_lists) || !(fabsf(s.oh) <= rlim && fabsf(s.ow) <= rlim);
             const bool mine = !far_mode || !(fabsf(s.oh) < TL_NEAR && fabsf(s.ow) < TL_NEAR);   // sample owned by this launch
             if (far_mode && !__any(mine)) continue;
             const unsigned char *cnt_p = inv.cnt + ((size_t)b * S_all + seg) * HW;
@@ -2059,13 +2068,13 @@ __global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict_
 
 // One launch instead of up to six hipMemsetAsync calls (each is its own ~5 us kernel on the stream).
 struct ZeroRanges {
-    unsigned *p[7];
-    unsigned n[7];        // dwords
+    unsigned *p[8];
+    unsigned n[8];        // dwords
 };
 __global__ void dcn_zero_ranges(ZeroRanges z)
 {
 #pragma unroll
-    for (int r = 0; r < 7; ++r) {
+    for (int r = 0; r < 8; ++r) {
         unsigned *p = z.p[r];
         const unsigned n = z.n[r];
         for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
@@ -2083,6 +2092,7 @@ inline int pick_mb(int nb, int tiles_total)
 }
 
 #include "dcn_v2_bf16x3.inc"
+#include "dcn_bwd_sweep.inc"
 
 }  // namespace
 
@@ -2182,8 +2192,9 @@ size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh
 {
     Geom g;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return 0;
-    // dense path (dcn_dense.inc): [column buffer | split-K partials] after the lists
-    return base_workspace_bytes(g) + dense_workspace_bytes(g);
+    // dense path (dcn_dense.inc): [column buffer | split-K partials] after the lists; then the one-pass backward's
+    // [prepared weights | grad_offset / grad_mask partial planes | grad_weight partials] (dcn_bwd_sweep.inc)
+    return base_workspace_bytes(g) + dense_workspace_bytes(g) + sweep_workspace_bytes(g);
 }
 
 int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, const float *bias,
@@ -2363,9 +2374,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     inv.flag_ty = (H + 3) / 4;
     const dim3 bm_grid(((g.Ho + 7) / 8) * ((g.Wo + 7) / 8), dg * g.KK, B);
 
-    if (dense_ok(g, true)) {
+    const bool use_sweep = sweep_ok(g) && g.Cop == 64 && (sweep_mode() == 2 || !dense_ok(g, true));
+    if (!use_sweep && dense_ok(g, true)) {
         ZeroRanges z;
-        for (int r = 0; r < 7; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
@@ -2391,6 +2403,99 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 
     const int tiles = (g.HoWo + 31) / 32;
     const int nblk = g.cpgp / 32;
+    if (use_sweep) {
+        // ---- one-pass backward (dcn_bwd_sweep.inc).  Near samples: dcn_bwd_sweep_f32 + its two reductions.  Far samples
+        // (>= TL_NEAR px): the generic kernels' far-only pass over the listed tiles, grad_input by atomics.  Far samples
+        // dominating the call (device-side decision): the sweep returns at once, the inverse lists are built after all and the
+        // generic kernels do everything, as in the three-pass path.
+        const SweepPlan sp = sweep_plan(g);
+        float *swp = (float *)((char *)workspace + base_workspace_bytes(g) + dense_workspace_bytes(g));
+        float *cpart = swp + sp.wp_floats, *dwpart = cpart + sp.cpart_floats;
+        const unsigned *fs = (const unsigned *)absmax;
+        int nsplit = 1;
+        while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
+        {
+            ZeroRanges z;
+            for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+            z.p[0] = absmax; z.n[0] = 4;
+            z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
+            z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
+            z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
+            z.p[4] = (unsigned *)grad_input; z.n[4] = (unsigned)((size_t)B * Cin * H * W);
+            hipLaunchKernelGGL(dcn_zero_ranges, dim3((unsigned)(z.n[4] / 1024 + 1 < 4096 ? z.n[4] / 1024 + 1 : 4096)), dim3(256), 0, stream, z);
+        }
+        hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g, sp.nck);
+        {
+            const int64_t noff = (int64_t)B * 18 * g.HoWo;
+            int gsz = (int)((noff + 4095) / 4096);
+            if (gsz > 512) gsz = 512;
+            hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, 18, (g.HoWo + 31) / 32,
+                               far_flag, far_list);
+        }
+        {
+            SweepArgs a;
+            a.in = input; a.off = offset; a.msk = mask; a.wp = swp; a.gy = grad_output; a.gin = grad_input; a.cpart = cpart;
+            a.dwpart = dwpart; a.far_scal = fs; a.g = g; a.nstrip = sp.nstrip; a.nseg = sp.nseg; a.seg_rows = sp.seg_rows;
+            a.nck = sp.nck; a.nv = sp.nv;
+            const int ngrp = (sp.nv + 7) / 8;
+            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3(ngrp * 8 * sp.nck), dim3(64), 0, stream, a);
+        }
+        {
+            int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+            hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
+        }
+        {
+            const int64_t n4 = (int64_t)B * 27 * g.HoWo / 4;
+            hipLaunchKernelGGL(dcn_sweep_reduce_coord, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, stream,
+                               cpart, grad_offset, grad_mask, B, g.HoWo, sp.nck, fs, B * tiles);
+            const int nred = sp.nck * SW_DW_FLOATS;
+            const int rg = sp.nv >= 64 ? 16 : (sp.nv >= 8 ? 4 : 1);
+            hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, g, sp.nck, sp.nv,
+                               fs, B * tiles);
+        }
+        // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
+        inv.packed = 0;
+        inv.tileflag = nullptr;
+        hipLaunchKernelGGL(dcn_offset_blockmax, bm_grid, dim3(64), 0, stream, offset, g, blockmax, fs);
+        hipLaunchKernelGGL(dcn_build_inverse, dim3((H * W + 255) / 256, 9, B), dim3(256), 0, stream, offset, mask, inv, g, fs);
+        {
+            const int in_tiles = (H * W + 31) / 32;
+            int mbi = nblk >= 8 ? 8 : nblk >= 4 ? 4 : nblk >= 2 ? 2 : 1;
+            while (mbi > 1 && (int64_t)in_tiles * B * ((nblk + mbi - 1) / mbi) < 1024) mbi >>= 1;
+            dim3 grid((in_tiles + 3) / 4, B, (nblk + mbi - 1) / mbi), block(256);
+            if (mbi == 8) hipLaunchKernelGGL(dcn_bwd_input_f32<8>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, 0, fs);
+            else if (mbi == 4) hipLaunchKernelGGL(dcn_bwd_input_f32<4>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, 0, fs);
+            else if (mbi == 2) hipLaunchKernelGGL(dcn_bwd_input_f32<2>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, 0, fs);
+            else hipLaunchKernelGGL(dcn_bwd_input_f32<1>, grid, block, 0, stream, grad_output, wb, inv, grad_input, g, 0, fs);
+        }
+        {
+            dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
+            // g.Cop == 64 here
+            hipLaunchKernelGGL(dcn_bwd_data_f32<32>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
+                               grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
+        }
+        {
+            const int RB = 9 * nblk;
+            const int nb = g.Cop / 32;
+            const int mb = nb >= 2 ? 2 : 1;
+            const int gx = (RB + 3) / 4, gz = (nb + mb - 1) / mb;
+            const int total = B * tiles;
+            int S = 512 / (gx * gz);
+            if (S < 1) S = 1;
+            if (S > total) S = total;
+            dim3 grid(gx, S, gz), block(256);
+            const size_t lds = (size_t)(4 * 32 * 33 + mb * 32 * 33) * sizeof(float);
+            if (mb == 2)
+                hipLaunchKernelGGL(dcn_bwd_weight_f32<2>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, tiles, S,
+                                   fs, (const int *)far_list);
+            else
+                hipLaunchKernelGGL(dcn_bwd_weight_f32<1>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, tiles, S,
+                                   fs, (const int *)far_list);
+        }
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     // split the channel blocks over grid.z when there are too few pixel tiles to fill the chip
     int nsplit = 1;
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
@@ -2407,7 +2512,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     const bool bd_tile_ok = tile_shape && (g.Cop == 64 || (g.Cop == 128 && bd128));
     {
         ZeroRanges z;
-        for (int r = 0; r < 7; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
+        for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;                         // max |offset| bits, far-tile count, overflowed-list count
         z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
         z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);

@@ -216,16 +216,48 @@ def test_convergent_offsets_overflow_and_far_fallback(cuda, oracle_dcn):
         close(g_, r_, 5e-5, "convergent " + name)
 
 
-def test_backward_is_deterministic_without_fallback(cuda):
-    """With offsets inside the search radius nothing is scattered atomically: grad_input is bit-reproducible
-    (the reference's col2im is not)."""
+def test_backward_is_deterministic_without_fallback(cuda, monkeypatch):
+    """Three-pass backward (inverse lists): with offsets inside the search radius nothing is scattered atomically, so
+    grad_input is bit-reproducible (the reference's col2im is not)."""
     from dcd_amd import _ext
+    monkeypatch.setenv("DCD_BWD_SWEEP", "0")
     x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 64, 64, 24, 40, off_scale=0.25, seed=5))
     off.clamp_(-0.9, 0.9)      # |offset| < 1 px: a cell collects at most 9 samples of one tap <= list capacity 10
     a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
     g1 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)[0]
     g2 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)[0]
     assert torch.equal(g1, g2)
+
+
+def test_one_pass_backward_reproducibility(cuda):
+    """One-pass backward (dcn_bwd_sweep.inc, round 3): grad_offset / grad_mask are sums of per-chunk planes in a fixed order
+    -> bit-reproducible; grad_input leaves the LDS windows through global atomics where strips overlap, like the reference's
+    col2im (cuda/dcn_v2_im2col_cuda.cu:249) -> reproducible to summation-order noise only."""
+    from dcd_amd import _ext
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 64, 64, 24, 40, off_scale=0.25, seed=5))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    r1 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    r2 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    assert torch.equal(r1[1], r2[1]) and torch.equal(r1[2], r2[2])
+    close(r1[0], r2[0], 2e-6, "grad_input run to run")
+    close(r1[3], r2[3], 2e-6, "grad_weight run to run")
+
+
+def test_one_pass_backward_equals_three_pass(cuda, monkeypatch):
+    """Same call through both backward paths (A/B switch DCD_BWD_SWEEP), incl. a ragged channel count, a partial strip,
+    offsets that make quarter collisions (jumps of >= 2 px over 4 px) and some far samples."""
+    from dcd_amd import _ext
+    for (B, C, Co, H, W, osc, seed) in ((2, 64, 64, 24, 64, 0.5, 11), (1, 40, 50, 19, 44, 1.2, 12), (1, 128, 64, 16, 48, 2.0, 13)):
+        x, w, b, off, m, gy = (t.to(cuda) for t in make_case(B, C, Co, H, W, off_scale=osc, seed=seed))
+        off[:, :, :, 1::4] += 1.4          # neighbouring pixel groups pushed towards each other
+        off[:, :, :, 3::4] -= 1.4
+        a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+        monkeypatch.setenv("DCD_BWD_SWEEP", "1")
+        one = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+        monkeypatch.setenv("DCD_BWD_SWEEP", "0")
+        three = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+        for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), one, three):
+            close(g_, r_, 2e-5, "one-pass vs three-pass %s %s" % (name, (B, C, Co, H, W)))
 
 
 # the seven distinct DCN geometries of DLA-34 at 384x1280 (bench.py::DCN_LAYERS; SURVEY.md section 8 a1), at the BASELINE batch
