@@ -2374,7 +2374,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     inv.flag_ty = (H + 3) / 4;
     const dim3 bm_grid(((g.Ho + 7) / 8) * ((g.Wo + 7) / 8), dg * g.KK, B);
 
-    const bool use_sweep = sweep_ok(g) && g.Cop == 64 && (sweep_mode() == 2 || !dense_ok(g, true));
+    // one-pass backward wherever it applies (Cout <= 64), the dense path included: 256->64 @ 24x80 0.36 vs 0.50 ms.
+    // DCD_BWD_SWEEP=2 keeps the dense path for the layers it takes (A/B)
+    const bool use_sweep = sweep_ok(g) && g.Cop <= 64 && dense_mode() != 1 && (sweep_mode() == 1 || !dense_ok(g, true));
     if (!use_sweep && dense_ok(g, true)) {
         ZeroRanges z;
         for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
@@ -2438,7 +2440,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             a.dwpart = dwpart; a.far_scal = fs; a.g = g; a.nstrip = sp.nstrip; a.nseg = sp.nseg; a.seg_rows = sp.seg_rows;
             a.nck = sp.nck; a.nv = sp.nv;
             const int ngrp = (sp.nv + 7) / 8;
-            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3(ngrp * 8 * sp.nck), dim3(64), 0, stream, a);
+            static LdsLimit sw_lds_limit;
+            const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
+            if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep_f32)) return DCD_ERR_LAUNCH;
+            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3((ngrp * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), ldsb, stream, a);
         }
         {
             int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
@@ -2472,9 +2477,12 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         }
         {
             dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
-            // g.Cop == 64 here
-            hipLaunchKernelGGL(dcn_bwd_data_f32<32>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
-                               grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
+            if (g.Cop == 64)
+                hipLaunchKernelGGL(dcn_bwd_data_f32<32>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
+                                   grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
+            else
+                hipLaunchKernelGGL(dcn_bwd_data_f32<16>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
+                                   grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
         }
         {
             const int RB = 9 * nblk;
@@ -2689,6 +2697,13 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
+
+#ifdef SW_PROFILE
+int dcd_debug_sweep_profile(unsigned long long *host_out)
+{
+    return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sw_prof_buf), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : 1;
+}
+#endif
 
 int dcd_dcn_offset_mask_split(void *stream_, const float *out, float *offset, float *mask, int B, int taps, int64_t HW)
 {

@@ -194,12 +194,16 @@ def test_boundary_samples(cuda, oracle_dcn):
         close(g_, r_, 5e-5, "boundary " + name)
 
 
-def test_convergent_offsets_overflow_and_far_fallback(cuda, oracle_dcn):
-    """grad_input comes from inverse sample lists (capacity 10 per cell and tap, radius <= 3 px) with an atomic fallback.
-    Offsets that make every pixel of a 4x4 block sample the SAME location overflow the lists; offsets of 4..7 px are
-    'far'.  Both fallbacks and their mix with the list path must reproduce the oracle."""
+@pytest.mark.parametrize("W,sweep", [(20, "1"), (48, "1"), (48, "0")])
+def test_convergent_offsets_overflow_and_far_fallback(cuda, oracle_dcn, monkeypatch, W, sweep):
+    """Three-pass backward: grad_input comes from inverse sample lists (capacity 10 per cell and tap, radius <= 3 px) with an
+    atomic fallback.  Offsets that make every pixel of a 4x4 block sample the SAME location overflow the lists; offsets of
+    4..7 px are 'far'.  Both fallbacks and their mix with the list path must reproduce the oracle.
+    One-pass backward (W = 48): the same offsets make the four quarters of every pixel step meet in one cell -- every tap goes
+    through the fix-up loop (LDS atomics) -- and the far half through the generic kernels' far-only pass."""
     from dcd_amd import _ext
-    B, C, Co, H, W = 2, 8, 8, 16, 20
+    monkeypatch.setenv("DCD_BWD_SWEEP", sweep)
+    B, C, Co, H = 2, 8, 8, 16
     x, w, b, off, m, gy = make_case(B, C, Co, H, W, seed=11)
     ys = torch.arange(H).view(1, 1, H, 1).float()
     xs = torch.arange(W).view(1, 1, 1, W).float()
@@ -394,6 +398,7 @@ def test_local_search_radius_of_the_inverse_lists(cuda, oracle_dcn, monkeypatch,
     them (7.5 px: the local bound saturates and the call-wide radius is used)."""
     from dcd_amd import _ext
     monkeypatch.setenv("DCD_DCN_DENSE", dense)
+    monkeypatch.setenv("DCD_BWD_SWEEP", "0")               # the inverse lists belong to the three-pass / dense backward
     B, C, Co, H, W = 2, 16, 8, 40, 40
     x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=0.2, seed=13)
     off[:, 1::2, 16:24, 16:24] += jump                     # x offsets of every tap inside the patch
