@@ -6,10 +6,13 @@
       started bare, by bench.py itself (it spawns torch.distributed.run as a child before touching the GPU).
 
 A step = forward + 13-term loss + backward + gradient all-reduce (RCCL, N>1) + grad clip + AdamW, on a synthetic
-KITTI-shaped batch that is resident in HBM before the timed region.  Every rank trains on 8 images (the metric's batch on
-one GPU; BASELINE.json configs[2] is this at N = 4: bs 32 on 4 GPUs), value = all ranks' images / time: "scaling": "weak".
-`--scaling strong` splits ONE batch of 8 over the ranks instead (IMS_PER_BATCH // world, DGDE/data/build.py:63-67: one
-image per rank at N = 8, north_star's wording); DESIGN.md section 6 gives the measured one-image step and what it projects to.
+KITTI-shaped batch that is resident in HBM before the timed region.  The metric's batch is GLOBAL: with N > 1 the 8 images
+are split over the ranks as the reference does (IMS_PER_BATCH // world, DGDE/data/build.py:63-67: one image per rank at
+N = 8, north_star's partition), value = 8 images / max-over-ranks step time, "scaling": "strong" -- the default since
+round 3.  The same run then also times 8 images PER rank (BASELINE.json configs[2] is that at N = 4: bs 32 on 4 GPUs) and
+reports it under the extra key "weak_scaling"; `--scaling weak` makes that the headline instead (metric string says so).
+At <= 2 images per rank the step is launch-bound and is replayed from ONE HIP graph that contains the SyncBN and gradient
+collectives (engine.trainer.GraphedTrainStep(distributed=True)); DCD_STEP_GRAPH=0 keeps the eager DDP step.
 
 One JSON line on rank 0.  Besides the driver's contract it carries
   roofline     -- DCNv2 forward+backward of the 16 DLA-34 DCN layers: GEMM flops (computed from the
@@ -98,7 +101,7 @@ def build_everything(args, device, world, local_rank):
     from dcd_amd import _ext
     from dcd_amd.config import get_cfg
     from dcd_amd.data.synthetic import make_batch
-    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, wrap_distributed
+    from dcd_amd.engine.trainer import build_optimizer, init_like_trained, prepare_data_parallel, wrap_distributed
     from dcd_amd.model.detector import KeypointDetector
 
     _ext.set_precision(args.precision)
@@ -110,11 +113,18 @@ def build_everything(args, device, world, local_rank):
     init_like_trained(model, std=0.01, seed=0)
     model = model.to(device).train()
     optimizer = build_optimizer(model, cfg)
-    model = wrap_distributed(model, cfg, local_rank)
     per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
+    # <= 2 images per rank: launch-bound -> whole-step HIP graph (collectives inside it when data parallel)
+    graph_env = os.environ.get("DCD_STEP_GRAPH")
+    use_graph = graph_env == "1" or (graph_env is None and per_rank <= 2)
+    data_parallel = world > 1 or force_ddp
+    if data_parallel and use_graph:
+        model = prepare_data_parallel(model, cfg)            # bare module: the graphed step reduces the gradients itself
+    else:
+        model = wrap_distributed(model, cfg, local_rank)
     rank = int(os.environ.get("RANK", 0))
     images, targets = make_batch(per_rank, seed=100 + rank, n_objects=args.objects, device=device)
-    return cfg, model, optimizer, images, targets, per_rank
+    return cfg, model, optimizer, images, targets, per_rank, use_graph, data_parallel
 
 
 def run_gpu(args):
@@ -140,23 +150,40 @@ def run_gpu(args):
     # conv kernels.  DCD_MIOPEN_FIND=1 turns the search on (measured in round 1: no gain).
     torch.backends.cudnn.benchmark = os.environ.get("DCD_MIOPEN_FIND", "0") == "1"
 
-    cfg, model, optimizer, images, targets, per_rank = build_everything(args, device, world, local_rank)
+    cfg, model, optimizer, images, targets, per_rank, use_graph, data_parallel = build_everything(args, device, world, local_rank)
     timer = DcnTimer(torch, _ext)
     clip = cfg.SOLVER.GRAD_NORM_CLIP
 
-    # DCD_STEP_GRAPH=1 (one process only): the whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep).
-    # Opt-in: at bs 8 the GPU is the limit either way (52.95 vs 53.1 ms); at one image per GPU it is 21.4 -> 17.7 ms
-    # (tools/check_step_graph.py compares its loss trajectory with eager steps at full size).  The loss section's own graph is
-    # always on.
+    # Whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep) when the step is launch-bound (<= 2 images per
+    # rank; DCD_STEP_GRAPH=1 / 0 forces it on / off).  At bs 8 the GPU is the limit either way (49.7 vs 48.7 ms, round 2), so
+    # the default single-GPU line stays eager.  Data parallel: the graph holds the SyncBN + gradient all-reduces; if capturing
+    # fails on ANY rank all ranks agree (one eager all-reduce) to fall back to the eager DDP step.
     force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
-    use_graph = world == 1 and not force_ddp and os.environ.get("DCD_STEP_GRAPH", "0") == "1"
+    step_launch = "eager"
     if use_graph:
-        from dcd_amd.engine.trainer import GraphedTrainStep
-        graphed = GraphedTrainStep(model, optimizer, clip)
+        from dcd_amd.engine.trainer import GraphedTrainStep, wrap_distributed
+        graphed = GraphedTrainStep(model, optimizer, clip, distributed=data_parallel)
+        ok = True
+        try:
+            graphed(images, targets)                       # captures (after its own eager warm-up steps) and replays once
+            torch.cuda.synchronize()
+        except Exception as e:                             # noqa: BLE001 -- any failure means "use the eager step"
+            sys.stderr.write("[bench] whole-step graph unavailable (%r): eager step\n" % (e,))
+            ok = False
+        if data_parallel:
+            flag = torch.tensor([1 if ok else 0], device=device)
+            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
+            ok = bool(flag.item())
+        if ok:
+            step_launch = "one HIP graph per step" + (" (SyncBN + gradient all-reduce inside)" if data_parallel else "")
 
-        def step():
-            graphed(images, targets)
-    else:
+            def step():
+                graphed(images, targets)
+        else:
+            use_graph = False
+            if data_parallel:
+                model = wrap_distributed(model, cfg, local_rank)
+    if not use_graph:
         def step():
             train_step(model, optimizer, images, targets, clip)
     trace = (lambda m: (sys.stderr.write("[bench] %s\n" % m), sys.stderr.flush())) if os.environ.get("DCD_BENCH_TRACE") else (lambda m: None)
@@ -205,7 +232,7 @@ def run_gpu(args):
     out = None
     if rank == 0:
         out = {
-            "metric": "images/sec DGDE train step (bs=8, 384x1280)", "value": global_batch * args.steps / elapsed,
+            "metric": "images/sec DGDE train step (bs=%d, 384x1280)" % global_batch, "value": global_batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
@@ -213,8 +240,8 @@ def run_gpu(args):
                                    "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
                                        global_batch, "bf16 autocast (MODEL.FP16)" if args.amp else "fp32", world, args.objects),
                        "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
-                       "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": "one HIP graph per step" if use_graph else "eager",
-                       "sync_bn": bool(world > 1)},
+                       "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": step_launch,
+                       "sync_bn": bool(data_parallel)},
             # The fused op has 196 FLOP per algorithmic byte (ridge of the part: 157.3 TF / 8 TB/s = 19.7), so the matrix pipe
             # is the bound that applies; the HBM view north_star also asks for is kept beside it.
             "roofline": {"bound": "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers, batch %d per GPU" % per_rank,
@@ -228,6 +255,28 @@ def run_gpu(args):
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
                              "algorithmic_bytes": by},
         }
+    # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
+    # bucketed all-reduce overlapped with the backward) as an extra key -- what BASELINE.json configs[2] is at N = 4
+    if world > 1 and args.scaling == "strong" and not args.no_weak:
+        from dcd_amd.data.synthetic import make_batch
+        from dcd_amd.engine.trainer import wrap_distributed
+        if not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+            model = wrap_distributed(model, cfg, local_rank)
+        w_images, w_targets = make_batch(args.batch, seed=200 + rank, n_objects=args.objects, device=device)
+        w_steps = max(2, min(args.steps, 5))
+        for _ in range(2):
+            train_step(model, optimizer, w_images, w_targets, clip)
+        fence()
+        t0 = time.perf_counter()
+        for _ in range(w_steps):
+            train_step(model, optimizer, w_images, w_targets, clip)
+        fence()
+        w_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
+        dist.all_reduce(w_el, op=dist.ReduceOp.MAX)
+        if out is not None:
+            out["weak_scaling"] = {"value": args.batch * world * w_steps / float(w_el.item()), "unit": "images/s", "scaling": "weak",
+                                   "global_batch": args.batch * world, "per_gpu_batch": args.batch, "steps": w_steps,
+                                   "ms_per_step": 1e3 * float(w_el.item()) / w_steps, "step_launch": "eager DDP"}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
@@ -494,7 +543,7 @@ def run_dry(args):
         dist.destroy_process_group()
     if rank != 0:
         return None
-    return {"metric": "images/sec DGDE train step (bs=8, 384x1280)", "value": None, "unit": "images/s", "n_gpus": world,
+    return {"metric": "images/sec DGDE train step (bs=%d, 384x1280)" % (per_rank * world), "value": None, "unit": "images/s", "n_gpus": world,
             "steps": args.steps, "warmup": args.warmup, "ms_per_step": 1e3 * elapsed / max(args.steps, 1),
             "higher_is_better": True, "scaling": args.scaling, "vs_baseline": None, "dtype": "f32", "data": "none",
             "dry": True, "config": {"workload": "DRY RUN of the launch path, no GPU work", "global_batch": per_rank * world,
@@ -507,8 +556,11 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=10)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=8, help="global batch (strong) or per-GPU batch (weak)")
-    ap.add_argument("--scaling", choices=("strong", "weak"), default="weak")
+    ap.add_argument("--batch", type=int, default=8, help="global batch (strong, default) or per-GPU batch (weak)")
+    ap.add_argument("--scaling", choices=("strong", "weak"), default="strong",
+                    help="strong (default): --batch is the GLOBAL batch, split over the ranks like DGDE/data/build.py:63-67; "
+                         "weak: --batch images on every rank")
+    ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--objects", type=int, default=6)
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
                     help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")

@@ -231,6 +231,20 @@ def wrap_distributed(model, cfg, local_rank):
     return nn.parallel.DistributedDataParallel(model, **kw)
 
 
+def prepare_data_parallel(model, cfg):
+    """What `wrap_distributed` does to the model itself -- SyncBN, frozen dead projections -- WITHOUT the DistributedDataParallel
+    wrapper: `GraphedTrainStep(..., distributed=True)` all-reduces the gradients itself, as one flat buffer inside the captured
+    step (at one image per rank there is nothing for DDP's bucket overlap to hide behind: the backward is 12 ms, the 85 MB
+    all-reduce < 1.5 ms, and the reducer's hooks are host work the graph exists to remove)."""
+    for m in model.modules():
+        if getattr(m, "dead_project", False):
+            for p in m.project.parameters():
+                p.requires_grad_(False)
+    if cfg.MODEL.USE_SYNC_BN:
+        enable_sync_bn(model)
+    return model
+
+
 _PARAM_LISTS = weakref.WeakKeyDictionary()
 
 
@@ -291,8 +305,8 @@ class GraphedTrainStep:
     Inputs are copied into static buffers before each replay (images, every tensor field of the targets, and the per-image
     intrinsics as a (6,) row: Calibration objects are host data).  Before capturing, `warmup` eager steps run on a side
     stream so that lazily created handles / MIOpen selections exist; model, BN buffers and optimizer state are restored
-    afterwards, so the captured step is the first one that counts.  Single process only: with world size > 1 the SyncBN /
-    gradient collectives would have to be captured too -- `train_step` is used there.  Returned loss tensors are the graph's
+    afterwards, so the captured step is the first one that counts.  Data parallel: `distributed=True` (see __init__) captures the
+    SyncBN and gradient collectives with the kernels; a DDP-wrapped model is not accepted.  Returned loss tensors are the graph's
     static outputs (read them before the next call).
 
     Opt-in (bench.py: DCD_STEP_GRAPH=1).  Checked at 96x320 against eager steps (tests/test_gpu_golden.py, opt-in) and at
@@ -302,9 +316,42 @@ class GraphedTrainStep:
     this stack (profiles/r02_graph_memset_hazard.txt), so the graphed loss uses two-stage sums and our kernels zero-fill with
     kernels (csrc/zero_fill.h)."""
 
-    def __init__(self, model, optimizer, grad_norm_clip=15.0, warmup=2):
+    def __init__(self, model, optimizer, grad_norm_clip=15.0, warmup=2, distributed=False, group=None):
+        """distributed=True (round 3): data parallel INSIDE the graph -- the model is the bare module prepared by
+        `prepare_data_parallel` (SyncBN on), its SyncBN all-reduces and ONE all-reduce of the flat gradient buffer are captured
+        with the kernels (RCCL collectives are stream work like any other; DGDE/tools/plain_train_net.py:54-62 is DDP + SyncBN
+        around the same step).  Every rank must call the step the same number of times."""
         self.model, self.optimizer, self.clip, self.warmup = model, optimizer, grad_norm_clip, warmup
+        self.distributed, self.group = distributed, group
         self._graphs = {}
+        self._flat = None
+        if distributed:
+            if isinstance(model, nn.parallel.DistributedDataParallel):
+                raise ValueError("GraphedTrainStep(distributed=True) takes the bare module (prepare_data_parallel), not a DDP wrapper")
+            params = [p for p in model.parameters() if p.requires_grad]
+            self._dp_params = params
+            self._flat = torch.zeros(sum(p.numel() for p in params), dtype=params[0].dtype, device=params[0].device)
+            views, o = [], 0
+            for p in params:
+                views.append(self._flat[o:o + p.numel()].view_as(p))
+                o += p.numel()
+            self._dp_views = views
+            import torch.distributed as dist
+            self._world = dist.get_world_size(group)
+
+    def _reduce_gradients(self):
+        """grads -> flat buffer (multi-tensor copy), ONE all-reduce, mean; the parameters' .grad then ARE the flat views, so the
+        clip and the fused AdamW read the reduced values.  A parameter without a gradient in this step contributes zeros."""
+        import torch.distributed as dist
+        have = [(v, p.grad) for v, p in zip(self._dp_views, self._dp_params) if p.grad is not None]
+        if len(have) != len(self._dp_params):
+            self._flat.zero_()
+        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        dist.all_reduce(self._flat, group=self.group)
+        if self._world > 1:
+            self._flat.mul_(1.0 / self._world)
+        for v, p in zip(self._dp_views, self._dp_params):
+            p.grad = v
 
     @staticmethod
     def _calib_row(c):
@@ -361,6 +408,8 @@ class GraphedTrainStep:
         if total is None:
             total = sum(loss_dict.values())
         total.backward()
+        if self.distributed:
+            self._reduce_gradients()
         if self.clip and self.clip > 0:
             guard_nonfinite_step(self.optimizer, clip_grad_norm(_parameters_of(self.model), self.clip))
         self.optimizer.step()
@@ -379,8 +428,8 @@ class GraphedTrainStep:
         side = torch.cuda.Stream()
         side.wait_stream(torch.cuda.current_stream())
         with torch.cuda.stream(side):
-            for _ in range(max(self.warmup, 1)):          # >= 1: the optimizer's state tensors must exist before the capture
-                self._eager(st_images, st_targets)
+            for _ in range(max(self.warmup, 3 if self.distributed else 1)):     # >= 1: the optimizer's state tensors must exist before the
+                self._eager(st_images, st_targets)                                # capture; collectives: communicators set up eagerly first
         torch.cuda.current_stream().wait_stream(side)
         self.model.load_state_dict(model_state)            # in place: parameters and BN buffers keep their storage
         with torch.no_grad():
@@ -391,7 +440,17 @@ class GraphedTrainStep:
                         v.copy_(old[k]) if old is not None and k in old else v.zero_()
         self.optimizer.zero_grad(set_to_none=True)
         graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
+        if self.distributed:
+            # the process group's watchdog thread polls the events of the warm-up collectives; in the default (global) capture
+            # mode such a query from ANOTHER thread aborts the capture ("operation not permitted when stream is capturing",
+            # seen 1 run in 3) -> let the queue drain and restrict the capture checks to this thread
+            import time
+            torch.cuda.synchronize()
+            time.sleep(0.2)
+            ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")
+        else:
+            ctx = torch.cuda.graph(graph)
+        with ctx:
             loss_dict, log = self._eager(st_images, st_targets)
         entry["graph"], entry["out"] = graph, (loss_dict, log)
         return entry

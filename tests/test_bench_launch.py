@@ -24,11 +24,12 @@ def _env():
 
 def test_bare_invocation_spawns_its_own_ranks():
     res = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "3", "--warmup", "1", "--dry",
-                          "--scaling", "strong"], capture_output=True, text=True, timeout=300, env=_env())
+                          "--scaling", "weak"], capture_output=True, text=True, timeout=300, env=_env())
     assert res.returncode == 0, res.stderr[-2000:]
     out = _one_json_line(res.stdout)
     assert out["n_gpus"] == 2 and out["steps"] == 3 and out["warmup"] == 1 and out["dry"] is True
-    assert out["config"]["per_gpu_batch"] == 4 and out["config"]["global_batch"] == 8 and out["scaling"] == "strong"
+    # opt-in: every rank keeps 8 images (BASELINE config 3 = 4 x 8) -> weak scaling, whole-job value
+    assert out["config"]["per_gpu_batch"] == 8 and out["config"]["global_batch"] == 16 and out["scaling"] == "weak"
 
 
 def test_under_the_drivers_launcher():
@@ -40,9 +41,10 @@ def test_under_the_drivers_launcher():
     res = subprocess.run(cmd, capture_output=True, text=True, timeout=300, env=_env())
     assert res.returncode == 0, res.stderr[-2000:]
     out = _one_json_line(res.stdout)
-    # default: every rank keeps the metric's 8 images (BASELINE config 3 = 4 x 8) -> weak scaling, whole-job value
-    assert out["n_gpus"] == 2 and out["scaling"] == "weak"
-    assert out["config"]["per_gpu_batch"] == 8 and out["config"]["global_batch"] == 16
+    # default since round 3: north_star's partition -- the metric's GLOBAL batch of 8 split over the ranks
+    # (DGDE/data/build.py:63-67) -> strong scaling
+    assert out["n_gpus"] == 2 and out["scaling"] == "strong"
+    assert out["config"]["per_gpu_batch"] == 4 and out["config"]["global_batch"] == 8
 
 
 def test_single_rank_dry():

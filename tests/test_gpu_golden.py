@@ -288,10 +288,12 @@ def test_model_fp16_flag_trains_in_bf16_autocast(cuda):
     assert abs(sum(l16.values()) - sum(l32.values())) <= 0.03 * sum(l32.values())
 
 
-@pytest.mark.skipif(__import__("os").environ.get("DCD_TEST_STEP_GRAPH") != "1",
-                    reason="GraphedTrainStep is experimental on this ROCm stack (memset nodes in HIP graphs); DCD_TEST_STEP_GRAPH=1 runs it")
-def test_graphed_train_step_equals_eager(cuda):
+@pytest.mark.parametrize("data_parallel", [False, True])
+def test_graphed_train_step_equals_eager(cuda, data_parallel):
     """The whole step replayed from one HIP graph (engine.trainer.GraphedTrainStep) against the eager `train_step`.
+    data_parallel: the graph also holds the SyncBN all-reduces and the flat gradient all-reduce (RCCL, a one-rank group here:
+    the mechanics of capturing collectives; the eager reference runs the same SyncBN code, and with one rank its
+    unreduced gradients are the reduced ones).
     AdamW's first updates are +-lr whatever the gradient's size, so round-off in a near-zero gradient flips whole updates and
     two runs of the SAME eager code drift apart after one step; the comparison therefore holds the weights fixed (lr = 0:
     AdamW's decay is lr-scaled too) over three steps on three DIFFERENT batches -- the graph is captured on the first and must
@@ -308,12 +310,27 @@ def test_graphed_train_step_equals_eager(cuda):
     batches[1][1][0].get_field("calib").f_u *= 1.01            # other intrinsics in the second batch
     lrs = (0.0, 0.0, 0.0, 3e-4)
     runs = []
+    if data_parallel:
+        import socket
+        import torch.distributed as dist
+        from dcd_amd.engine.trainer import prepare_data_parallel
+        with socket.socket() as s_:
+            s_.bind(("127.0.0.1", 0))
+            port = s_.getsockname()[1]
+        dist.init_process_group("nccl", init_method="tcp://127.0.0.1:%d" % port, rank=0, world_size=1, device_id=cuda)
+        request_cleanup = dist.destroy_process_group
+    else:
+        request_cleanup = lambda: None
     for graphed in (False, True):
         torch.manual_seed(0)
         model = KeypointDetector(cfg).to(cuda).train()
         init_like_trained(model)
         opt = build_optimizer(model, cfg)
-        step = GraphedTrainStep(model, opt, cfg.SOLVER.GRAD_NORM_CLIP) if graphed else None
+        if data_parallel:                                   # both runs: SyncBN kernels + frozen dead projections; only the graphed one reduces
+            cfg_dp = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "MODEL.USE_SYNC_BN", True,
+                                   "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+            prepare_data_parallel(model, cfg_dp)
+        step = GraphedTrainStep(model, opt, cfg.SOLVER.GRAD_NORM_CLIP, distributed=data_parallel) if graphed else None
         trace = []
         for (images, targets), lr in zip(batches, lrs):
             for g_ in opt.param_groups:
@@ -325,6 +342,7 @@ def test_graphed_train_step_equals_eager(cuda):
                           [p.detach().clone() for p in model.parameters()],
                           [opt.state[p]["exp_avg"].clone() for p in model.parameters() if p in opt.state]))
         runs.append(trace)
+    request_cleanup()
     eager, graph = runs
     # Forward quantities are bit-stable run to run; gradients are not (fp32 atomics in the backward of DCN / BN-at-positions /
     # scatter-adds, amplified by the cancellation inside grad_offset on the deep layers: two runs of the SAME eager step differ
@@ -332,9 +350,14 @@ def test_graphed_train_step_equals_eager(cuda):
     # whole-model fixture test.
     def norms(ts):
         return [None if t is None else float(t.double().norm()) for t in ts]
+    # Two losses sit behind the edge solver's top-1500 selection (DGDE/model/anno_encoder.py:355-377: pairs with the largest |dv|):
+    # a near-tie at the 1500th pair flips with the 1e-7 noise of the forward (fp32 atomics in BN-at-positions / scatter-adds) and
+    # moves them by a few 1e-4 -- seen between two runs of the SAME eager code (tools/scratch/dp_graph_check.py: corner_loss
+    # 0.200333 in five runs, 0.200249 in the sixth; every other loss unchanged).  Those two get the wider bar.
+    behind_topk = ("corner_loss", "extra_kpts_depth_loss")
     for i, ((l0, g0, b0, w0, m0), (l1, g1, b1, w1, m1)) in enumerate(zip(eager, graph)):
         for k in l0:
-            assert abs(l0[k] - l1[k]) <= 1e-4 * max(abs(l0[k]), 1e-2), (i, k, l0[k], l1[k])
+            assert abs(l0[k] - l1[k]) <= (3e-3 if k in behind_topk else 1e-4) * max(abs(l0[k]), 1e-2), (i, k, l0[k], l1[k])
         n0, n1 = norms(g0), norms(g1)
         floor = 1e-5 * max(v for v in n0 if v is not None)
         for a, b in zip(n0, n1):
