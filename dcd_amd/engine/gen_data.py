@@ -25,10 +25,10 @@ def dump_gen_data_train(loss_evaluator, out_dir="gen_data"):
 def infer_records(output, visualize_preds, cat="Car"):
     """One image's detections (N,14) + the PostProcessor's `gen_*` tensors -> list of GMW records."""
     n = output.shape[0]
-    k2, k3 = visualize_preds['gen_pred_extra_kpts_2d'], visualize_preds['gen_pred_extra_kpts_3d']
-    nk = k2.shape[1] if n else 0
-    if n == 0:
+    if n == 0:                                                  # nothing above the score threshold: no `gen_*` entries either
         return []
+    k2, k3 = visualize_preds['gen_pred_extra_kpts_2d'], visualize_preds['gen_pred_extra_kpts_3d']
+    nk = k2.shape[1]
     # one packed device buffer, one device-to-host copy for the whole image (SURVEY 8f-2)
     f32 = output.dtype
     packed = torch.cat((output.detach(), k2.detach().reshape(n, nk * 2).to(f32), k3.detach().reshape(n, nk * 3).to(f32)), dim=1).cpu().numpy()

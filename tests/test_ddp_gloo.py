@@ -69,7 +69,28 @@ def _worker(rank, world, port, out_dir):
     others = [torch.zeros_like(flat) for _ in range(world)]
     dist.all_gather(others, flat)
     same = all(torch.equal(others[0], o) for o in others)
-    torch.save({"err": err, "same": same}, os.path.join(out_dir, "r%d.pt" % rank))
+
+    # The data-parallel step of GraphedTrainStep (round 3; on the GPU it is captured into one HIP graph, collectives included):
+    # bare module, ONE all-reduce of the flat gradient buffer.  Its eager body must produce the same mean-of-locals gradient
+    # and leave identical parameters on every rank.
+    from dcd_amd.engine.trainer import GraphedTrainStep, prepare_data_parallel
+    torch.manual_seed(0)
+    bare = KeypointDetector(cfg).train()
+    init_like_trained(bare)
+    prepare_data_parallel(bare, cfg)
+    opt2 = build_optimizer(bare, cfg)
+    gstep = GraphedTrainStep(bare, opt2, cfg.SOLVER.GRAD_NORM_CLIP, distributed=True)
+    for g_ in opt2.param_groups:
+        g_["lr"] = g_["lr"] * 0.0 if torch.is_tensor(g_["lr"]) else 0.0      # keep the weights: the gradient is what is compared
+    gstep._eager(images, targets)
+    got2 = torch.cat([p.grad.flatten() for p in bare.parameters() if p.grad is not None])
+    exp2 = expected
+    if got2.numel() != exp2.numel():                      # frozen dead projections have no gradient in either form; sizes must agree
+        raise AssertionError((got2.numel(), exp2.numel()))
+    # the clip has scaled the reduced gradient by min(1, clip / norm): compare directions and the clipped norm
+    scale = min(1.0, cfg.SOLVER.GRAD_NORM_CLIP / (float(exp2.double().norm()) + 1e-6))      # fp64: 21 M elements
+    err2 = (got2 - exp2 * scale).abs().max().item() / (exp2.abs().max().item() * scale)
+    torch.save({"err": err, "same": same, "err_graph_body": err2}, os.path.join(out_dir, "r%d.pt" % rank))
     dist.barrier()
     dist.destroy_process_group()
 
@@ -82,6 +103,7 @@ def test_ddp_world_size_2_gloo(tmp_path, oracle_dcn):
         res = torch.load(os.path.join(str(tmp_path), "r%d.pt" % r))
         assert res["err"] < 1e-5, "DDP gradient != mean of local gradients (%g)" % res["err"]
         assert res["same"], "parameters diverged across ranks after one step"
+        assert res["err_graph_body"] < 1e-5, "flat-buffer all-reduce of the graphed step != mean of local gradients (%g)" % res["err_graph_body"]
 
 
 def _syncbn_worker(rank, world, port, out_dir):

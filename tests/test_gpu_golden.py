@@ -447,3 +447,35 @@ def test_train_steps_at_sizes_off_the_alignment_rules(cuda, size):
         v = float((total if total is not None else sum(ld.values())).detach())
         assert v == v and abs(v) < 1e6
     assert all(bool(torch.isfinite(p).all()) for p in model.parameters())
+
+
+def test_generate_for_gmw_pass_full_size(cuda):
+    """BASELINE config 4 at full size (bench.py --workload gen): both halves of the --generate_for_GMW pass over a 384x1280
+    batch.  Size-independent properties: the train half writes one record per annotated object with 73 K-normalised key points,
+    every image yields DETECTIONS_PER_IMG rows at a zero score threshold, record fields have the wire format's shapes
+    (DGDE/engine/inference.py:59-84), depths lie inside the solver's clamp [2, 80] - P[2,3] and everything is finite."""
+    import argparse
+    import sys
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from dcd_amd.engine.gen_data import infer_records
+    args = argparse.Namespace(batch=2, objects=6)
+    cfg, model, images, targets = bench._gen_build(args, cuda)
+    n_train, n_det = bench._gen_pass(model, images, targets, torch)
+    lc = model.heads.loss_evaluator
+    assert n_train == 2 * 6 and n_det == 2 * cfg.TEST.DETECTIONS_PER_IMG
+    k2 = np.array(lc.gen_data["kpts_2d"][0], np.float32)
+    k3 = np.array(lc.gen_data["kpts_3d"][0], np.float32)
+    assert k2.shape == (12, 73, 2) and k3.shape == (12, 73, 3) and np.isfinite(k2).all() and np.isfinite(k3).all()
+    assert len(lc.gen_data["pred_location"][0]) == 12 and len(lc.gen_data["img_idx"][0]) == 12
+    model.eval()
+    with torch.no_grad():
+        result, _, vis = model(images[:1], targets[:1])
+    recs = infer_records(result, vis)
+    assert result.shape == (50, 14) and len(recs) == 50 and bool(torch.isfinite(result).all())
+    r = recs[0]
+    assert (len(r["kpts_2d"]), len(r["kpts_2d"][0]), len(r["kpts_3d"][0]), len(r["box"]), len(r["dim"]), len(r["pred_location"])) == (73, 2, 3, 4, 3, 3)
+    z = result[:, 11]
+    assert float(z.min()) > 0.0 and float(z.max()) <= 101.0                    # decoded depths are clamped ([0.1, 100] direct, [2, 80] pair depths)
