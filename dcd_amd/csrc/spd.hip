@@ -87,7 +87,9 @@ __global__ __launch_bounds__(256) void spd_diag_block(float *__restrict__ A, int
                 if (i >= c0 && i < c0 + SP_IB) colbuf[cur][i - c0] = a[jj];
                 __syncthreads();
                 float piv = colbuf[cur][jj];
-                if (!(piv > 0.f)) { bad_flag = 1; piv = 1e-30f; }
+                // not positive definite: poison the factor (NaN) so that the solution is NaN and the step's non-finite guard skips
+                // the update -- a clamped pivot gave a finite but meaningless y that trained on (advisor r2)
+                if (!(piv > 0.f)) { bad_flag = 1; piv = __builtin_nanf(""); }
                 const float inv = __frsqrt_rn(piv);
                 if (i < SP_NB && i >= j) {
                     const float lij = i == j ? piv * inv : a[jj] * inv;

@@ -132,8 +132,20 @@ def optimizer_state_to_reference(model, optimizer):
             if loc[1] in sd["state"]:
                 state[ref_idx] = sd["state"][loc[1]]
         g["params"] = [ref_idx]
-        g["fused"] = None                                  # the reference's optimizer is the plain for-loop AdamW
+        # The reference's optimizer is the plain for-loop AdamW and adopts the saved groups verbatim after
+        # torch.load(map_location=cpu) (DGDE/utils/check_point.py:138): device learning-rate tensors, `capturable` and the
+        # fused flag of OUR optimizer must not travel -- plain floats, capturable off, host step counters.
+        g["fused"] = None
+        g["foreach"] = None
+        g["capturable"] = False
+        for k in ("lr", "initial_lr", "weight_decay", "eps"):
+            if torch.is_tensor(g.get(k)):
+                g[k] = float(g[k])
         groups.append(g)
+    for st in state.values():
+        for k, v in list(st.items()):
+            if torch.is_tensor(v):
+                st[k] = v.detach().cpu() if k != "step" else torch.tensor(float(v), dtype=torch.float32)
     return {"state": state, "param_groups": groups}
 
 
@@ -152,9 +164,16 @@ def optimizer_state_from_reference(ref_sd, model, optimizer):
         rg = ref_sd["param_groups"][ref_idx]
         if loc[0] not in seen:
             seen.add(loc[0])
+            og = ours["param_groups"][loc[0]]
             for k, v in rg.items():
-                if k not in ("params", "fused", "foreach"):
-                    ours["param_groups"][loc[0]][k] = v
+                if k in ("params", "fused", "foreach", "capturable"):
+                    continue                               # how THIS optimizer runs is not the checkpoint's business
+                if torch.is_tensor(og.get(k)):
+                    # our learning rates are device tensors (capturable fused AdamW; GraphedTrainStep addresses them): keep
+                    # the tensor, take the value -- a float here would freeze the rate inside a captured step
+                    og[k] = og[k].clone().fill_(float(v))
+                else:
+                    og[k] = float(v) if torch.is_tensor(v) else v
         if ref_idx in ref_sd["state"]:
             state[loc[1]] = ref_sd["state"][ref_idx]
     ours["state"] = state
@@ -196,7 +215,14 @@ def load_checkpoint_state(data, model, optimizer=None, scheduler=None):
     data = dict(data)
     m.load_state_dict(data.pop("model"))
     if optimizer is not None and "optimizer" in data:
+        # Optimizer.load_state_dict deep-copies the groups: a device learning-rate tensor would come back as a NEW tensor, while a
+        # captured step (GraphedTrainStep) and the scheduler keep addressing the old one.  Keep the objects, move the values.
+        keep = [{k: v for k, v in g.items() if torch.is_tensor(v) and k != "params"} for g in optimizer.param_groups]
         optimizer.load_state_dict(optimizer_state_from_reference(data.pop("optimizer"), model, optimizer))
+        for g, old in zip(optimizer.param_groups, keep):
+            for k, t in old.items():
+                t.fill_(float(g[k]))
+                g[k] = t
     if scheduler is not None and "scheduler" in data:
         sd = data.pop("scheduler")
         if optimizer is not None:

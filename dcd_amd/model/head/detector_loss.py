@@ -396,7 +396,8 @@ class Loss_Computation():
                 for c in cols:
                     M[r, c] = 1.0
             self._mcache = (key, (M.to(device), torch.ones(n, dtype=torch.float32, device=device),
-                                  torch.tensor(list(ratio_cols), dtype=torch.long, device=device)))
+                                  torch.tensor(list(ratio_cols), dtype=torch.long, device=device),
+                                  (M.sum(dim=0) == 0).to(device)))          # columns no loss reads (logging-only metrics)
         return self._mcache[1]
 
     def _core(self, predictions, targets_heatmap, targets_variables):
@@ -524,11 +525,13 @@ class Loss_Computation():
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
             log_tensors['keypoint_depth_loss'] = Sd[i_kd_log]
             spec.append(('keypoint_depth_loss', [i_kd_v, i_kd_i] if self.modify_invalid_keypoint_depths else [i_kd_v]))
-        M, rc_one, rc_idx = self._loss_matrix(spec, n_cols + 1, ratio_cols, pred_heatmap.device)
+        M, rc_one, rc_idx, unused = self._loss_matrix(spec, n_cols + 1, ratio_cols, pred_heatmap.device)
         cols = torch.cat((S, hm_loss.reshape(1).to(S.dtype)))
         if ratio_cols:
             cols = cols * rc_one.index_copy(0, rc_idx, ratios.to(S.dtype))
-        stacked = torch.mv(M, cols)
+        # the metric-only columns (3-D IoU, 2-D IoU, MAE, ...) have zero rows in M, but 0 * NaN is NaN: a non-finite logging
+        # value (3-D IoU of a degenerate box) must not turn every loss into NaN (advisor r2) -- they are zeroed out of the product
+        stacked = torch.mv(M, cols.masked_fill(unused, 0.0))
         loss_dict = LossDict(zip([k for k, _ in spec], stacked.unbind(0)))
         loss_dict.stacked, loss_dict.total = stacked, stacked.sum()
 

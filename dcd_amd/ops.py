@@ -385,8 +385,9 @@ def spd_buffer(b, n, device):
 
 def spd_solve_inplace(aug):
     """y[b] = S[b]^-1 r[b] with S = aug[b, :n], r = aug[b, n] (see `spd_buffer`); aug is overwritten (Cholesky factor / L^-1 r).
-    Blocked Cholesky + substitutions on csrc/spd.hip; no host synchronisation (a matrix that is not positive definite yields a
-    meaningless y instead of the exception torch.linalg.cholesky raises)."""
+    Blocked Cholesky + substitutions on csrc/spd.hip; no host synchronisation: a matrix that is not positive definite yields a
+    NaN y (the kernel poisons the factor at the first non-positive pivot) where torch.linalg.cholesky would raise, so the
+    train step's non-finite guard skips the update."""
     _lib.require_cuda(aug)
     b, rows, n = aug.shape
     if aug.dtype != torch.float32 or not aug.is_contiguous() or rows < n + 1:

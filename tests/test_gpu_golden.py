@@ -479,3 +479,50 @@ def test_generate_for_gmw_pass_full_size(cuda):
     assert (len(r["kpts_2d"]), len(r["kpts_2d"][0]), len(r["kpts_3d"][0]), len(r["box"]), len(r["dim"]), len(r["pred_location"])) == (73, 2, 3, 4, 3, 3)
     z = result[:, 11]
     assert float(z.min()) > 0.0 and float(z.max()) <= 101.0                    # decoded depths are clamped ([0.1, 100] direct, [2, 80] pair depths)
+
+
+def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
+    """Advisor r2: a checkpoint written from the GPU optimizer (tensor learning rates, capturable fused AdamW) must be the
+    reference's plain layout on disk (floats, capturable off: the reference adopts the saved groups verbatim after
+    torch.load(map_location=cpu), DGDE/utils/check_point.py:138), and loading one -- ours or the reference's -- must keep the
+    optimizer's learning-rate TENSORS (a captured step addresses them), take the values, and leave the scheduler in control."""
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import (build_optimizer, build_scheduler, checkpoint_state, init_like_trained,
+                                        load_checkpoint_state, train_step)
+    from dcd_amd.model.detector import KeypointDetector
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(cuda), "MODEL.USE_SYNC_BN", False,
+                        "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    images, targets = make_batch(1, seed=3, n_objects=3, input_size=(320, 96), device=cuda)
+
+    def fresh():
+        torch.manual_seed(0)
+        model = KeypointDetector(cfg).to(cuda).train()
+        init_like_trained(model)
+        opt = build_optimizer(model, cfg)
+        sched, _ = build_scheduler(opt, cfg)
+        return model, opt, sched
+    model, opt, sched = fresh()
+    assert all(torch.is_tensor(g["lr"]) and g["lr"].is_cuda for g in opt.param_groups)
+    train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    for g in opt.param_groups:
+        g["lr"].fill_(1.25e-4)
+    path = str(tmp_path / "ck.pth")
+    torch.save(checkpoint_state(model, opt, sched, iteration=1, iter_per_epoch=10), path)
+    data = torch.load(path, map_location="cpu", weights_only=False)
+    for g in data["optimizer"]["param_groups"]:
+        assert isinstance(g["lr"], float) and abs(g["lr"] - 1.25e-4) < 1e-12 and g["capturable"] is False and g["fused"] is None
+        assert not torch.is_tensor(g.get("initial_lr", 0.0))
+    assert all(not v.is_cuda for st in data["optimizer"]["state"].values() for v in st.values() if torch.is_tensor(v))
+    model2, opt2, sched2 = fresh()
+    lr_objs = [g["lr"] for g in opt2.param_groups]
+    extras = load_checkpoint_state(data, model2, opt2, sched2)
+    assert extras["iteration"] == 1
+    for g, t in zip(opt2.param_groups, lr_objs):
+        assert g["lr"] is t and t.is_cuda and abs(float(t) - 1.25e-4) < 1e-10
+    before = [p.detach().clone() for p in model2.parameters()]
+    train_step(model2, opt2, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)           # fused capturable AdamW with the restored state
+    assert any(not torch.equal(a, p) for a, p in zip(before, model2.parameters()))
+    for g in opt2.param_groups:
+        g["lr"].fill_(7e-5)                                                         # what a scheduler step does to a tensor rate
+    assert all(g["lr"] is t and abs(float(t) - 7e-5) < 1e-10 for g, t in zip(opt2.param_groups, lr_objs))

@@ -42,3 +42,16 @@ def test_transport_schur_system(cuda):
     ref = torch.linalg.solve(S, rhs.unsqueeze(-1)).squeeze(-1)
     y = ops.spd_solve(S.float().to(cuda).contiguous(), rhs.float().to(cuda)).cpu().double()
     assert (y - ref).abs().max().item() <= 2e-4 * ref.abs().max().item()
+
+
+def test_not_positive_definite_yields_nan(cuda):
+    """A matrix that is not positive definite must not produce a finite-looking solution (advisor r2): the kernel poisons the
+    factor at the first non-positive pivot, y is NaN (torch.linalg.cholesky would raise), and the train step's non-finite
+    guard then skips the update.  The well-conditioned matrix in the same batch is unaffected."""
+    from dcd_amd import ops
+    S, r = spd(2, 132, 3, 0.5)
+    S[1, 40, 40] = -5.0
+    y = ops.spd_solve(S.float().to(cuda).contiguous(), r.float().to(cuda)).cpu()
+    ref0 = torch.linalg.solve(S[0], r[0])
+    assert torch.isfinite(y[0]).all() and (y[0].double() - ref0).abs().max() <= 1e-4 * ref0.abs().max()
+    assert torch.isnan(y[1]).any()

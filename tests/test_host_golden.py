@@ -260,6 +260,23 @@ def test_loss_computation_matches_reference(cpu_backend):
     check_loss_computation(torch.device("cpu"), 2e-5)
 
 
+def test_nonfinite_logging_metric_does_not_poison_the_losses(cpu_backend, monkeypatch):
+    """Advisor r2: the 13 losses leave as M (rc * columns); a NaN in a logging-only column (3-D IoU of a degenerate box) has a zero
+    row in M, but 0 * NaN = NaN -- the metric columns are zeroed out of the product, the losses stay those of the fixture."""
+    from dcd_amd.model.head import detector_loss
+    from dcd_amd.model.head.detector_loss import Loss_Computation
+    g = load("loss_computation")
+    preds, targets = gi.loss_inputs()
+    real = detector_loss.get_iou_3d
+    monkeypatch.setattr(detector_loss, "get_iou_3d", lambda a, b: real(a, b) * float("nan"))
+    loss_dict, log = Loss_Computation(small_cfg("cpu"))({"cls": torch.from_numpy(preds["cls"]), "reg": torch.from_numpy(preds["reg"])},
+                                                        list(targets))
+    for k in LOSS_KEYS:
+        ref = float(g["loss_" + k])
+        assert abs(float(loss_dict[k]) - ref) <= 2e-5 * max(abs(ref), 1e-3), (k, float(loss_dict[k]), ref)
+    assert bool(torch.isfinite(loss_dict.total))
+
+
 def test_gen_data_for_gmw_matches_reference(cpu_backend):
     check_gen_data(torch.device("cpu"), 2e-5)
 
