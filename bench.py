@@ -228,7 +228,7 @@ def run_gpu(args):
     dcn_count = args.dcn_steps if use_graph else args.steps
     dcn_ms = timer.total_ms() / max(dcn_count, 1)                       # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
-    traffic, mfma_busy, pmc_source = load_pmc(per_rank)
+    traffic, mfma_busy, pmc_source, pmc_commit = load_pmc(per_rank)
     out = None
     if rank == 0:
         out = {
@@ -248,7 +248,12 @@ def run_gpu(args):
                          "achieved": fl / 1e12 / (dcn_ms / 1e3) if dcn_ms > 0 else None,
                          "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
                          "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
-                         "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
+                         "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "pmc_commit": pmc_commit,
+                         # what the counters say bounds these kernels (the algorithmic bound is "mfma": 196 FLOP/B): on gfx950 the
+                         # f32-input MFMA executes on the vector ALUs' FP32 lanes -- one MFMA and one VALU instruction never
+                         # overlap (tools/micro/mfma_valu_overlap.hip, profiles/r03_mfma_valu_overlap.txt) -- so the measured bound
+                         # is the SUM of matrix and vector issue cycles, not the matrix pipe alone
+                         "bound_measured": "valu+mfma issue (f32 MFMA shares the VALU lanes)", "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
                          "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source,
                          "layers": timer.per_layer(max(dcn_count, 1), per_rank)},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
@@ -285,18 +290,21 @@ def run_gpu(args):
 
 def load_pmc(per_rank):
     """Counter evidence for the DCN kernels, from separate `rocprofv3 --pmc` passes over THIS command (tools/pmc_kernels.py ->
-    profiles/dcn_pmc_r02.json): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as MI355X_MICROARCH.md prescribes) and the
-    time-weighted matrix-pipe busy fraction.  (None, None, "absent") when the passes have not been made for this batch."""
-    path = os.path.join(ROOT, "profiles", "dcn_pmc_r02.json")
-    try:
-        with open(path) as f:
-            d = json.load(f)
-        if "--batch" in d.get("command", "") or per_rank != 8:      # the committed passes are the default bs-8 single-GPU step
-            return None, None, "absent for this batch"
-        s_ = d["summary"]
-        return int(s_["hbm_bytes_per_step"]), float(s_["mfma_busy_time_weighted"]), "profiles/dcn_pmc_r02.json"
-    except (OSError, ValueError, KeyError):
-        return None, None, "absent"
+    profiles/dcn_pmc_r03.json, falling back to round 2's file): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
+    MI355X_MICROARCH.md prescribes) and the time-weighted matrix-pipe busy fraction, plus the commit the passes were made from.
+    (None, None, "absent", None) when the passes have not been made for this batch."""
+    for name in ("dcn_pmc_r03.json", "dcn_pmc_r02.json"):
+        path = os.path.join(ROOT, "profiles", name)
+        try:
+            with open(path) as f:
+                d = json.load(f)
+            if "--batch" in d.get("command", "") or per_rank != 8:      # the committed passes are the default bs-8 single-GPU step
+                return None, None, "absent for this batch", None
+            s_ = d["summary"]
+            return int(s_["hbm_bytes_per_step"]), float(s_["mfma_busy_time_weighted"]), "profiles/" + name, d.get("commit", "unknown")
+        except (OSError, ValueError, KeyError):
+            continue
+    return None, None, "absent", None
 
 
 def cpu_baseline_child(args):

@@ -89,7 +89,12 @@ def main():
                    "dispatches_per_step": sum(e["dispatches"] for e in res.values()) / steps,
                    "mfma_busy_time_weighted": (sum(e.get("mfma_busy", 0) * e.get("avg_us_profiled", 0) * e["dispatches"] for e in res.values())
                                                / max(sum(e.get("avg_us_profiled", 0) * e["dispatches"] for e in res.values()), 1e-9))}
+    import hashlib
     json.dump({"command": " ".join(cmd), "filter": flt, "summary": summary, "kernels": res,
+               # provenance (VERDICT r2 hygiene): the commit the passes were made from (DCD_COMMIT: the GPU box has no .git) and a
+               # hash of the kernel list, so a bench line can say which build its counter evidence belongs to
+               "commit": os.environ.get("DCD_COMMIT", "unknown"),
+               "kernel_list_sha1": hashlib.sha1("\n".join(sorted(res)).encode()).hexdigest(),
                "notes": "bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024: gfx950 FETCH_SIZE counts 128-B requests as 64 B (MI355X_MICROARCH.md "
                         "HBM); WRITE_SIZE uncalibrated; Infinity-Cache hits are included in both.  mfma_busy = SQ_VALU_MFMA_BUSY_CYCLES / "
                         "(4 * SQ_BUSY_CU_CYCLES).  Each counter group is its own pass of the same command."},
