@@ -1300,10 +1300,19 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
     // far-only mode (far_scal != nullptr): the tiled kernel produced grad_offset / grad_mask of every sample displaced by
     // less than TL_NEAR; this launch visits the listed tiles and OVERWRITES the entries of the remaining samples only.
     const bool far_mode = far_scal != nullptr && !far_dominated(far_scal, g.B * ((g.HoWo + 31) / 32));   // else: everything
+    int tap_only = -1;
     if (far_mode) {
         const int tiles_per_img = (g.HoWo + 31) / 32;
-        const int L = (b * (int)gridDim.x + bx) * 4 + wave;
-        if (L >= (int)far_scal[1]) return;
+        int L = (b * (int)gridDim.x + bx) * 4 + wave;
+        // one-pass backward: a listed tile's taps go to different waves when the launch has the waves for it.  A listed tile was
+        // ONE wave's serial walk over 9 taps x all channel blocks -- 100-230 us per layer in the train step for a handful of far
+        // samples (profiles/step_r03_v1_sequence.txt), whatever the size of the rest of the launch.
+        const int nfar = (int)far_scal[1], waves = (int)(gridDim.x * gridDim.y) * 4;
+        if (no_lists && (int64_t)nfar * g.KK <= (int64_t)waves) {
+            tap_only = L % g.KK;
+            L /= g.KK;
+        }
+        if (L >= nfar) return;
         const int tid_ = far_list[L];
         b = tid_ / tiles_per_img;
         tile = tid_ - b * tiles_per_img;
@@ -1344,6 +1353,7 @@ __global__ __launch_bounds__(256) void dcn_bwd_data_f32(const float *__restrict_
         const float *in_g = in_b + (size_t)grp * g.cpg * HW;
         float *gin_g = gin_b + (size_t)grp * g.cpg * HW;
         for (int t = 0; t < g.KK; ++t) {
+            if (tap_only >= 0 && t != tap_only) continue;
             const int seg = grp * g.KK + t;
             const Tap s = make_tap(off_b, msk_b, g, seg, t, ho, wo, Pc, pv);
             float s_m = 0.f, s_h = 0.f, s_w = 0.f;
@@ -2414,8 +2424,11 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         float *swp = (float *)((char *)workspace + base_workspace_bytes(g) + dense_workspace_bytes(g));
         float *cpart = swp + sp.wp_floats, *dwpart = cpart + sp.cpart_floats;
         const unsigned *fs = (const unsigned *)absmax;
+        // the generic data kernel's channel blocks over grid.z (its far-only pass is latency: a few listed tiles); with more than
+        // one block it accumulates grad_offset / grad_mask with atomics onto what dcn_sweep_reduce_coord wrote (zeros for the
+        // samples it owns)
         int nsplit = 1;
-        while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
+        while (nsplit * 2 <= nblk) nsplit *= 2;
         {
             ZeroRanges z;
             for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
