@@ -2452,11 +2452,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             a.in = input; a.off = offset; a.msk = mask; a.wp = swp; a.gy = grad_output; a.gin = grad_input; a.cpart = cpart;
             a.dwpart = dwpart; a.far_scal = fs; a.g = g; a.nstrip = sp.nstrip; a.nseg = sp.nseg; a.seg_rows = sp.seg_rows;
             a.nck = sp.nck; a.nv = sp.nv;
-            const int ngrp = (sp.nv + 7) / 8;
             static LdsLimit sw_lds_limit;
             const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
             if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep_f32)) return DCD_ERR_LAUNCH;
-            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3((ngrp * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), ldsb, stream, a);
+            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3((((sp.nv + 7) / 8) * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), ldsb, stream, a);
         }
         {
             int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
