@@ -2439,7 +2439,11 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             z.p[4] = (unsigned *)grad_input; z.n[4] = (unsigned)((size_t)B * Cin * H * W);
             hipLaunchKernelGGL(dcn_zero_ranges, dim3((unsigned)(z.n[4] / 1024 + 1 < 4096 ? z.n[4] / 1024 + 1 : 4096)), dim3(256), 0, stream, z);
         }
-        hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g, sp.nck);
+        if (split)
+            hipLaunchKernelGGL(dcn_sweep_prep_weights_bf16, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight,
+                               (unsigned *)swp, g, sp.nck);
+        else
+            hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g, sp.nck);
         {
             const int64_t noff = (int64_t)B * 18 * g.HoWo;
             int gsz = (int)((noff + 4095) / 4096);
@@ -2454,8 +2458,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             a.nck = sp.nck; a.nv = sp.nv;
             static LdsLimit sw_lds_limit;
             const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
-            if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep_f32)) return DCD_ERR_LAUNCH;
-            hipLaunchKernelGGL(dcn_bwd_sweep_f32, dim3((((sp.nv + 7) / 8) * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES), dim3(64 * SW_WAVES), ldsb, stream, a);
+            if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep<DCD_PREC_F32>, dcn_bwd_sweep<DCD_PREC_BF16X3>)) return DCD_ERR_LAUNCH;
+            const dim3 sgrid((((sp.nv + 7) / 8) * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES);
+            if (split) hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_BF16X3>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
+            else hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_F32>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
         }
         {
             int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);

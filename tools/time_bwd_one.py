@@ -16,12 +16,12 @@ b = torch.zeros(Co, device=dev)
 gy = torch.randn(B, Co, H, W, device=dev)
 a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
 for _ in range(3):
-    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=os.environ.get("DCD_PREC", "f32"))
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize()
 e0.record()
 for _ in range(iters):
-    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=os.environ.get("DCD_PREC", "f32"))
 e1.record()
 torch.cuda.synchronize()
 print("%d->%d @%dx%d B=%d off=%.2g  bwd %.3f ms" % (C, Co, H, W, B, osc, e0.elapsed_time(e1) / iters))
