@@ -114,10 +114,13 @@ def build_everything(args, device, world, local_rank):
     model = model.to(device).train()
     optimizer = build_optimizer(model, cfg)
     per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
-    # <= 2 images per rank: launch-bound -> whole-step HIP graph (collectives inside it when data parallel)
+    # Whole-step HIP graph: at <= 2 images per rank the step is launch-bound (bs 1: 23.1 -> 15.9 ms, bs 2: 21.9 -> 20.3, bs 4: no gain);
+    # under data parallelism at EVERY batch -- the 136 SyncBN all-reduces issued from Python cost the eager step 6-11 ms
+    # (DDP + SyncBN forced on one GPU: bs 8 52.3 -> 46.5 ms, bs 4 38.4 -> 30.1, bs 1 33.9 -> 17.2), inside the graph they are
+    # stream work between kernels.  DCD_STEP_GRAPH=1 / 0 forces it on / off.
     graph_env = os.environ.get("DCD_STEP_GRAPH")
-    use_graph = graph_env == "1" or (graph_env is None and per_rank <= 2)
     data_parallel = world > 1 or force_ddp
+    use_graph = graph_env == "1" or (graph_env is None and (per_rank <= 2 or data_parallel))
     if data_parallel and use_graph:
         model = prepare_data_parallel(model, cfg)            # bare module: the graphed step reduces the gradients itself
     else:
@@ -154,10 +157,10 @@ def run_gpu(args):
     timer = DcnTimer(torch, _ext)
     clip = cfg.SOLVER.GRAD_NORM_CLIP
 
-    # Whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep) when the step is launch-bound (<= 2 images per
-    # rank; DCD_STEP_GRAPH=1 / 0 forces it on / off).  At bs 8 the GPU is the limit either way (49.7 vs 48.7 ms, round 2), so
-    # the default single-GPU line stays eager.  Data parallel: the graph holds the SyncBN + gradient all-reduces; if capturing
-    # fails on ANY rank all ranks agree (one eager all-reduce) to fall back to the eager DDP step.
+    # Whole step replayed from ONE HIP graph (engine.trainer.GraphedTrainStep): see build_everything for when.  At bs 8 on one
+    # GPU without collectives the GPU is the limit either way (49.7 vs 48.7 ms, round 2), so the default single-GPU line stays
+    # eager.  Data parallel: the graph holds the SyncBN + gradient all-reduces; if capturing fails on ANY rank all ranks agree
+    # (one eager all-reduce) to fall back to the eager DDP step.
     force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
     step_launch = "eager"
     if use_graph:
@@ -262,26 +265,35 @@ def run_gpu(args):
         }
     # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
     # bucketed all-reduce overlapped with the backward) as an extra key -- what BASELINE.json configs[2] is at N = 4
-    if world > 1 and args.scaling == "strong" and not args.no_weak:
+    test_weak = force_ddp and os.environ.get("DCD_TEST_WEAK") == "1"        # one-GPU rehearsal of this branch (twice the batch)
+    if (world > 1 or test_weak) and args.scaling == "strong" and not args.no_weak:
         from dcd_amd.data.synthetic import make_batch
         from dcd_amd.engine.trainer import wrap_distributed
-        if not isinstance(model, torch.nn.parallel.DistributedDataParallel):
-            model = wrap_distributed(model, cfg, local_rank)
-        w_images, w_targets = make_batch(args.batch, seed=200 + rank, n_objects=args.objects, device=device)
+        w_batch = args.batch * (2 if test_weak else 1)
+        w_images, w_targets = make_batch(w_batch, seed=200 + rank, n_objects=args.objects, device=device)
+        if use_graph:                                          # same graphed data-parallel step, captured for this batch size
+            def w_step():
+                graphed(w_images, w_targets)
+        else:
+            if not isinstance(model, torch.nn.parallel.DistributedDataParallel):
+                model = wrap_distributed(model, cfg, local_rank)
+
+            def w_step():
+                train_step(model, optimizer, w_images, w_targets, clip)
         w_steps = max(2, min(args.steps, 5))
         for _ in range(2):
-            train_step(model, optimizer, w_images, w_targets, clip)
+            w_step()
         fence()
         t0 = time.perf_counter()
         for _ in range(w_steps):
-            train_step(model, optimizer, w_images, w_targets, clip)
+            w_step()
         fence()
         w_el = torch.tensor([time.perf_counter() - t0], dtype=torch.float64, device=device)
         dist.all_reduce(w_el, op=dist.ReduceOp.MAX)
         if out is not None:
-            out["weak_scaling"] = {"value": args.batch * world * w_steps / float(w_el.item()), "unit": "images/s", "scaling": "weak",
-                                   "global_batch": args.batch * world, "per_gpu_batch": args.batch, "steps": w_steps,
-                                   "ms_per_step": 1e3 * float(w_el.item()) / w_steps, "step_launch": "eager DDP"}
+            out["weak_scaling"] = {"value": w_batch * world * w_steps / float(w_el.item()), "unit": "images/s", "scaling": "weak",
+                                   "global_batch": w_batch * world, "per_gpu_batch": w_batch, "steps": w_steps,
+                                   "ms_per_step": 1e3 * float(w_el.item()) / w_steps, "step_launch": step_launch}
     if dist.is_initialized():
         dist.barrier()
         dist.destroy_process_group()
