@@ -1252,8 +1252,12 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
 
 // grad_bias[o] = sum_{b,p} dY[b,o,p].  grid = (Cout, splits); one float atomic per block (same-address atomics from
 // every wave of the data kernel serialised in L2 and cost more than the whole MFMA work).
-__global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo)
+__global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo,
+                                                     const unsigned *__restrict__ only_if_far = nullptr)
 {
+    // one-pass backward: its chunk-0 waves sum dY themselves (dcn_sweep_reduce_dw adds the partials); this kernel then runs only
+    // when the generic kernels take the call over
+    if (only_if_far && !far_dominated(only_if_far, B * ((HoWo + 31) / 32))) return;
     // block (o, split): split s walks its slice of every image's plane with 16-byte loads, no per-element index division
     const int o = blockIdx.x;
     const int nq = HoWo >> 2;                                  // float4 per plane (planes are 16-byte aligned when HoWo % 4 == 0)
@@ -2455,28 +2459,30 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             SweepArgs a;
             a.in = input; a.off = offset; a.msk = mask; a.wp = swp; a.gy = grad_output; a.gin = grad_input; a.cpart = cpart;
             a.dwpart = dwpart; a.far_scal = fs; a.g = g; a.nstrip = sp.nstrip; a.nseg = sp.nseg; a.seg_rows = sp.seg_rows;
-            a.nck = sp.nck; a.nv = sp.nv;
+            a.nck = sp.nck; a.nv = sp.nv; a.nslot = sp.nslot;
             static LdsLimit sw_lds_limit;
             const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
             if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep<DCD_PREC_F32>, dcn_bwd_sweep<DCD_PREC_BF16X3>)) return DCD_ERR_LAUNCH;
-            const dim3 sgrid((((sp.nv + 7) / 8) * 8 * sp.nck + SW_WAVES - 1) / SW_WAVES);
+            const dim3 sgrid(sp.nslot / SW_WAVES);
             if (split) hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_BF16X3>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
             else hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_F32>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
-        }
-        {
-            int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
-            if (splits > 32) splits = 32;
-            if (splits < 1) splits = 1;
-            hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
         }
         {
             const int64_t n4 = (int64_t)B * 27 * g.HoWo / 4;
             hipLaunchKernelGGL(dcn_sweep_reduce_coord, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, stream,
                                cpart, grad_offset, grad_mask, B, g.HoWo, sp.nck, fs, B * tiles);
-            const int nred = sp.nck * SW_DW_FLOATS;
-            const int rg = sp.nv >= 64 ? 16 : (sp.nv >= 8 ? 4 : 1);
-            hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, g, sp.nck, sp.nv,
-                               fs, B * tiles);
+            {
+                int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
+                if (splits > 32) splits = 32;
+                if (splits < 1) splits = 1;
+                hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo, fs);
+            }
+            // grad_weight and grad_bias (the sweep's chunk-0 waves summed dY over their pixels) from the per-wave partials
+            const int nred = sp.nck * SW_DW_FLOATS + 64;
+            const int nvp = sp.nslot / sp.nck;
+            const int rg = nvp >= 64 ? 16 : (nvp >= 8 ? 4 : 1);
+            hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, grad_bias, g,
+                               sp.nck, nvp, fs, B * tiles);
         }
         // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
         inv.packed = 0;
