@@ -511,7 +511,7 @@ def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
     torch.save(checkpoint_state(model, opt, sched, iteration=1, iter_per_epoch=10), path)
     data = torch.load(path, map_location="cpu", weights_only=False)
     for g in data["optimizer"]["param_groups"]:
-        assert isinstance(g["lr"], float) and abs(g["lr"] - 1.25e-4) < 1e-12 and g["capturable"] is False and g["fused"] is None
+        assert isinstance(g["lr"], float) and abs(g["lr"] - 1.25e-4) < 1e-9 and g["capturable"] is False and g["fused"] is None
         assert not torch.is_tensor(g.get("initial_lr", 0.0))
     assert all(not v.is_cuda for st in data["optimizer"]["state"].values() for v in st.values() if torch.is_tensor(v))
     model2, opt2, sched2 = fresh()
