@@ -40,9 +40,10 @@ const char *dcd_version(void);
  * offset (B,dg*2*kh*kw,Ho,Wo)   interleaved (dh,dw) per tap   mask (B,dg*kh*kw,Ho,Wo)
  * output / grad_output (B,Cout,Ho,Wo), Ho = (H+2ph-(dh*(kh-1)+1))/sh+1, likewise Wo.
  *
- * precision: 0 = DCD_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32)
- *            1 = DCD_PREC_BF16X3 split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16,
- *                                fp32 accumulate; ~2^-16 relative per product)
+ * precision: 0 = DCD_PREC_F32    exact fp32 MFMA (v_mfma_f32_32x32x2_f32 / v_mfma_f32_16x16x4_f32)
+ *            1 = DCD_PREC_BF16X3 split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMAs, fp32 accumulate;
+ *                                ~2^-16 relative per product).  Permits, does not oblige: geometries
+ *                                without a split kernel run the exact fp32 kernels.
  * workspace: device scratch of at least dcd_dcn_v2_workspace_bytes(...) bytes, 256-byte aligned,
  *            owned by the caller; contents are dead after the call's kernels complete.
  * ---------------------------------------------------------------------------------------------- */
@@ -58,7 +59,10 @@ int dcd_dcn_v2_forward(void *stream, const float *input, const float *weight, co
                        int precision, void *workspace, size_t workspace_bytes);
 
 /* All five gradients are fully overwritten (the callee zero-fills what it accumulates into).
- * grad_input uses fp32 atomics, like the reference's col2im (order-nondeterministic sums). */
+ * grad_input and grad_weight are summed with fp32 atomics where work units overlap, like the reference's col2im
+ * (cuda/dcn_v2_im2col_cuda.cu:249: order-nondeterministic sums); grad_offset / grad_mask are bit-reproducible on the
+ * one-pass path (3x3, stride 1, pad 1, one group, Cout <= 64: csrc/dcn_bwd_sweep.inc) when no sample is displaced by
+ * 3 px or more. */
 int dcd_dcn_v2_backward(void *stream, const float *input, const float *weight, const float *bias,
                         const float *offset, const float *mask, const float *grad_output, float *grad_input,
                         float *grad_offset, float *grad_mask, float *grad_weight, float *grad_bias, int B,
