@@ -11,7 +11,7 @@ def run(args, graphed):
     import bench
     from dcd_amd.engine import trainer
     device = torch.device("cuda", 0)
-    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)
+    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)[:6]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     step = trainer.GraphedTrainStep(model, optimizer, clip) if graphed else None
     losses = []

@@ -12,7 +12,7 @@ def main():
     from dcd_amd.structures.image_list import to_image_list
     args = argparse.Namespace(batch=8, objects=6, precision="f32", scaling="weak", amp=False)
     dev = torch.device("cuda:0")
-    cfg, model, optimizer, images, targets, _ = bench.build_everything(args, dev, 1, 0)
+    cfg, model, optimizer, images, targets = bench.build_everything(args, dev, 1, 0)[:5]
     with torch.no_grad():
         feats = model.backbone(to_image_list(images).tensors)
     feats = feats.detach().requires_grad_(True) if torch.is_tensor(feats) else [f.detach().requires_grad_(True) for f in feats]

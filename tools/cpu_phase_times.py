@@ -17,7 +17,7 @@ def main():
     import bench
     from dcd_amd.engine import trainer
     device = torch.device("cuda", 0)
-    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)
+    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)[:6]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     for _ in range(4):
         trainer.train_step(model, optimizer, images, targets, clip)

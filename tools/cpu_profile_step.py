@@ -41,7 +41,7 @@ def main():
         os.environ.setdefault("RANK", "0")
         os.environ.setdefault("WORLD_SIZE", "1")
         dist.init_process_group(backend="nccl", device_id=device)
-    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)
+    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)[:6]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     for _ in range(args.warmup):
         train_step(model, optimizer, images, targets, clip)

@@ -21,7 +21,7 @@ def main():
     from dcd_amd.engine import trainer
     from dcd_amd.structures.image_list import to_image_list
     device = torch.device("cuda", 0)
-    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)
+    cfg, model, optimizer, images, targets, per_rank = bench.build_everything(args, device, 1, 0)[:6]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     for _ in range(4):
         trainer.train_step(model, optimizer, images, targets, clip)
