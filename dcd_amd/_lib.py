@@ -13,6 +13,20 @@ _LIB = None
 c_void_p, c_int, c_float, c_size_t, c_int64, c_double = (ctypes.c_void_p, ctypes.c_int, ctypes.c_float,
                                                          ctypes.c_size_t, ctypes.c_int64, ctypes.c_double)
 
+
+class LossRowsArgs(ctypes.Structure):
+    """`dcd_loss_rows_args` of include/dcd_hip.h, field for field."""
+    _INTS = ("B", "M", "C", "K", "NP", "num_classes", "ch_box2d", "ch_offset", "ch_corner", "ch_corner_unc", "ch_dims",
+             "ch_ori_cls", "ch_ori_off", "ch_depth", "ch_depth_unc", "ch_kpts2d", "ch_kpts3d", "trunc_log")
+    _FLOATS = ("depth_lo", "depth_hi", "unc_lo", "unc_hi", "depth_weight")
+    _POINTERS = ("pois", "reg_mask", "trunc_mask", "find_pcl", "ori_mask", "cls_ids", "centers", "pad_size", "bboxes",
+                 "locations", "rotys", "offset_3D", "dimensions", "orientations", "keypoints", "kp_depth_mask", "kpts2d",
+                 "kpts3d", "calib_P", "calib", "dim_mean", "kps_pred", "kps_tgt", "kps3d_pred", "kps3d_tgt", "rot", "P_rows",
+                 "kmask", "pair_depth", "pair_mask", "cols", "corners_pred", "corners_tgt", "iou3d", "sums", "grad_sums",
+                 "grad_pois", "grad_pair", "grad_kps", "grad_kps3d")
+    _fields_ = ([(n, c_int) for n in _INTS] + [(n, c_float) for n in _FLOATS] + [("dim_weight", c_float * 3)]
+                + [("down_ratio", c_float), ("kd_eps", c_float)] + [(n, c_void_p) for n in _POINTERS])
+
 # name -> (restype, argtypes); mirrors include/dcd_hip.h one to one
 SIGNATURES = {
     "dcd_version": (ctypes.c_char_p, []),
@@ -72,6 +86,10 @@ SIGNATURES = {
                           c_int, c_int, c_int, c_int, c_float, c_int, c_int]),
     "dcd_spd_solve_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dcd_spd_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "dcd_loss_rows_prepare": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
+    "dcd_loss_rows_forward": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
+    "dcd_loss_rows_backward": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
+    "dcd_loss_rows_finish": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
     "dcd_encode_targets": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_double] * 3 + [c_int, c_int, c_void_p, c_int]),
 }
 

@@ -114,6 +114,17 @@ class Loss_Computation():
         self.extra_kpts_2d_loss_fnc = RegWeightedL1Loss()
 
         self.use_graph = os.environ.get("DCD_LOSS_GRAPH", "1") != "0"
+        # the per-object rows as one kernel (csrc/loss_rows.hip) when the configuration is the one it implements (the DGDE
+        # run); any other configuration, and data generation, evaluate the same terms op by op below
+        enc = self.anno_encoder
+        self.fused_rows = (os.environ.get("DCD_LOSS_ROWS", "1") != "0" and not self.is_gen and self.multibin
+                           and self.orien_bin_size == 4 and self.reg_loss == 'L1' and box_loss == 'giou' and depth_loss == 'L1'
+                           and all(getattr(self, f) for f in list(_LOSS_FLAGS) + list(_HEAD_FLAGS) if f != "compute_weighted_depth_loss")
+                           and self.corner_loss_depth == 'edges' and self.uncertainty_range is not None
+                           and enc.depth_mode == 'inv_sigmoid' and enc.depth_range is not None
+                           and enc.dim_modes[0] == 'exp' and not enc.dim_modes[2]
+                           and self.trunc_offset_loss_type in ('L1', 'log'))
+        self._rows_spec = None
         self._graphs = {}                      # input-shape key -> (graphed callable, {'loss_keys', 'log_names'})
         self._wcache = (None, None)
         self._mcache = (None, None)
@@ -400,9 +411,34 @@ class Loss_Computation():
                                   (M.sum(dim=0) == 0).to(device)))          # columns no loss reads (logging-only metrics)
         return self._mcache[1]
 
+    def _fused_rows(self, predictions, tv, batch_weight):
+        """The per-object columns from one kernel (ops.loss_rows): (column sums, column indices as `_rows` returns them)."""
+        pois = predictions['reg_pois']
+        k2c, enc, lw = self.key2channel, self.anno_encoder, self.loss_weights
+        K = tv['extra_kpts_2d'].shape[2]
+        if self._rows_spec is None or self._rows_spec["K"] != K:
+            heads = {'ch_box2d': '2d_dim', 'ch_offset': '3d_offset', 'ch_corner': 'corner_offset',
+                     'ch_corner_unc': 'corner_uncertainty', 'ch_dims': '3d_dim', 'ch_ori_cls': 'ori_cls',
+                     'ch_ori_off': 'ori_offset', 'ch_depth': 'depth', 'ch_depth_unc': 'depth_uncertainty',
+                     'ch_kpts2d': 'extra_kpts_2d', 'ch_kpts3d': 'extra_kpts_3d'}
+            spec = {f: k2c(name).start for f, name in heads.items()}
+            spec.update(K=K, NP=1500, trunc_log=int(self.trunc_offset_loss_type != 'L1'),
+                        depth_lo=float(enc.depth_range[0]), depth_hi=float(enc.depth_range[1]),
+                        unc_lo=float(self.uncertainty_range[0]), unc_hi=float(self.uncertainty_range[1]),
+                        depth_weight=float(lw['depth_loss']), dim_weight=[float(v) for v in self.dim_weight.reshape(-1).tolist()],
+                        down_ratio=float(enc.down_ratio), kd_eps=float(enc.EPS))
+            self._rows_spec = spec
+        if enc.dim_mean.device != pois.device:
+            enc.dim_mean = enc.dim_mean.to(pois.device)
+        tv = dict(tv)
+        tv['calib'] = enc._calib_table(tv['calib'], pois.device)
+        S = ops.loss_rows(pois, self._rows_spec, enc.dim_mean.float(), tv)
+        names = ('ov', 'giou', 'iou', 'm2', 'depth_real', 'depth', 'trunc', 'off', 'ori', 'dims', 'iou3d', 'corner', 'kp',
+                 'l2d', 'm2d', 'l3d', 'm3d', 'valid_l', 'invalid_l', 'n_valid', 'n_invalid', 'mae', 'kd_log', 'kd_v', 'kd_i')
+        return S, {n: i for i, n in enumerate(names)}
+
     def _core(self, predictions, targets_heatmap, targets_variables):
         pred_heatmap = predictions['cls']
-        pt, preds, reg_nums, weights = self.prepare_predictions(targets_variables, predictions)
         lw = self.loss_weights
         batch_weight = pred_heatmap.shape[0] * self.batch_weight_factor
 
@@ -411,107 +447,130 @@ class Loss_Computation():
         hm_loss, num_hm_pos = self.cls_loss_fnc(pred_heatmap, targets_heatmap)
         hm_loss = lw['hm_loss'] * hm_loss / batch_weight
 
-        # Every other term is a masked sum over the B*M object slots: the per-object columns are collected in `acc` and
-        # reduced together (see _MaskedSums); `W` holds weight / batch_weight per column.
-        acc = _MaskedSums()
-        W = {}
+        reg_pois = predictions.get('reg_pois')
+        if (self.fused_rows and reg_pois is not None and reg_pois.dim() == 3 and targets_variables['keypoints'].shape[2] == 10
+                and targets_variables['orientations'].shape[-1] == 8):
+            S_raw, ix = self._fused_rows(predictions, targets_variables, batch_weight)
+        else:
+            S_raw, ix = self._rows(predictions, targets_variables)
+        return self._losses_from_columns(S_raw, ix, hm_loss, batch_weight)
 
-        def term(vec, mask, weight=1.0):
-            i = acc.add(vec, mask)
-            W[i] = weight
-            return i
+    def _rows(self, predictions, targets_variables):
+        """The per-object columns op by op: (column sums, {name: column index})."""
+        pt, preds, reg_nums, weights = self.prepare_predictions(targets_variables, predictions)
+        lw = self.loss_weights
+
+        # Every term is a masked sum over the B*M object slots: the per-object columns are collected in `acc` and reduced
+        # together (see _MaskedSums); `_losses_from_columns` applies weight / batch_weight per column.
+        acc = _MaskedSums()
+        ix = {}
+
+        def term(name, vec, mask):
+            ix[name] = acc.add(vec, mask)
 
         ov = pt['obj_valid'].float()                             # 1 for annotated objects, 0 for the padded slots
         one = torch.ones_like(ov)
         trunc = pt['trunc_mask_3D'].bool().float()
-        i_ov = term(one, ov)
+        term('ov', one, ov)
 
         # 2-D box: GIoU on the objects with a non-degenerate box
         m2 = pt['reg_2D_mask']
         safe_target = torch.where(m2.unsqueeze(1), pt['reg_2D'], torch.ones_like(pt['reg_2D']))
         giou_l, iou = self.iou_loss(preds['reg_2D'], safe_target)
         m2f = m2.float()
-        i_giou = term(giou_l, m2f, lw['bbox_loss'] / batch_weight)
-        i_iou, i_m2 = term(iou.detach(), m2f), term(one, m2f)
+        term('giou', giou_l, m2f)
+        term('iou', iou.detach(), m2f)
+        term('m2', one, m2f)
 
         # direct depth (+ aleatoric uncertainty)
-        depth_3D_loss = lw['depth_loss'] * self.depth_loss(preds['depth_3D'], pt['depth_3D'], reduction='none')
-        i_depth_real = term(depth_3D_loss.detach(), ov, 1.0 / batch_weight)
-        if self.depth_with_uncertainty:
-            depth_3D_loss = depth_3D_loss * torch.exp(-preds['depth_uncertainty']) + preds['depth_uncertainty'] * lw['depth_loss']
-        i_depth = term(depth_3D_loss, ov, 1.0 / batch_weight)
+        if self.pred_direct_depth:
+            depth_3D_loss = lw['depth_loss'] * self.depth_loss(preds['depth_3D'], pt['depth_3D'], reduction='none')
+            term('depth_real', depth_3D_loss.detach(), ov)
+            if self.depth_with_uncertainty:
+                depth_3D_loss = depth_3D_loss * torch.exp(-preds['depth_uncertainty']) + preds['depth_uncertainty'] * lw['depth_loss']
+            term('depth', depth_3D_loss, ov)
 
         # projected-centre offset; truncated objects use the log form
         off_l = self.reg_loss_fnc(preds['offset_3D'], pt['offset_3D'], reduction='none').sum(dim=1)
         if self.separate_trunc_offset:
             t_l = off_l if self.trunc_offset_loss_type == 'L1' else torch.log(1 + off_l)
             tv = trunc * ov
-            i_trunc = term(t_l, tv, lw['trunc_offset_loss'] / batch_weight)
-            i_off = term(off_l, ov - tv, lw['offset_loss'] / batch_weight)
+            term('trunc', t_l, tv)
+            term('off', off_l, ov - tv)
         else:
-            i_off = term(off_l, ov, lw['offset_loss'] / batch_weight)
+            term('off', off_l, ov)
 
         if self.multibin:
             ori_rows = Real_MultiBin_loss(preds['orien_3D'], pt['orien_3D'], num_bin=self.orien_bin_size, per_row_only=True)
-            i_ori = term(ori_rows, (pt['ori_mask'].bool() & pt['obj_valid']).float(), lw['orien_loss'] / batch_weight)
+            term('ori', ori_rows, (pt['ori_mask'].bool() & pt['obj_valid']).float())
         else:
             raise NotImplementedError("only INPUT.ORIENTATION == 'multi-bin' is on the DGDE path")
 
         if self.dim_weight.device != preds['dims_3D'].device:      # one host->device copy, ever (a per-step copy from
             self.dim_weight = self.dim_weight.to(preds['dims_3D'])  # pageable memory synchronises the stream)
         dims_rows = (self.reg_loss_fnc(preds['dims_3D'], pt['dims_3D'], reduction='none') * self.dim_weight).sum(dim=1)
-        i_dims = term(dims_rows, ov, lw['dims_loss'] / batch_weight)
+        term('dims', dims_rows, ov)
 
         with torch.no_grad():
-            i_iou3d = term(get_iou_3d(preds['corners_3D'], pt['corners_3D']), ov)
+            term('iou3d', get_iou_3d(preds['corners_3D'], pt['corners_3D']), ov)
 
         if self.compute_corner_loss:
-            i_corner = term(self.reg_loss_fnc(preds['corners_3D'], pt['corners_3D'], reduction='none').sum(dim=(1, 2)), ov,
-                            lw['corner_loss'] / batch_weight)
+            term('corner', self.reg_loss_fnc(preds['corners_3D'], pt['corners_3D'], reduction='none').sum(dim=(1, 2)), ov)
         if self.compute_keypoint_corner:
             kl = self.keypoint_loss_fnc(preds['keypoints'], pt['keypoints'], reduction='none').sum(dim=2) * pt['keypoints_mask']
-            i_kp = term(kl.sum(dim=1), ov, lw['keypoint_loss'] / batch_weight)
+            term('kp', kl.sum(dim=1), ov)
         if self.compute_extra_kpts_corner:
             ix_pairs, _mae = self.compute_pairs_kpts_loss(preds, pt, acc, one)
-            W[ix_pairs['l2d']], W[ix_pairs['l3d']] = lw['extra_kpts_2d_loss'], lw['extra_kpts_3d_loss']
-            W[ix_pairs['valid_l']] = W[ix_pairs['invalid_l']] = lw['pairs_kpts_depth_loss']
+            ix.update(ix_pairs)
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
             kd = preds['keypoints_depths']
             km = pt['keypoints_depth_mask'].bool().float()
             tgt = pt['depth_3D'].unsqueeze(-1).expand_as(kd)
-            w = lw['keypoint_depth_loss']
             v_l = self.reg_loss_fnc(kd, tgt, reduction='none')
-            i_kd_log = term((v_l.detach() * km).sum(dim=1), ov, w / batch_weight)
+            term('kd_log', (v_l.detach() * km).sum(dim=1), ov)
             i_l = v_l.detach()
             if self.corner_with_uncertainty:
                 cu = preds['corner_offset_uncertainty']
                 ecu = torch.exp(-cu)
                 v_l = v_l * ecu + cu
                 i_l = i_l * ecu
-            i_kd_v = term((v_l * km).sum(dim=1), ov, w / batch_weight)
-            i_kd_i = term((i_l * (1 - km)).sum(dim=1), ov, w / batch_weight)
+            term('kd_v', (v_l * km).sum(dim=1), ov)
+            term('kd_i', (i_l * (1 - km)).sum(dim=1), ov)
+        return acc.reduce(), ix
 
-        # Column sums -> the 13 losses as ONE vector: `stacked = M (rc * [S, hm_loss])`, M a constant 0/1 matrix (which columns
-        # make up which loss), rc = 1 except for the four columns the reference divides by a mask count (no gradient through
-        # the counts).  Selecting the losses one by one out of S would cost a zero-filled vector + a copy + an accumulation per
-        # loss in the backward.
-        n_cols = len(acc.cols)
-        S = acc.reduce() * self._column_weights(W, n_cols, pred_heatmap.device)
+    def _losses_from_columns(self, S_raw, ix, hm_loss, batch_weight):
+        """Column sums -> the 13 losses as ONE vector: `stacked = M (rc * [S, hm_loss])`, M a constant 0/1 matrix (which
+        columns make up which loss), rc = 1 except for the four columns the reference divides by a mask count (no gradient
+        through the counts).  Selecting the losses one by one out of S would cost a zero-filled vector + a copy + an
+        accumulation per loss in the backward."""
+        lw = self.loss_weights
+        n_cols = S_raw.shape[0]
+        # weight / batch_weight per column (the pair terms are means over their own mask counts: no batch weight)
+        per_batch = {'giou': lw['bbox_loss'], 'depth_real': 1.0, 'depth': 1.0, 'trunc': lw.get('trunc_offset_loss', 1.0),
+                     'off': lw['offset_loss'], 'ori': lw['orien_loss'], 'dims': lw['dims_loss'], 'corner': lw.get('corner_loss', 1.0),
+                     'kp': lw.get('keypoint_loss', 1.0), 'kd_log': lw.get('keypoint_depth_loss', 1.0),
+                     'kd_v': lw.get('keypoint_depth_loss', 1.0), 'kd_i': lw.get('keypoint_depth_loss', 1.0)}
+        plain = {'l2d': lw.get('extra_kpts_2d_loss', 1.0), 'l3d': lw.get('extra_kpts_3d_loss', 1.0),
+                 'valid_l': lw.get('pairs_kpts_depth_loss', 1.0), 'invalid_l': lw.get('pairs_kpts_depth_loss', 1.0)}
+        W = {ix[k]: v / batch_weight for k, v in per_batch.items() if k in ix}
+        W.update({ix[k]: v for k, v in plain.items() if k in ix})
+        S = S_raw * self._column_weights(W, n_cols, S_raw.device)
         Sd = S.detach()
-        spec = [('hm_loss', [n_cols]), ('bbox_loss', [i_giou]), ('dims_loss', [i_dims]), ('orien_loss', [i_ori]), ('offset_loss', [i_off])]
-        log_tensors = {'2D_IoU': Sd[i_iou] / torch.clamp(Sd[i_m2], min=1), '3D_IoU': Sd[i_iou3d] / Sd[i_ov]}   # means over the objects
+        i_ov = ix['ov']
+        spec = [('hm_loss', [n_cols]), ('bbox_loss', [ix['giou']]), ('dims_loss', [ix['dims']]), ('orien_loss', [ix['ori']]),
+                ('offset_loss', [ix['off']])]
+        log_tensors = {'2D_IoU': Sd[ix['iou']] / torch.clamp(Sd[ix['m2']], min=1), '3D_IoU': Sd[ix['iou3d']] / Sd[i_ov]}   # means over the objects
         if self.separate_trunc_offset:
-            spec.append(('trunc_offset_loss', [i_trunc]))
+            spec.append(('trunc_offset_loss', [ix['trunc']]))
         if self.compute_corner_loss:
-            spec.append(('corner_loss', [i_corner]))
+            spec.append(('corner_loss', [ix['corner']]))
         if self.pred_direct_depth:
-            spec.append(('depth_loss', [i_depth]))
-            log_tensors['depth_loss'] = Sd[i_depth_real]
+            spec.append(('depth_loss', [ix['depth']]))
+            log_tensors['depth_loss'] = Sd[ix['depth_real']]
         if self.compute_keypoint_corner:
-            spec.append(('keypoint_loss', [i_kp]))
+            spec.append(('keypoint_loss', [ix['kp']]))
         ratio_cols, ratios = [], []
         if self.compute_extra_kpts_corner:
-            ix = ix_pairs
             scale = Sd[i_ov] / batch_weight                       # number of annotated objects / batch weight
             n_valid = Sd[ix['n_valid']]
             den = torch.clamp(torch.stack((Sd[ix['m2d']], Sd[ix['m3d']], n_valid, Sd[ix['n_invalid']])), min=1)
@@ -523,9 +582,9 @@ class Loss_Computation():
             log_tensors['extra_kpts_depth_loss'] = Sd[ix['valid_l']] / n_valid   # mean over the valid set (nan if empty, as the reference)
             all_mae = Sd[ix['mae']] / den[2]
         if self.compute_keypoint_corner and self.compute_keypoint_depth_loss:
-            log_tensors['keypoint_depth_loss'] = Sd[i_kd_log]
-            spec.append(('keypoint_depth_loss', [i_kd_v, i_kd_i] if self.modify_invalid_keypoint_depths else [i_kd_v]))
-        M, rc_one, rc_idx, unused = self._loss_matrix(spec, n_cols + 1, ratio_cols, pred_heatmap.device)
+            log_tensors['keypoint_depth_loss'] = Sd[ix['kd_log']]
+            spec.append(('keypoint_depth_loss', [ix['kd_v'], ix['kd_i']] if self.modify_invalid_keypoint_depths else [ix['kd_v']]))
+        M, rc_one, rc_idx, unused = self._loss_matrix(spec, n_cols + 1, ratio_cols, S_raw.device)
         cols = torch.cat((S, hm_loss.reshape(1).to(S.dtype)))
         if ratio_cols:
             cols = cols * rc_one.index_copy(0, rc_idx, ratios.to(S.dtype))

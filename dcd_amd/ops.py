@@ -159,6 +159,123 @@ def giou_loss(pred, target):
 # ----------------------------------------------------------------------------------------------
 # Heat-map decode
 # ----------------------------------------------------------------------------------------------
+# ----------------------------------------------------------------------------------------------
+# Per-object rows of the training loss (csrc/loss_rows.hip)
+# ----------------------------------------------------------------------------------------------
+LOSS_ROWS_NCOL = 25
+# (name in the targets dict, dtype the kernel reads)
+_ROWS_TARGETS = (("reg_mask", torch.uint8), ("trunc_mask", torch.uint8), ("find_pcl", torch.uint8), ("ori_mask", torch.uint8),
+                 ("cls_ids", torch.int32), ("target_centers", torch.int32), ("pad_size", torch.int64), ("bboxes", torch.float32),
+                 ("locations", torch.float32), ("rotys", torch.float32), ("offset_3D", torch.float32),
+                 ("dimensions", torch.float32), ("orientations", torch.float32), ("keypoints", torch.float32),
+                 ("keypoints_depth_mask", torch.float32), ("extra_kpts_2d", torch.float32), ("extra_kpts_3d", torch.float32),
+                 ("Calib_P", torch.float32), ("calib", torch.float32))
+_ROWS_FIELD = {"target_centers": "centers", "keypoints_depth_mask": "kp_depth_mask", "extra_kpts_2d": "kpts2d",
+               "extra_kpts_3d": "kpts3d", "Calib_P": "calib_P"}
+
+
+def _typed(t, dtype):
+    if t.dtype == torch.bool and dtype == torch.uint8:
+        t = t.view(torch.uint8)
+    elif t.dtype != dtype:
+        t = t.to(dtype)
+    return t.contiguous()
+
+
+class _LossRows(torch.autograd.Function):
+    """sums (25,) = column sums of the per-object loss rows; differentiable w.r.t. `pois` (B, M, C)."""
+
+    @staticmethod
+    def _args(spec, pois, targets, dim_mean):
+        a = _lib.LossRowsArgs()
+        B, M, C = pois.shape
+        a.B, a.M, a.C, a.K, a.NP = B, M, C, spec["K"], spec["NP"]
+        a.num_classes = dim_mean.shape[0]
+        for k in ("ch_box2d", "ch_offset", "ch_corner", "ch_corner_unc", "ch_dims", "ch_ori_cls", "ch_ori_off", "ch_depth",
+                  "ch_depth_unc", "ch_kpts2d", "ch_kpts3d", "trunc_log", "depth_lo", "depth_hi", "unc_lo", "unc_hi",
+                  "depth_weight", "down_ratio", "kd_eps"):
+            setattr(a, k, spec[k])
+        a.dim_weight[0], a.dim_weight[1], a.dim_weight[2] = spec["dim_weight"]
+        a.pois = pois.data_ptr()
+        for (name, _), t in zip(_ROWS_TARGETS, targets):
+            setattr(a, _ROWS_FIELD.get(name, name), t.data_ptr())
+        a.dim_mean = dim_mean.data_ptr()
+        return a
+
+    @staticmethod
+    def forward(ctx, pois, spec, dim_mean, *targets):
+        _lib.require_cuda(pois, dim_mean, *targets)
+        L = _lib.lib()
+        pois = _f32c(pois)
+        targets = tuple(_typed(t, dt) for t, (_, dt) in zip(targets, _ROWS_TARGETS))
+        dim_mean = _f32c(dim_mean)
+        B, M, C = pois.shape
+        BM, K, NP = B * M, spec["K"], spec["NP"]
+        dev, f32 = pois.device, torch.float32
+        stream = _lib.stream_of(pois)
+        a = _LossRows._args(spec, pois, targets, dim_mean)
+        kps_pred, kps_tgt = torch.empty((2, BM, K, 2), dtype=f32, device=dev).unbind(0)
+        kps3d_pred, kps3d_tgt = torch.empty((2, BM, K, 3), dtype=f32, device=dev).unbind(0)
+        rot = torch.empty((2, BM), dtype=f32, device=dev)
+        P_rows = torch.empty((2, BM, 3, 4), dtype=f32, device=dev)
+        kmask = torch.empty((2, BM, K), dtype=torch.uint8, device=dev)
+        a.kps_pred, a.kps_tgt, a.kps3d_pred, a.kps3d_tgt = (t.data_ptr() for t in (kps_pred, kps_tgt, kps3d_pred, kps3d_tgt))
+        a.rot, a.P_rows, a.kmask = rot.data_ptr(), P_rows.data_ptr(), kmask.data_ptr()
+        _lib.check(L.dcd_loss_rows_prepare(stream, a), "dcd_loss_rows_prepare")
+        # one solver call over [predictions | targets]: the depths that are trained come from the predicted keypoints, the
+        # pair mask from the TARGET keypoints' top-NP ordering (detector_loss.py:381 vs :378; kept as the reference has it)
+        both_depth = torch.empty((2, BM, NP), dtype=f32, device=dev)
+        both_mask = torch.empty((2, BM, NP), dtype=f32, device=dev)
+        both_idx = torch.empty((2, BM, NP), dtype=torch.int32, device=dev)
+        _lib.check(L.dcd_edge_depth_forward(stream, kps_pred.data_ptr(), kps3d_pred.data_ptr(), rot.data_ptr(), P_rows.data_ptr(),
+                                            kmask.data_ptr(), 2 * BM, K, NP, 2.0, 80.0, 0, 1, both_depth.data_ptr(),
+                                            both_idx.data_ptr(), both_mask.data_ptr()), "dcd_edge_depth_forward")
+        depth, idx, pmask = both_depth[0], both_idx[0], both_mask[1]
+        cols = torch.empty((LOSS_ROWS_NCOL, BM), dtype=f32, device=dev)
+        corners = torch.empty((2, BM, 8, 3), dtype=f32, device=dev)
+        iou3d = torch.empty(BM, dtype=f32, device=dev)
+        sums = torch.empty(LOSS_ROWS_NCOL, dtype=f32, device=dev)
+        a.pair_depth, a.pair_mask = depth.data_ptr(), pmask.data_ptr()
+        a.cols, a.corners_pred, a.corners_tgt = cols.data_ptr(), corners[0].data_ptr(), corners[1].data_ptr()
+        a.iou3d, a.sums = iou3d.data_ptr(), sums.data_ptr()
+        _lib.check(L.dcd_loss_rows_forward(stream, a), "dcd_loss_rows_forward")
+        ctx.spec = spec
+        ctx.save_for_backward(pois, dim_mean, kps_pred, kps3d_pred, rot[0], P_rows[0], depth, pmask, idx, *targets)
+        return sums
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gsums):
+        pois, dim_mean, kps_pred, kps3d_pred, rot, P_rows, depth, pmask, idx = ctx.saved_tensors[:9]
+        targets = ctx.saved_tensors[9:]
+        spec = ctx.spec
+        L = _lib.lib()
+        B, M, C = pois.shape
+        BM, K, NP = B * M, spec["K"], spec["NP"]
+        stream = _lib.stream_of(pois)
+        a = _LossRows._args(spec, pois, targets, dim_mean)
+        gsums = _f32c(gsums)
+        gpois = torch.empty_like(pois)
+        gpair = torch.empty_like(depth)
+        gk = torch.empty_like(kps_pred)
+        gk3 = torch.empty_like(kps3d_pred)
+        a.pair_depth, a.pair_mask, a.grad_sums = depth.data_ptr(), pmask.data_ptr(), gsums.data_ptr()
+        a.grad_pois, a.grad_pair, a.grad_kps, a.grad_kps3d = gpois.data_ptr(), gpair.data_ptr(), gk.data_ptr(), gk3.data_ptr()
+        _lib.check(L.dcd_loss_rows_backward(stream, a), "dcd_loss_rows_backward")
+        _lib.check(L.dcd_edge_depth_backward(stream, kps_pred.data_ptr(), kps3d_pred.data_ptr(), rot.data_ptr(), P_rows.data_ptr(),
+                                             gpair.data_ptr(), idx.data_ptr(), BM, K, NP, 2.0, 80.0, 0, gk.data_ptr(),
+                                             gk3.data_ptr()), "dcd_edge_depth_backward")
+        _lib.check(L.dcd_loss_rows_finish(stream, a), "dcd_loss_rows_finish")
+        return (gpois, None, None) + (None,) * len(targets)
+
+
+def loss_rows(pois, spec, dim_mean, targets):
+    """Column sums (25,) of the per-object loss rows of Loss_Computation (detector_loss.py:405-583) for head outputs `pois`
+    (B, M, C) at the object centres; `targets` = the stacked target fields (dict), `spec` = channel map and constants
+    (keys of `dcd_loss_rows_args`).  One autograd node: 5 launches forward, 4 backward."""
+    return _LossRows.apply(pois, spec, dim_mean, *[targets[name] for name, _ in _ROWS_TARGETS])
+
+
 def nms_hm(heat_map, kernel=3, reso=1):
     kernel = int(kernel / reso)
     if kernel % 2 == 0:

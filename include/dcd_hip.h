@@ -159,6 +159,74 @@ int dcd_patch_scatter_add(void *stream, const float *grad_patches, const int64_t
  * ---------------------------------------------------------------------------------------------- */
 int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corners, int N, float *iou);
 
+/* ------------------------------------------------------------------------------------------------
+ * Per-object rows of the training loss: every term of Loss_Computation.forward that is a sum over the
+ * annotated objects (DGDE/model/head/detector_loss.py:405-583) and the decodes of
+ * prepare_predictions that feed them (:217-403; DGDE/model/anno_encoder.py:93-128 encode_box3d, :130-145
+ * decode_depth, :147-161 decode_location_flatten, :193-224 decode_depth_from_keypoints_batch, :226-252
+ * decode_dimension, :254-304 decode_axes_orientation, :392-393 decode_kpts_2d_img), evaluated for all B*M object
+ * slots at once: one wave per slot, empty slots masked out of every sum (they read the first annotated object so
+ * that all arithmetic stays finite).  Supported configuration = the DGDE run: multi-bin orientation with 4 bins,
+ * 10 box keypoints, 'inv_sigmoid' depth, 'exp' dimensions scaled by the class mean, L1 regression losses, corner
+ * depth from the edge solver, depth and keypoint-depth uncertainties.
+ *
+ * Columns (sums over the slots in `sums`, per slot in `cols` (DCD_LOSS_ROWS_NCOL, B*M)), masks already applied:
+ *   0 annotated, 1 GIoU loss, 2 IoU, 3 box valid, 4 depth L1 (log), 5 depth L1 with uncertainty, 6 truncated offset,
+ *   7 offset, 8 multi-bin, 9 dimensions, 10 3-D IoU, 11 corners L1, 12 keypoints L1, 13 dense 2-D keypoints,
+ *   14 their mask count, 15 dense 3-D keypoints, 16 their mask count, 17 pair depth L1 on valid pairs, 18 on invalid
+ *   pairs (no gradient), 19 / 20 the pair counts, 21 pair relative error (log), 22 keypoint depth L1 (log),
+ *   23 with uncertainty on visible groups, 24 uncertainty-scaled L1 on invisible groups (gradient to the uncertainty).
+ *
+ * Call order, all on one stream:
+ *   dcd_loss_rows_prepare   fills kps_pred/kps_tgt (B*M,K,2 image pixels), kps3d_pred/kps3d_tgt (B*M,K,3), and, each
+ *                           stored twice, rot (2,B*M), P_rows (2,B*M,3,4), kmask (2,B*M,K) -- the inputs of
+ *                           dcd_edge_depth_forward; with kps_pred|kps_tgt and kps3d_pred|kps3d_tgt adjacent in memory
+ *                           one solver call over 2*B*M rows serves both
+ *   dcd_edge_depth_forward  (caller): predictions -> pair_depth (+ pair_idx); targets -> pair_mask
+ *   dcd_loss_rows_forward   cols, corners_pred / corners_tgt (B*M,8,3), iou3d (B*M), sums (NCOL)
+ *   dcd_loss_rows_backward  grad_sums (NCOL) -> grad_pois (B*M,C; every element written), grad_pair (B*M,NP)
+ *   dcd_edge_depth_backward (caller): grad_pair -> grad_kps, grad_kps3d
+ *   dcd_loss_rows_finish    grad_pois += the solver's gradients (4 * grad_kps on the 2-D keypoint channels)
+ * ---------------------------------------------------------------------------------------------- */
+#define DCD_LOSS_ROWS_NCOL 25
+typedef struct dcd_loss_rows_args {
+    int B, M, C, K, NP, num_classes;          /* images, slots per image, head channels, dense keypoints, pairs, classes */
+    /* first channel of each regression head inside the C channels (Converter_key2channel, layers/utils.py:22-37) */
+    int ch_box2d, ch_offset, ch_corner, ch_corner_unc, ch_dims, ch_ori_cls, ch_ori_off, ch_depth, ch_depth_unc,
+        ch_kpts2d, ch_kpts3d;
+    int trunc_log;                            /* TRUNCATION_OFFSET_LOSS: 1 = log(1 + l1), 0 = l1 */
+    float depth_lo, depth_hi, unc_lo, unc_hi; /* DEPTH_RANGE, UNCERTAINTY_RANGE */
+    float depth_weight;                       /* loss weight of depth_loss (inside the uncertainty form, :438-441) */
+    float dim_weight[3];                      /* DIMENSION_WEIGHT */
+    float down_ratio, kd_eps;                 /* BACKBONE.DOWN_RATIO; Anno_Encoder.EPS */
+    const float *pois;                        /* (B*M, C) head outputs at the object centres */
+    /* targets, (B, M, ...) as ParamsList stacks them */
+    const uint8_t *reg_mask, *trunc_mask, *find_pcl, *ori_mask;
+    const int32_t *cls_ids, *centers;         /* (B,M), (B,M,2) */
+    const int64_t *pad_size;                  /* (B,2) */
+    const float *bboxes, *locations, *rotys, *offset_3D, *dimensions, *orientations;   /* (..,4) (..,3) (..) (..,2) (..,3) (..,8) */
+    const float *keypoints, *kp_depth_mask;   /* (B,M,10,3), (B,M,3) */
+    const float *kpts2d, *kpts3d;             /* (B,M,K,3) each */
+    const float *calib_P;                     /* (B,M,3,4) */
+    const float *calib;                       /* (B,6): c_u, c_v, f_u, f_v, b_x, b_y */
+    const float *dim_mean;                    /* (num_classes,3) */
+    /* solver side */
+    float *kps_pred, *kps_tgt, *kps3d_pred, *kps3d_tgt, *rot, *P_rows;
+    uint8_t *kmask;
+    const float *pair_depth, *pair_mask;      /* (B*M, NP) */
+    /* forward outputs */
+    float *cols, *corners_pred, *corners_tgt, *iou3d, *sums;
+    /* backward */
+    const float *grad_sums;
+    float *grad_pois, *grad_pair;
+    const float *grad_kps, *grad_kps3d;
+} dcd_loss_rows_args;
+
+int dcd_loss_rows_prepare(void *stream, const dcd_loss_rows_args *args);
+int dcd_loss_rows_forward(void *stream, const dcd_loss_rows_args *args);
+int dcd_loss_rows_backward(void *stream, const dcd_loss_rows_args *args);
+int dcd_loss_rows_finish(void *stream, const dcd_loss_rows_args *args);
+
 /* out = srcs[0] + ... + srcs[n-1] (n <= 16 device tensors of `numel` floats; `srcs` is a HOST array of
  * device pointers).  Replaces autograd's chain of n-1 pairwise gradient additions where one feature map feeds the twelve
  * head trunks (DGDE/model/head/detector_predictor.py:149-160 call every trunk on the same `features`). */
