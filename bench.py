@@ -333,6 +333,7 @@ def cpu_baseline_child(args):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
+    os.environ["DCD_LOSS_ROWS"] = "0"        # the loss's per-object rows op by op on the patched ops (the row kernel is HIP only)
     cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False])
     torch.manual_seed(0)
     model = KeypointDetector(cfg).train()

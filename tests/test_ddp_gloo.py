@@ -31,6 +31,7 @@ def _worker(rank, world, port, out_dir):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
+    os.environ["DCD_LOSS_ROWS"] = "0"          # per-object loss rows op by op on the patched ops
     from dcd_amd.config import get_cfg
     from dcd_amd.data.synthetic import make_batch
     from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step, wrap_distributed
@@ -168,6 +169,7 @@ def _config3_worker(rank, world, port, out_dir):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
+    os.environ["DCD_LOSS_ROWS"] = "0"          # per-object loss rows op by op on the patched ops
     cpu_syncbn.install()
     from dcd_amd.config import get_cfg
     from dcd_amd.data.synthetic import make_batch
