@@ -2227,9 +2227,10 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     const bool split = precision == DCD_PREC_BF16X3;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
-    if (dense_ok(g, false)) {                                  // wide input, small map: column buffer + GEMM, exact fp32
+    if (dense_ok(g, false)) {                                  // wide input, small map: column buffer + GEMM
         if (workspace_bytes < base_workspace_bytes(g) + dense_workspace_bytes(g)) return DCD_ERR_WORKSPACE;
-        dense_forward(stream, input, weight, bias, offset, mask, output, g, (float *)((char *)workspace + base_workspace_bytes(g)));
+        dense_forward(stream, input, weight, bias, offset, mask, output, g, (float *)((char *)workspace + base_workspace_bytes(g)),
+                      split);
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
     float *wf = (float *)workspace, *wb = wf + nw;
@@ -2411,7 +2412,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (splits > 32) splits = 32;
         hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
         dense_backward(stream, input, wb, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, g, inv,
-                       (float *)((char *)workspace + base_workspace_bytes(g)));
+                       (float *)((char *)workspace + base_workspace_bytes(g)), split);
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
     hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),

@@ -116,6 +116,28 @@ def test_bf16x3_path_is_the_split_kernel(cuda, oracle_dcn):
     assert 1e-8 < rel < 3e-5, rel
 
 
+def test_bf16x3_dense_path_is_the_split_gemm(cuda):
+    """The column-buffer path (wide inputs) under DCD_PREC_BF16X3 runs its three products on sgemm_bf16x3.inc: forward, input /
+    coordinate gradients (through T = W^T dY) and grad_weight all differ from the exact-fp32 result in the low bits and stay
+    ~2^-16-close; odd sizes exercise the tile edges and the k tail of the split-K chunks."""
+    from dcd_amd import _ext
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    for C, Co, H, W in ((256, 256, 24, 80), (256, 72, 12, 20)):
+        x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, C, Co, H, W, off_scale=0.5, seed=11))
+        y32 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="f32")
+        y16 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="bf16x3")
+        assert not torch.equal(y32, y16)
+        rel = (y32 - y16).abs().max().item() / y32.abs().max().item()
+        assert 1e-8 < rel < 3e-5, ("forward", C, Co, rel)
+        g32 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="f32")
+        g16 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="bf16x3")
+        for name, p32, p16 in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight"), g32, g16):
+            assert not torch.equal(p32, p16), name
+            rel = (p32 - p16).abs().max().item() / p32.abs().max().item()
+            assert 1e-8 < rel < 3e-5, (name, C, Co, rel)
+        assert torch.equal(g32[4], g16[4])                       # the bias gradient is a plain sum in both
+
+
 @pytest.mark.parametrize("geom", [(64, 64, 96, 320), (128, 64, 48, 160), (256, 256, 24, 80)])
 def test_full_size_bf16x3(cuda, oracle_dcn, geom):
     """BASELINE batch (8) in split precision: image 0 against the fp32 oracle, forward and all five gradients."""

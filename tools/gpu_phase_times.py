@@ -26,7 +26,7 @@ def main():
     for _ in range(4):
         trainer.train_step(model, optimizer, images, targets, clip)
     torch.cuda.synchronize()
-    marks = []
+    marks, fines = [], []
     for _ in range(args.steps):
         ev = [torch.cuda.Event(enable_timing=True) for _ in range(5)]
         if args.presleep_ms > 0:
@@ -34,7 +34,21 @@ def main():
         ev[0].record()
         features = model.backbone(to_image_list(images).tensors)
         ev[1].record()
-        loss_dict, _ = model.heads(features, targets)
+        fine = [torch.cuda.Event(enable_timing=True) for _ in range(3)]     # after predictor | loss bwd done | heads bwd done
+        features.register_hook(lambda g, e=fine[2]: e.record())
+        preds_ = model.heads.predictor(features, targets)
+        fine[0].record()
+        first = [True]
+
+        def after_loss_bwd(g, e=fine[1]):
+            if first[0]:
+                first[0] = False
+                e.record()
+        for v in preds_.values():
+            if torch.is_tensor(v) and v.requires_grad:
+                v.register_hook(after_loss_bwd)
+        loss_dict, _ = model.heads.loss_evaluator(preds_, targets)
+        fines.append(fine)
         total = getattr(loss_dict, "total", None)
         losses = total if total is not None else sum(loss_dict.values())
         ev[2].record()
@@ -67,6 +81,13 @@ def main():
             lb += e[1].elapsed_time(e[2]) / args.steps
     print("loss section alone: forward %.2f ms, backward %.2f ms (GPU, events around the calls; host-bound if eager)" % (lf, lb))
     n = len(marks)
+    pf = sum(m[1].elapsed_time(f[0]) for m, f in zip(marks, fines)) / n
+    lfw = sum(f[0].elapsed_time(m[2]) for m, f in zip(marks, fines)) / n
+    lbw = sum(m[2].elapsed_time(f[1]) for m, f in zip(marks, fines)) / n
+    hbw = sum(f[1].elapsed_time(f[2]) for m, f in zip(marks, fines)) / n
+    bbw = sum(f[2].elapsed_time(m[3]) for m, f in zip(marks, fines)) / n
+    print("  predictor fwd %.2f | loss fwd %.2f | loss bwd (first gradient out) %.2f | predictor bwd %.2f | backbone bwd %.2f" % (
+        pf, lfw, lbw, hbw, bbw))
     acc = [sum(e[i].elapsed_time(e[i + 1]) for e in marks) / n for i in range(4)]
     print("batch %d: GPU ms/step  backbone fwd %.2f | heads+loss fwd %.2f | backward %.2f | clip+adam %.2f | sum %.2f" % (
         per_rank, acc[0], acc[1], acc[2], acc[3], sum(acc)))

@@ -29,3 +29,18 @@ print("  sum of gaps below threshold: %.2f ms" % (small / 1e6))
 for g in sorted(gaps, reverse=True)[:25]:
     if g[0] >= thr * 1e3:
         print("  %8.1f us at %7.2f ms  after %-45s before %s" % (g[0] / 1e3, g[3], g[1].replace("(anonymous namespace)::", "")[:45], g[2].replace("(anonymous namespace)::", "")[:45]))
+# idle time and kernel count per millisecond of the step: where the gaps sit
+nb = int((t1 - t0) / 1e6) + 1
+idle, cnt = [0.0] * nb, [0] * nb
+for gdur, _, _, at in gaps:
+    idle[min(int(at), nb - 1)] += gdur / 1e3
+for _, s, _ in rows:
+    cnt[min(int((s - t0) / 1e6), nb - 1)] += 1
+print("per ms of the step: idle us / kernels started")
+print("  " + " ".join("%d:%d/%d" % (i, idle[i], cnt[i]) for i in range(nb)))
+# memory operations inside the window, if the trace has them
+try:
+    mem = cur.execute("select name, start, end from memory_copies where start >= ? and end <= ? order by start", (t0, t1)).fetchall()
+    print("memory copies in the window: %d, %.1f us" % (len(mem), sum(e - s for _, s, e in mem) / 1e3))
+except Exception as exc:
+    print("no memory-copy table:", exc)
