@@ -263,6 +263,31 @@ def run_gpu(args):
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
                              "algorithmic_bytes": by},
         }
+    # The same job with the DCN contractions in split-bf16 (DCD_PREC_BF16X3: hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32
+    # accumulate, ~2^-16 relative per product against north_star's 1e-3 bound) as an EXTRA object: `value` above stays the exact
+    # fp32 run.  One GPU, eager step only (a captured graph has the fp32 kernels baked in).
+    if out is not None and world == 1 and not use_graph and not args.amp and args.precision == "f32" and not args.no_split_line:
+        _ext.set_precision("bf16x3")
+        s_steps = args.steps
+        for _ in range(max(args.warmup, 2)):
+            step()
+        torch.cuda.synchronize()
+        timer2 = DcnTimer(torch, _ext)
+        timer2.enabled = True
+        t0 = time.perf_counter()
+        for _ in range(s_steps):
+            step()
+        torch.cuda.synchronize()
+        s_el = time.perf_counter() - t0
+        timer2.enabled = False
+        _ext.set_precision("f32")
+        s_dcn = timer2.total_ms() / s_steps
+        out["split_bf16x3"] = {"value": global_batch * s_steps / s_el, "unit": "images/s", "ms_per_step": 1e3 * s_el / s_steps,
+                               "steps": s_steps, "dcn_precision": "bf16x3", "dcn_ms_per_step": s_dcn,
+                               "dcn_tflops": fl / 1e12 / (s_dcn / 1e3) if s_dcn > 0 else None,
+                               "dcn_frac_of_fp32_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if s_dcn > 0 else None,
+                               "dcn_hbm_frac": (by / 1e9 / (s_dcn / 1e3)) / HBM_PEAK_GBS if s_dcn > 0 else None,
+                               "note": "same model, data and step as `value`; only the DCN weight contractions change precision"}
     # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
     # bucketed all-reduce overlapped with the backward) as an extra key -- what BASELINE.json configs[2] is at N = 4
     test_weak = force_ddp and os.environ.get("DCD_TEST_WEAK") == "1"        # one-GPU rehearsal of this branch (twice the batch)
@@ -724,6 +749,7 @@ def main():
                          "weak: --batch images on every rank")
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--objects", type=int, default=6)
+    ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 measurement of the default run")
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
                     help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")
     ap.add_argument("--amp", action="store_true", help="MODEL.FP16: bf16 autocast around the backbone + split-bf16 DCN "
