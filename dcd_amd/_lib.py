@@ -67,6 +67,7 @@ SIGNATURES = {
     "dcd_upsample_dw_backward": (c_int, [c_void_p] * 6 + [c_int] * 5),
     "dcd_bn_workspace_bytes": (c_size_t, [c_int]),
     "dcd_bn_stats": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),
+    "dcd_channel_sums": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int64, c_void_p, c_void_p, c_size_t]),
     "dcd_bn_train_apply": (c_int, [c_void_p] * 6 + [c_double] + [c_void_p] * 3 + [c_float, c_float, c_int] + [c_void_p] * 3
                            + [c_int, c_int, c_int64]),
     "dcd_bn_eval_apply": (c_int, [c_void_p] * 7 + [c_float, c_int, c_void_p, c_int, c_int, c_int64]),

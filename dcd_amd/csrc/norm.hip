@@ -122,6 +122,52 @@ __global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ part
     if (threadIdx.x == 0) { out[2 * c] = a; out[2 * c + 1] = b; }
 }
 
+// ---- per-channel sums in ONE launch (a bias gradient): the slices of bn_partial, and the block that arrives last at a
+// channel's counter adds the channel's S partials in bn_combine's order -- same value as bn_partial + bn_combine + a cast,
+// two launches fewer.  The counters are zero when the module is loaded and every last block leaves its own at zero again.
+__device__ unsigned g_channel_arrivals[65536];
+
+__global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict__ x, Plane g, int S, double *__restrict__ partial,
+                                                         float *__restrict__ out)
+{
+    const int c = blockIdx.y, s = blockIdx.x;
+    const int P = g.B * g.cpp;
+    const bool vec = (g.HW & 3) == 0;
+    double ds = 0.0, unused = 0.0;
+    for (int j = s; j < P; j += S) {
+        const int b = j / g.cpp, k = j - b * g.cpp;
+        const float *p = x + ((long)b * g.C + c) * g.HW;
+        const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
+        float fs = 0.f;
+        if (vec) {
+            for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
+                const float4 v = *reinterpret_cast<const float4 *>(p + i);
+                fs += (v.x + v.y) + (v.z + v.w);
+            }
+        } else {
+            for (long i = lo + threadIdx.x; i < hi; i += BT) fs += p[i];
+        }
+        ds += (double)fs;
+    }
+    block_sum2(ds, unused);
+    __shared__ int is_last;
+    if (threadIdx.x == 0) {
+        partial[(long)c * S + s] = ds;
+        __threadfence();
+        is_last = atomicAdd(&g_channel_arrivals[c], 1u) == (unsigned)(S - 1);
+    }
+    __syncthreads();
+    if (!is_last || threadIdx.x >= 64) return;
+    __threadfence();
+    double a = 0.0;
+    for (int q = threadIdx.x; q < S; q += 64) a += __builtin_nontemporal_load(partial + (long)c * S + q);
+    a = wave_sum(a);
+    if (threadIdx.x == 0) {
+        out[c] = (float)a;
+        g_channel_arrivals[c] = 0u;
+    }
+}
+
 // ---- forward apply: y = act((x - mean) * invstd * w + b [+ residual]) ------------------------------------------------
 // stats != nullptr: training, batch statistics from (sum, sumsq, count); else eval with (mean_in, var_in).
 __global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, const float *__restrict__ residual,
@@ -510,6 +556,18 @@ int dcd_bn_stats(void *stream_, const float *x, int B, int C, int64_t HW, double
     const int S = slices(g);
     hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
     hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, stats);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_channel_sums(void *stream_, const float *x, int B, int C, int64_t HW, float *sums, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!x || !sums || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, sums);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

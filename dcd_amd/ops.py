@@ -929,15 +929,16 @@ _OFFSET_CONV_FWD = os.environ.get("DCD_OFFSET_CONV_FWD", "1") != "0"       # 0: 
 
 
 def channel_sums(gy):
-    """Per-channel sums of a (B, C, ...) fp32 tensor (a bias gradient) by the two-stage fp64 sums of csrc/norm.hip."""
+    """Per-channel sums of a (B, C, ...) fp32 tensor (a bias gradient) by the two-stage fp64 sums of csrc/norm.hip, one launch."""
     L = _lib.lib()
     gy = _f32c(gy)
     B, C = gy.shape[0], gy.shape[1]
     HW = gy.numel() // (B * C)
-    stats = torch.empty((C, 2), dtype=torch.float64, device=gy.device)
+    sums = torch.empty(C, dtype=torch.float32, device=gy.device)
     ws = _bn_ws(C, gy.device)
-    _lib.check(L.dcd_bn_stats(_lib.stream_of(gy), gy.data_ptr(), B, C, HW, stats.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_stats")
-    return stats[:, 0].float()
+    _lib.check(L.dcd_channel_sums(_lib.stream_of(gy), gy.data_ptr(), B, C, HW, sums.data_ptr(), ws.data_ptr(), ws.numel()),
+               "dcd_channel_sums")
+    return sums
 
 
 def conv3x3_bias_supported(x, weight, stride, padding, dilation):

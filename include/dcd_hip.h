@@ -307,6 +307,11 @@ int dcd_context_norm_backward(void *stream, const float *grad_y, const float *y,
 size_t dcd_bn_workspace_bytes(int C);
 int dcd_bn_stats(void *stream, const float *x, int B, int C, int64_t HW, double *stats, void *workspace,
                  size_t workspace_bytes);
+
+/* sums[c] = sum over b and positions of x[b][c][...] (fp64 two-stage sum, rounded once): a bias gradient
+ * (torch.autograd's grad_bias of the reference's nn.Conv2d, DGDE/model/backbone/DCNv2/dcn_v2.py:111-128 conv_offset_mask).
+ * One launch; workspace as dcd_bn_stats. */
+int dcd_channel_sums(void *stream, const float *x, int B, int C, int64_t HW, float *sums, void *workspace, size_t workspace_bytes);
 int dcd_bn_train_apply(void *stream, const float *x, const float *residual, const float *weight, const float *bias,
                        const double *stats, double count, float *running_mean, float *running_var,
                        int64_t *num_batches_tracked, float momentum, float eps, int relu, float *y, float *save_mean,

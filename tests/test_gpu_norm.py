@@ -158,3 +158,21 @@ def test_bn_relu_at_positions_matches_dense_then_gather(cuda, B, C, H, W, N):
     _close(bn.running_mean.cpu(), rm, "running_mean")
     _close(bn.running_var.cpu(), rv, "running_var")
     assert int(bn.num_batches_tracked) == 1
+
+
+@pytest.mark.parametrize("shape", [(8, 27, 96, 320), (2, 27, 12, 40), (3, 5, 7, 9), (1, 300, 4, 4)])
+def test_channel_sums_one_launch_equals_fp64_sum_and_repeats(cuda, shape):
+    """Bias gradient of the DCN offset convolution (ops.channel_sums, one launch with a last-arriver combine): the fp64 sum rounded
+    once, identical on every call (the arrival counters must be left at zero), also for two different tensors back to back."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(*shape, generator=g).to(cuda)
+    y = (torch.randn(*shape, generator=g) * 3 + 1).to(cuda)
+    ref_x = x.double().sum(dim=(0, 2, 3))
+    ref_y = y.double().sum(dim=(0, 2, 3))
+    first = ops.channel_sums(x)
+    for _ in range(3):
+        sx, sy = ops.channel_sums(x), ops.channel_sums(y)
+        assert torch.equal(sx, first)
+        assert (sx.double() - ref_x).abs().max().item() <= 1e-6 * max(ref_x.abs().max().item(), 1.0)
+        assert (sy.double() - ref_y).abs().max().item() <= 1e-6 * max(ref_y.abs().max().item(), 1.0)
