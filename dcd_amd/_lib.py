@@ -27,6 +27,18 @@ class LossRowsArgs(ctypes.Structure):
     _fields_ = ([(n, c_int) for n in _INTS] + [(n, c_float) for n in _FLOATS] + [("dim_weight", c_float * 3)]
                 + [("down_ratio", c_float), ("kd_eps", c_float)] + [(n, c_void_p) for n in _POINTERS])
 
+HEADS_MAX = 16
+
+
+class HeadRowsArgs(ctypes.Structure):
+    """`dcd_head_rows_args` of include/dcd_hip.h, field for field."""
+    _fields_ = ([(n, c_int) for n in ("n_heads", "T", "R", "K", "C")]
+                + [(n, c_int * HEADS_MAX) for n in ("trunk", "ch0", "out")]
+                + [("weight", c_void_p * HEADS_MAX), ("bias", c_void_p * HEADS_MAX), ("feat", c_void_p), ("y", c_void_p),
+                   ("grad_y", c_void_p), ("grad_feat", c_void_p), ("grad_weight", c_void_p * HEADS_MAX),
+                   ("grad_bias", c_void_p * HEADS_MAX)])
+
+
 # name -> (restype, argtypes); mirrors include/dcd_hip.h one to one
 SIGNATURES = {
     "dcd_version": (ctypes.c_char_p, []),
@@ -87,6 +99,8 @@ SIGNATURES = {
                           c_int, c_int, c_int, c_int, c_float, c_int, c_int]),
     "dcd_spd_solve_workspace_bytes": (c_size_t, [c_int, c_int]),
     "dcd_spd_solve": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_size_t]),
+    "dcd_head_rows_forward": (c_int, [c_void_p, ctypes.POINTER(HeadRowsArgs)]),
+    "dcd_head_rows_backward": (c_int, [c_void_p, ctypes.POINTER(HeadRowsArgs)]),
     "dcd_loss_rows_prepare": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
     "dcd_loss_rows_forward": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),
     "dcd_loss_rows_backward": (c_int, [c_void_p, ctypes.POINTER(LossRowsArgs)]),

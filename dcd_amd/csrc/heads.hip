@@ -734,6 +734,105 @@ __global__ __launch_bounds__(256) void sum_tensors_kernel(SumSrcs srcs, int n, f
     }
 }
 
+// ---------------------------------------------------------------------------------------------
+// Output layers of the regression heads at listed rows (dcd_head_rows_*).  detector_predictor.py:84-101, :198-203.
+// forward: a workgroup holds four rows' T trunk vectors in LDS and takes an eighth of the channels; a wave handles one channel
+// at a time, its lanes split the K = 256 contraction into float4 pieces (one coalesced 1 KB read of the weight row serves the
+// four rows) and meet in a wave sum.
+// ---------------------------------------------------------------------------------------------
+constexpr int HR_KMAX = 256, HR_TMAX = 16;
+
+__device__ __forceinline__ int hr_head_of(const dcd_head_rows_args &a, int ch)
+{
+    int j = 0;
+    while (j + 1 < a.n_heads && ch >= a.ch0[j + 1]) ++j;
+    return j;
+}
+
+constexpr int HR_ROWS = 4, HR_CSPLIT = 8;      // rows per workgroup (one weight read serves four rows), channel slices per row group
+
+__global__ __launch_bounds__(256) void head_rows_fwd_kernel(const dcd_head_rows_args a)
+{
+    extern __shared__ __attribute__((aligned(16))) float f[];          // [HR_ROWS][T][K]
+    const int r0 = blockIdx.x * HR_ROWS, tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+    const int TK = a.T * a.K;
+    for (int e = tid; e < HR_ROWS * TK; e += 256) {
+        const int q = e / TK, rem = e - q * TK;
+        const int t = rem / a.K, k = rem - t * a.K;
+        f[e] = r0 + q < a.R ? a.feat[((size_t)t * a.R + r0 + q) * a.K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int ch = blockIdx.y * 4 + wave; ch < a.C; ch += 4 * HR_CSPLIT) {
+        const int j = hr_head_of(a, ch), o = ch - a.ch0[j];
+        const float *w = a.weight[j] + (size_t)o * a.K, *x = f + a.trunk[j] * a.K;
+        float acc[HR_ROWS];
+#pragma unroll
+        for (int q = 0; q < HR_ROWS; ++q) acc[q] = 0.f;
+        for (int k = 4 * lane; k < a.K; k += 256) {
+            const float4 wv = *reinterpret_cast<const float4 *>(w + k);
+#pragma unroll
+            for (int q = 0; q < HR_ROWS; ++q) {
+                const float4 xv = *reinterpret_cast<const float4 *>(x + q * TK + k);
+                acc[q] = fmaf(wv.x, xv.x, fmaf(wv.y, xv.y, fmaf(wv.z, xv.z, fmaf(wv.w, xv.w, acc[q]))));
+            }
+        }
+#pragma unroll
+        for (int q = 0; q < HR_ROWS; ++q) {
+#pragma unroll
+            for (int m = 32; m >= 1; m >>= 1) acc[q] += __shfl_xor(acc[q], m, 64);
+        }
+        const float bv = a.bias[j] ? a.bias[j][o] : 0.f;
+        if (lane < HR_ROWS && r0 + lane < a.R) {
+            float v = acc[0];
+#pragma unroll
+            for (int q = 1; q < HR_ROWS; ++q) v = lane == q ? acc[q] : v;
+            a.y[(size_t)(r0 + lane) * a.C + ch] = v + bv;
+        }
+    }
+}
+
+// feature gradient: one workgroup per row, thread = k; a trunk's gradient is the sum over the channels of all its heads
+__global__ __launch_bounds__(256) void head_rows_bwd_feat_kernel(const dcd_head_rows_args a)
+{
+    __shared__ float g[1024];
+    const int r = blockIdx.x, k = threadIdx.x;
+    for (int e = k; e < a.C; e += 256) g[e] = a.grad_y[(size_t)r * a.C + e];
+    __syncthreads();
+    if (k >= a.K) return;
+    int j = 0;
+    for (int t = 0; t < a.T; ++t) {
+        float acc = 0.f;
+        for (; j < a.n_heads && a.trunk[j] == t; ++j) {
+            const float *w = a.weight[j] + k;
+            const float *gj = g + a.ch0[j];
+            for (int o = 0; o < a.out[j]; ++o) acc = fmaf(gj[o], w[(size_t)o * a.K], acc);
+        }
+        a.grad_feat[((size_t)t * a.R + r) * a.K + k] = acc;
+    }
+}
+
+// weight / bias gradient: one workgroup per output channel, thread = k, rows in order (reproducible)
+__global__ __launch_bounds__(256) void head_rows_bwd_weight_kernel(const dcd_head_rows_args a)
+{
+    __shared__ float g[256];
+    const int ch = blockIdx.x, k = threadIdx.x;
+    const int j = hr_head_of(a, ch), o = ch - a.ch0[j];
+    const float *x = a.feat + (size_t)a.trunk[j] * a.R * a.K;
+    float acc = 0.f, gb = 0.f;
+    for (int r0 = 0; r0 < a.R; r0 += 256) {
+        __syncthreads();
+        if (r0 + k < a.R) g[k] = a.grad_y[(size_t)(r0 + k) * a.C + ch];
+        __syncthreads();
+        const int n = a.R - r0 < 256 ? a.R - r0 : 256;
+        if (k < a.K)
+            for (int i = 0; i < n; ++i) acc = fmaf(g[i], x[(size_t)(r0 + i) * a.K + k], acc);
+        if (k == 0)
+            for (int i = 0; i < n; ++i) gb += g[i];
+    }
+    if (k < a.K) a.grad_weight[j][(size_t)o * a.K + k] = acc;
+    if (k == 0 && a.grad_bias[j]) a.grad_bias[j][o] = gb;
+}
+
 }  // namespace
 
 extern "C" {
@@ -928,6 +1027,43 @@ int dcd_sum_tensors(void *stream_, const float *const *srcs, int n, float *out, 
     if (blocks > 8192) blocks = 8192;
     if (blocks < 1) blocks = 1;
     hipLaunchKernelGGL(sum_tensors_kernel, dim3((unsigned)blocks), dim3(256), 0, stream, a, n, out, n4, numel);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+static bool head_rows_ok(const dcd_head_rows_args *a)
+{
+    if (!a || a->n_heads <= 0 || a->n_heads > DCD_HEADS_MAX || a->T <= 0 || a->T > HR_TMAX || a->R < 0 || a->K <= 0 || a->K > HR_KMAX ||
+        (a->K & 3) || a->C <= 0 || a->C > 1024 || !a->feat)
+        return false;
+    int c = 0;
+    for (int j = 0; j < a->n_heads; ++j) {
+        if (a->ch0[j] != c || a->out[j] <= 0 || a->trunk[j] < 0 || a->trunk[j] >= a->T || !a->weight[j]) return false;
+        if (j && a->trunk[j] < a->trunk[j - 1]) return false;                 // heads ordered by trunk
+        c += a->out[j];
+    }
+    return c == a->C;
+}
+
+int dcd_head_rows_forward(void *stream_, const dcd_head_rows_args *a)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!head_rows_ok(a) || !a->y) return DCD_ERR_BAD_ARG;
+    if (a->R == 0) return DCD_OK;
+    hipLaunchKernelGGL(head_rows_fwd_kernel, dim3((a->R + HR_ROWS - 1) / HR_ROWS, HR_CSPLIT), dim3(256),
+                       sizeof(float) * HR_ROWS * a->T * a->K, stream, *a);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_head_rows_backward(void *stream_, const dcd_head_rows_args *a)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!head_rows_ok(a) || !a->grad_y || !a->grad_feat) return DCD_ERR_BAD_ARG;
+    for (int j = 0; j < a->n_heads; ++j)
+        if (!a->grad_weight[j]) return DCD_ERR_BAD_ARG;
+    if (a->R > 0) hipLaunchKernelGGL(head_rows_bwd_feat_kernel, dim3(a->R), dim3(256), 0, stream, *a);
+    hipLaunchKernelGGL(head_rows_bwd_weight_kernel, dim3(a->C), dim3(256), 0, stream, *a);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

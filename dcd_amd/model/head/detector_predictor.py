@@ -23,6 +23,7 @@ from dcd_amd.model.head import trunk_moments
 
 import os
 _HEAD_FUSED = os.environ.get("DCD_HEAD_FUSED", "1") != "0"      # 0: stock 1x1 conv + separate gather (A/B timing)
+_HEAD_ROWS = os.environ.get("DCD_HEAD_ROWS", "1") != "0"        # 0: one F.linear per regression head (A/B timing, CPU tests)
 
 
 @registry.PREDICTOR.register("Base_Predictor")
@@ -215,8 +216,23 @@ class _predictor(nn.Module):
         moments = None
         if not self.deeper_head and all(isinstance(fl[2], nn.Identity) for fl in self.reg_features) \
                 and trunk_moments.usable(self.reg_features, reg_inputs[0]):
-            moments = trunk_moments.trunks_at(reg_inputs[0], self.reg_features, centers_lin,
-                                              (self.offset_index[0], edge_lin) if self.enable_edge_fusion else None)
+            extra = (self.offset_index[0], edge_lin) if self.enable_edge_fusion else None
+            if _HEAD_ROWS and features.is_cuda and features.dtype == torch.float32 and self._head_rows_ok():
+                # every 1x1 output layer at the object centres in ONE launch (ops.head_rows) instead of a GEMM per head, their
+                # concatenation and -- backward -- two GEMMs, a bias sum and a slice copy per head
+                at_centres, at_extra = trunk_moments.trunks_at(reg_inputs[0], self.reg_features, centers_lin, extra, stacked=True)
+                heads = [(i, h) for i, hs in enumerate(self.reg_heads) for h in hs]
+                reg_pois = ops.head_rows(at_centres.reshape(n_reg, b * M, self.head_conv), [i for i, _ in heads],
+                                         [h.weight for _, h in heads], [h.bias for _, h in heads]).view(b, M, -1)
+                if self.enable_edge_fusion:
+                    first = sum(len(hs) for hs in self.reg_heads[:self.offset_index[0]]) + self.offset_index[1]
+                    ch0 = sum(h.out_channels for _, h in heads[:first])              # first channel of the 3d_offset head
+                    edge = self._edge_fusion_at_pois(at_extra.transpose(1, 2), edge_lin, edge_valid, centers_lin)     # B x M x 2
+                    reg_pois = reg_pois + F.pad(edge, (ch0, reg_pois.shape[2] - ch0 - edge.shape[2]))
+                    output_cls = self._edge_fusion_cls(feature_cls, output_cls, targets, edge_cls_feature)
+                output_cls = sigmoid_hm(output_cls)
+                return {'cls': output_cls.float(), 'reg': None, 'reg_pois': reg_pois}
+            moments = trunk_moments.trunks_at(reg_inputs[0], self.reg_features, centers_lin, extra)
         for i, feat_layer in enumerate(self.reg_features):
             fused = i == self.offset_index[0] and self.enable_edge_fusion
             pos = torch.cat((centers_lin, edge_lin), dim=1) if fused else centers_lin
@@ -237,6 +253,13 @@ class _predictor(nn.Module):
                 outs.append(o)
         output_cls = sigmoid_hm(output_cls)
         return {'cls': output_cls.float(), 'reg': None, 'reg_pois': torch.cat(outs, dim=2).float()}
+
+    def _head_rows_ok(self):
+        """The shapes ops.head_rows takes: 1x1 output layers over a trunk of at most 256 channels, at most 16 heads."""
+        heads = [h for hs in self.reg_heads for h in hs]
+        return (len(heads) <= 16 and len(self.reg_features) <= 16 and self.head_conv <= 256 and self.head_conv % 4 == 0
+                and all(isinstance(h, nn.Conv2d) and h.kernel_size == (1, 1) and h.groups == 1 and h.in_channels == self.head_conv
+                        for h in heads) and sum(h.out_channels for h in heads) <= 1024)
 
     def _edge_fusion_cls(self, feature_cls, output_cls, targets, gathered=None):
         """The class-map half of `_edge_fusion` (dense: the focal loss reads every cell).  gathered: feature_cls at the border

@@ -272,10 +272,11 @@ def _taps(W, device):
     return _TAPS[key]
 
 
-def trunks_at(x, trunks, centers, extra=None):
+def trunks_at(x, trunks, centers, extra=None, stacked=False):
     """BN + ReLU outputs of every trunk at `centers` (B, M) linear pixel indices -> list of (B, M, Cout); `extra` = (trunk index,
     positions (B, Ke)) appends that trunk's outputs at further positions (the border cells of the edge-fusion branch).  Updates the
-    BatchNorm running estimates like a dense training forward."""
+    BatchNorm running estimates like a dense training forward.  stacked: return (all trunks at the centres as ONE (T, B, M, Cout)
+    tensor, the extra trunk's outputs at its extra positions (B, Ke, Cout) or None) instead of the list."""
     B, C, H, W = x.shape
     T = len(trunks)
     pos_all = centers.long() if extra is None else torch.cat((centers.long(), extra[1].long()), dim=1)
@@ -336,10 +337,16 @@ def trunks_at(x, trunks, centers, extra=None):
             return xp.gather(2, idx).reshape(B, K, n)                                          # (B, C, 9, n) -> (B, 9C, n)
     Xc = patches(centers, True)                                                                # (B, 9C, M)
     y = torch.einsum('bkm,tok->tbmo', Xc, Wall)
-    out = list(torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1)).unbind(0))
+    at_centres = torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1))
+    at_extra = None
     if extra is not None:
         i, pos = extra
         Xe = patches(pos, False)
         ye = torch.einsum('bkm,ok->bmo', Xe, Wall[i])
-        out[i] = torch.cat((out[i], torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))), dim=1)
+        at_extra = torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))
+    if stacked:
+        return at_centres, at_extra
+    out = list(at_centres.unbind(0))
+    if at_extra is not None:
+        out[extra[0]] = torch.cat((out[extra[0]], at_extra), dim=1)
     return out

@@ -160,6 +160,66 @@ def giou_loss(pred, target):
 # Heat-map decode
 # ----------------------------------------------------------------------------------------------
 # ----------------------------------------------------------------------------------------------
+# Output layers of the regression heads at listed rows (csrc/heads.hip, dcd_head_rows_*)
+# ----------------------------------------------------------------------------------------------
+class _HeadRows(torch.autograd.Function):
+    @staticmethod
+    def _args(feat, trunk_of, weights, biases):
+        a = _lib.HeadRowsArgs()
+        T, R, K = feat.shape
+        a.n_heads, a.T, a.R, a.K = len(weights), T, R, K
+        c = 0
+        for j, (t, w) in enumerate(zip(trunk_of, weights)):
+            a.trunk[j], a.ch0[j], a.out[j] = t, c, w.shape[0]
+            a.weight[j] = w.data_ptr()
+            a.bias[j] = None if biases[j] is None else biases[j].data_ptr()
+            c += w.shape[0]
+        a.C = c
+        a.feat = feat.data_ptr()
+        return a
+
+    @staticmethod
+    def forward(ctx, feat, trunk_of, n, *params):
+        _lib.require_cuda(feat, *[p for p in params if p is not None])
+        feat = _f32c(feat)
+        weights = [_f32c(w).reshape(w.shape[0], -1) for w in params[:n]]
+        biases = [None if b is None else _f32c(b) for b in params[n:]]
+        a = _HeadRows._args(feat, trunk_of, weights, biases)
+        y = torch.empty((feat.shape[1], a.C), dtype=torch.float32, device=feat.device)
+        a.y = y.data_ptr()
+        _lib.check(_lib.lib().dcd_head_rows_forward(_lib.stream_of(feat), a), "dcd_head_rows_forward")
+        ctx.trunk_of, ctx.n = trunk_of, n
+        ctx.shapes = [tuple(p.shape) for p in params[:n]]
+        ctx.has_bias = [b is not None for b in biases]
+        ctx.save_for_backward(feat, *weights)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        feat, weights = ctx.saved_tensors[0], list(ctx.saved_tensors[1:])
+        n = ctx.n
+        gy = _f32c(gy)
+        a = _HeadRows._args(feat, ctx.trunk_of, weights, [None] * n)
+        gfeat = torch.empty_like(feat)
+        gws = [torch.empty_like(w) for w in weights]
+        gbs = [torch.empty(w.shape[0], dtype=torch.float32, device=feat.device) if hb else None for w, hb in zip(weights, ctx.has_bias)]
+        a.grad_y, a.grad_feat = gy.data_ptr(), gfeat.data_ptr()
+        for j in range(n):
+            a.grad_weight[j] = gws[j].data_ptr()
+            a.grad_bias[j] = None if gbs[j] is None else gbs[j].data_ptr()
+        _lib.check(_lib.lib().dcd_head_rows_backward(_lib.stream_of(feat), a), "dcd_head_rows_backward")
+        return (gfeat, None, None) + tuple(g.view(s) for g, s in zip(gws, ctx.shapes)) + tuple(gbs)
+
+
+def head_rows(feat, trunk_of, weights, biases):
+    """y (R, sum out_j): the 1x1 output layers (weights[j] (out_j, K[, 1, 1]), biases[j]) of the regression heads applied to their
+    trunks' outputs feat (T, R, K) at R listed rows; trunk_of[j] = trunk of head j, heads ordered by trunk
+    (detector_predictor.py:84-101, :198-203).  One launch forward, two backward."""
+    return _HeadRows.apply(feat, tuple(int(t) for t in trunk_of), len(weights), *weights, *biases)
+
+
+# ----------------------------------------------------------------------------------------------
 # Per-object rows of the training loss (csrc/loss_rows.hip)
 # ----------------------------------------------------------------------------------------------
 LOSS_ROWS_NCOL = 25

@@ -160,6 +160,31 @@ int dcd_patch_scatter_add(void *stream, const float *grad_patches, const int64_t
 int dcd_iou3d(void *stream, const float *pred_corners, const float *target_corners, int N, float *iou);
 
 /* ------------------------------------------------------------------------------------------------
+ * The 1x1 output layers of the regression heads evaluated at listed rows: the reference applies one nn.Conv2d(256, out_j, 1)
+ * per head to its trunk's dense output and concatenates the maps (DGDE/model/head/detector_predictor.py:84-101, :160-170,
+ * :198-203); training reads them at the object centres only (detector_loss.py:231-233), so here
+ *     y[r][ch0_j + o] = bias_j[o] + sum_k feat[trunk_j][r][k] * weight_j[o][k]        r = 0 .. R-1 (R = B * MAX_OBJECTS)
+ * for all heads in ONE launch, and the backward in two (feature gradient per trunk; weight and bias gradients).
+ * feat (T, R, K) trunk outputs at the rows, heads ordered by trunk, ch0_j = running sum of out_j, C = their total.
+ * ---------------------------------------------------------------------------------------------- */
+#define DCD_HEADS_MAX 16
+typedef struct dcd_head_rows_args {
+    int n_heads, T, R, K, C;
+    int trunk[DCD_HEADS_MAX], ch0[DCD_HEADS_MAX], out[DCD_HEADS_MAX];
+    const float *weight[DCD_HEADS_MAX];      /* (out_j, K) */
+    const float *bias[DCD_HEADS_MAX];        /* (out_j) or NULL */
+    const float *feat;                       /* (T, R, K) */
+    float *y;                                /* (R, C): forward output */
+    const float *grad_y;                     /* (R, C) */
+    float *grad_feat;                        /* (T, R, K): every element written */
+    float *grad_weight[DCD_HEADS_MAX];       /* (out_j, K) */
+    float *grad_bias[DCD_HEADS_MAX];         /* (out_j) or NULL */
+} dcd_head_rows_args;
+
+int dcd_head_rows_forward(void *stream, const dcd_head_rows_args *args);
+int dcd_head_rows_backward(void *stream, const dcd_head_rows_args *args);
+
+/* ------------------------------------------------------------------------------------------------
  * Per-object rows of the training loss: every term of Loss_Computation.forward that is a sum over the
  * annotated objects (DGDE/model/head/detector_loss.py:405-583) and the decodes of
  * prepare_predictions that feed them (:217-403; DGDE/model/anno_encoder.py:93-128 encode_box3d, :130-145
