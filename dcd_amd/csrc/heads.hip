@@ -791,24 +791,38 @@ __global__ __launch_bounds__(256) void head_rows_fwd_kernel(const dcd_head_rows_
     }
 }
 
-// feature gradient: one workgroup per row, thread = k; a trunk's gradient is the sum over the channels of all its heads
+// feature gradient: a workgroup takes four rows (one read of a weight element serves the four) and ONE trunk, thread = k; the
+// trunk's gradient is the sum over the channels of all its heads
 __global__ __launch_bounds__(256) void head_rows_bwd_feat_kernel(const dcd_head_rows_args a)
 {
-    __shared__ float g[1024];
-    const int r = blockIdx.x, k = threadIdx.x;
-    for (int e = k; e < a.C; e += 256) g[e] = a.grad_y[(size_t)r * a.C + e];
+    __shared__ float g[HR_ROWS][1024];
+    const int r0 = blockIdx.x * HR_ROWS, t = blockIdx.y, k = threadIdx.x;
+    int j0 = 0;
+    while (j0 < a.n_heads && a.trunk[j0] != t) ++j0;
+    int j1 = j0;
+    while (j1 < a.n_heads && a.trunk[j1] == t) ++j1;
+    const int c0 = j0 < a.n_heads ? a.ch0[j0] : 0, c1 = j1 > j0 ? a.ch0[j1 - 1] + a.out[j1 - 1] : c0;
+    for (int e = k; e < HR_ROWS * (c1 - c0); e += 256) {
+        const int q = e / (c1 - c0), c = e - q * (c1 - c0);
+        g[q][c] = r0 + q < a.R ? a.grad_y[(size_t)(r0 + q) * a.C + c0 + c] : 0.f;
+    }
     __syncthreads();
     if (k >= a.K) return;
-    int j = 0;
-    for (int t = 0; t < a.T; ++t) {
-        float acc = 0.f;
-        for (; j < a.n_heads && a.trunk[j] == t; ++j) {
-            const float *w = a.weight[j] + k;
-            const float *gj = g + a.ch0[j];
-            for (int o = 0; o < a.out[j]; ++o) acc = fmaf(gj[o], w[(size_t)o * a.K], acc);
+    float acc[HR_ROWS];
+#pragma unroll
+    for (int q = 0; q < HR_ROWS; ++q) acc[q] = 0.f;
+    for (int j = j0; j < j1; ++j) {
+        const float *w = a.weight[j] + k;
+        const int cb = a.ch0[j] - c0;
+        for (int o = 0; o < a.out[j]; ++o) {
+            const float wv = w[(size_t)o * a.K];
+#pragma unroll
+            for (int q = 0; q < HR_ROWS; ++q) acc[q] = fmaf(g[q][cb + o], wv, acc[q]);
         }
-        a.grad_feat[((size_t)t * a.R + r) * a.K + k] = acc;
     }
+#pragma unroll
+    for (int q = 0; q < HR_ROWS; ++q)
+        if (r0 + q < a.R) a.grad_feat[((size_t)t * a.R + r0 + q) * a.K + k] = acc[q];
 }
 
 // weight / bias gradient: one workgroup per output channel, thread = k, rows in order (reproducible)
@@ -1062,7 +1076,7 @@ int dcd_head_rows_backward(void *stream_, const dcd_head_rows_args *a)
     if (!head_rows_ok(a) || !a->grad_y || !a->grad_feat) return DCD_ERR_BAD_ARG;
     for (int j = 0; j < a->n_heads; ++j)
         if (!a->grad_weight[j]) return DCD_ERR_BAD_ARG;
-    if (a->R > 0) hipLaunchKernelGGL(head_rows_bwd_feat_kernel, dim3(a->R), dim3(256), 0, stream, *a);
+    if (a->R > 0) hipLaunchKernelGGL(head_rows_bwd_feat_kernel, dim3((a->R + HR_ROWS - 1) / HR_ROWS, a->T), dim3(256), 0, stream, *a);
     hipLaunchKernelGGL(head_rows_bwd_weight_kernel, dim3(a->C), dim3(256), 0, stream, *a);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
