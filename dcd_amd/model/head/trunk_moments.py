@@ -227,22 +227,29 @@ def patch_moments(x, positions=None):
     # top / left band's (a mirrored axis turns d into -d along it: the result is mirrored back).
     rows = torch.stack((T, Bt.flip(2)))                                                         # (2,B,C,3,W), strip row = index 0
     nbr = F.pad(rows, (2, 2, 2, 0))                                                             # rows -2..2 around the strip row
-    row_t = torch.einsum('sbcx,sbkijx->sijck', rows[:, :, :, 0, :], nbr.unfold(4, W, 1))        # (2,5,5,C,C): [band, dy, dx]
+    # (one index per tensor and `unbind` for pairs: every separate integer index is a zero-filled tensor, a copy and an
+    # accumulation in the backward)
+    strip_rows = rows[:, :, :, 0, :]                                                            # (2,B,C,W)
+    row_t = torch.einsum('sbcx,sbkijx->sijck', strip_rows, nbr.unfold(4, W, 1))                 # (2,5,5,C,C): [band, dy, dx]
     cols = torch.stack((Lb, Rb.flip(3)))                                                        # (2,B,C,H,3), strip column = index 0
     nbc = F.pad(cols, (2, 0, 2, 2))
     col_t = torch.einsum('sbcy,sbkijy->sijck', cols[:, :, :, :, 0], nbc.unfold(3, H, 1))        # (2,5(dy),5(dx),C,C)
     # corners: the strip row's first / last pixel against its 5x5 neighbourhood
-    cor_l = torch.einsum('sbc,sbkij->sijck', rows[:, :, :, 0, 0], nbr[..., 0:5])                # column 0:    (top-left, bottom-left)
-    cor_r = torch.einsum('sbc,sbkij->sijck', rows[:, :, :, 0, W - 1], nbr[..., W - 1:W + 4])    # column W-1:  (top-right, bottom-right)
-    top_row, bot_row = row_t[0], row_t[1].flip(0)
-    left_col, right_col = col_t[0], col_t[1].flip(1)
-    strips = torch.stack((bot_row, top_row, right_col, left_col, cor_r[1].flip(0), cor_l[1].flip(0), cor_r[0], cor_l[0])).reshape(8, 25, C, C)
+    cor_l = torch.einsum('sbc,sbkij->sijck', strip_rows[..., 0], nbr[..., 0:5])                 # column 0:    (top-left, bottom-left)
+    cor_r = torch.einsum('sbc,sbkij->sijck', strip_rows[..., W - 1], nbr[..., W - 1:W + 4])     # column W-1:  (top-right, bottom-right)
+    top_row, bot_row = row_t.unbind(0)
+    left_col, right_col = col_t.unbind(0)
+    cor_l_top, cor_l_bot = cor_l.unbind(0)
+    cor_r_top, cor_r_bot = cor_r.unbind(0)
+    strips = torch.stack((bot_row.flip(0), top_row, right_col.flip(1), left_col, cor_r_bot.flip(0), cor_l_bot.flip(0), cor_r_top,
+                          cor_l_top)).reshape(8, 25, C, C)
     corr = (Mk @ strips.view(8, -1)).view(9, 25, C, C)
     Gt = (R25.unsqueeze(0) - corr)[torch.arange(9, device=x.device).view(9, 1), E]            # (9, 9, C, C): [t, t', c, c']
     G = Gt.permute(2, 0, 3, 1).reshape(9 * C, 9 * C)
     # S1[c,t] = sum over u in the image minus the row / column tap t never reads (+ the corner counted twice)
-    sums = torch.stack((Bt[:, :, 2, :].sum((0, 2)), T[:, :, 0, :].sum((0, 2)), Rb[:, :, :, 2].sum((0, 2)), Lb[:, :, :, 0].sum((0, 2)),
-                        Bt[:, :, 2, W - 1].sum(0), Bt[:, :, 2, 0].sum(0), T[:, :, 0, W - 1].sum(0), T[:, :, 0, 0].sum(0)))   # (8, C)
+    bot_line, top_line = Bt[:, :, 2, :].sum(0), T[:, :, 0, :].sum(0)                            # (C, W): outermost rows, summed over the batch
+    sums = torch.stack((bot_line.sum(1), top_line.sum(1), Rb[:, :, :, 2].sum((0, 2)), Lb[:, :, :, 0].sum((0, 2)),
+                        bot_line[:, W - 1], bot_line[:, 0], top_line[:, W - 1], top_line[:, 0]))                            # (8, C)
     S1 = (total.view(1, C) - Mk @ sums).t().reshape(9 * C)
     return S1, G, P
 
@@ -292,8 +299,9 @@ def trunks_at(x, trunks, centers, extra=None, stacked=False):
         import torch.distributed.nn.functional as distf
         sums = distf.all_reduce(sums, group=group)
         n = n * dist.get_world_size(group)
-    mean = sums[..., 0] / n
-    var = (sums[..., 1] / n - mean * mean).clamp_min(0)
+    sum_y, sum_yy = sums.unbind(-1)
+    mean = sum_y / n
+    var = (sum_yy / n - mean * mean).clamp_min(0)
     gamma = torch.stack([t[1].weight for t in trunks]).double()
     beta = torch.stack([t[1].bias for t in trunks]).double()
     eps = trunks[0][1].eps
