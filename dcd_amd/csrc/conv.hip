@@ -226,11 +226,9 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             rin[k] = zero4;
             if (sv_[k] && sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * WN_Q) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
         }
-#ifndef WN_A_GLOBAL
         const float *wsrc = ul_z + (size_t)ck * WN_U;
 #pragma unroll
         for (int k = 0; k < KW; ++k) rw[k] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * (tid + WN_NT * k));
-#endif
     };
     auto commit = [&](float *buf) {
 #pragma unroll
@@ -239,24 +237,9 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
                 float *d = buf + sl[k];                       // odd plane stride: dword stores
                 d[0] = rin[k].x; d[1] = rin[k].y; d[2] = rin[k].z; d[3] = rin[k].w;
             }
-#ifndef WN_A_GLOBAL
 #pragma unroll
         for (int k = 0; k < KW; ++k) *reinterpret_cast<f32x4 *>(buf + WN_IN + 4 * (tid + WN_NT * k)) = rw[k];
-#endif
     };
-#ifdef WN_A_GLOBAL
-    // experiment: the A operands (transformed weights) straight from L2 into registers, one chunk ahead; LDS holds the window only
-    f32x4 na0[4], na1[4], ga0[4], ga1[4];
-    auto load_a = [&](int ck, f32x4 (&x0)[4], f32x4 (&x1)[4]) {
-        const float *ug = ul_z + (size_t)ck * WN_U + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) {
-            x0[nu] = *reinterpret_cast<const f32x4 *>(ug + (nu * WN_KS) * 8);
-            if (NB == 2) x1[nu] = *reinterpret_cast<const f32x4 *>(ug + (nu * WN_KS + 32) * 8);
-        }
-    };
-    load_a(ck0, ga0, ga1);
-#endif
 
     f32x16 acc[4][NB];
 #pragma unroll
@@ -275,21 +258,15 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #ifndef WN_ABL_NOSTAGE
         if (ck + 1 < ck1) issue(ck + 1);
 #endif
+        const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
         // A operands of the chunk: 4 nu x 2 output blocks x 4 channel steps
         f32x4 a0[4], a1[4];
-#ifdef WN_A_GLOBAL
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) { a0[nu] = ga0[nu]; a1[nu] = ga1[nu]; }
-        if (ck + 1 < ck1) load_a(ck + 1, na0, na1);
-#else
-        const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             a0[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
             if (NB == 2) a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
         }
-#endif
         // software pipeline over the four channel steps: the eight LDS values of step s+1 are requested before the eight
         // MFMAs of step s are issued (in-order issue: otherwise their latency is exposed once the matrix pipe drains)
         float qa[4], qb[4];
@@ -322,10 +299,6 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
         }
 #ifndef WN_ABL_NOSTAGE
         if (ck + 1 < ck1) commit(lds + ((ck + 1 - ck0) & 1) * WN_BUF);
-#endif
-#ifdef WN_A_GLOBAL
-#pragma unroll
-        for (int nu = 0; nu < 4; ++nu) { ga0[nu] = na0[nu]; ga1[nu] = na1[nu]; }
 #endif
         __syncthreads();
     }
