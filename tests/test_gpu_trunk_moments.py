@@ -46,3 +46,27 @@ def test_moments_equal_patch_matrix_form(cuda, monkeypatch):
     S1b, Gb, _ = TM.patch_moments(x)
     assert (S1a - S1b).abs().max().item() <= 1e-3
     assert (Ga - Gb).abs().max().item() <= 2e-5 * Gb.abs().max().item()
+
+
+@pytest.mark.parametrize("shift,bound", [(0.0, 2e-6), (1.74, 1e-3), (17.4, 2e-2)])
+def test_batch_variance_error_with_a_dc_component(cuda, monkeypatch, shift, bound):
+    """w^T G w / n - mean^2 is a cancellation form and G is accumulated in fp32 pieces of ~2000 products (advisor, round 2): the
+    relative error of the batch variance grows LINEARLY with the input's mean / std.  Measured at 8 x 64 x 96 x 320
+    (tools/scratch/trunk_dc_error.py): 9e-8 at 0.7 (what a ReLU output has), 1.3e-4 at 1.7, 3.8e-4 at 3.7, 1.1e-3 at 10, 3.7e-3 at 30.
+    This test pins that curve from above on a smaller map, against the dense convolution's statistics in float64."""
+    from torch.nn import functional as F
+    from dcd_amd.model.head import trunk_moments as TM
+    torch.manual_seed(0)
+    B, C, H, W, O = 2, 64, 48, 80, 64
+    w = (torch.randn(O, C, 3, 3) / (C * 9) ** 0.5).to(cuda)
+    x = torch.relu(torch.randn(B, C, H, W, device=cuda)) + shift
+    y = F.conv2d(x.double(), w.double(), padding=1)
+    var_ref = y.var(dim=(0, 2, 3), unbiased=False)
+    monkeypatch.setenv("DCD_TRUNK_GRAM", "shift")
+    S1, G, _ = TM.patch_moments(x)
+    Wd = w.reshape(O, -1).double()
+    n = B * H * W
+    mean = (Wd @ S1) / n
+    var = ((Wd @ G) * Wd).sum(-1) / n - mean * mean
+    rel = ((var - var_ref).abs() / var_ref).max().item()
+    assert rel <= bound, (shift, rel)
