@@ -60,3 +60,23 @@ def test_row_kernel_rejects_a_channel_map_that_does_not_cover_the_heads(cuda):
     a.B, a.M, a.C, a.K, a.NP, a.num_classes = 1, 4, 415, 73, 1500, 3
     st = _lib.lib().dcd_loss_rows_forward(None, a)
     assert st == 1
+
+
+def test_batch_without_any_object_trains_on_the_heat_map_only(cuda, monkeypatch):
+    """No annotated object in the batch: the per-object losses are exactly 0 with zero gradient w.r.t. the head outputs, the
+    heat-map loss and its gradient are unaffected, nothing is non-finite (the op-by-op form divides by the zero depth target of
+    slot 0 in a logging column; the kernel never forms that quotient for an empty slot)."""
+    monkeypatch.setenv("DCD_LOSS_ROWS", "0")
+    host_loss, tv, pois = _rows_inputs()
+    tv = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tv.items()}
+    tv['reg_mask'].zero_()
+    preds, targets = gi.loss_inputs()
+    hm, _ = host_loss.prepare_targets(targets)
+    loss_dict, log, gp, gc = _losses(cuda, monkeypatch, "1", tv, pois, torch.from_numpy(preds["cls"]), hm)
+    for k in LOSS_KEYS:
+        v = float(loss_dict[k])
+        assert v == v and abs(v) != float("inf"), k
+        if k != "hm_loss":
+            assert v == 0.0, (k, v)
+    assert float(loss_dict["hm_loss"]) > 0
+    assert (gp == 0).all() and torch.isfinite(gc).all() and gc.abs().max().item() > 0

@@ -167,3 +167,15 @@ def test_column_names_are_the_same_in_both_evaluations(cpu_backend):
     finally:
         ops.loss_rows = orig
     assert ix == ix_fused
+
+
+def test_batch_without_any_object_gives_zero_columns_and_zero_gradients(cpu_backend, host_rows):
+    """No annotated object in the whole batch (the reference would index an empty list): every slot is empty, reads slot 0's
+    all-zero targets (depth 0, zero-size box) and must still produce finite arithmetic -- all 25 columns 0, gradients 0."""
+    loss, tv, pois = _rows_inputs()
+    tv = {k: (v.clone() if torch.is_tensor(v) else v) for k, v in tv.items()}
+    tv['reg_mask'].zero_()
+    gs = torch.ones(25)
+    sums, gpois, _ = _run_host(host_rows, loss, tv, pois, gs)
+    assert torch.isfinite(sums).all() and (sums == 0).all()
+    assert (gpois == 0).all()
