@@ -24,6 +24,7 @@
 
 #include "../../include/dcd_hip.h"
 #include "lds_limit.h"
+#include "bf16_split.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
 typedef float f32x4 __attribute__((ext_vector_type(4)));
@@ -341,6 +342,242 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
                     }
                     if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2 + r0.x, b0 + b1 + b2 + r0.y};
                     if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3 + r1.x, b1 - b2 - b3 + r1.y};
+                }
+            }
+        }
+        __syncthreads();
+    }
+}
+
+// ---------------------------------------------------------------------------------------------------------------------------
+// Split-bf16 form of the same kernel (DCD_PREC_BF16X3 for the 3x3 convolutions): the sixteen Winograd-domain products of a chunk
+// run on v_mfma_f32_32x32x16_bf16 with split operands (bf16_split.h): 16 input channels per chunk, 3 x 8 matrix instructions of 32
+// cycles per wave and chunk where the fp32 form issues 64 of 64 -- and the lanes' transform work (now also the splits of the
+// transformed input values) overlaps with them, which it cannot do with fp32 MFMAs on this part.
+//   * window: as the fp32 kernel's, 16 channels, ONE buffer (committed between two barriers);
+//   * weights: prepared in split form (wino_prep_weights_split) in exactly the order the lanes read them,
+//     us[z][chunk][pos 16][ob NB][hi|lo][lane 64][4 dwords], so a chunk's slab is a straight copy: global_load_lds (16 bytes per
+//     lane, no staging registers) into one of TWO LDS buffers, issued a chunk ahead;
+//   * lane = (tile l & 31, channel parity l >> 5): the lane's eight k-slots of an instruction are the channels 2 i + parity,
+//     i = 0..7, of the chunk (the weights are prepared in the same order), so the two lane halves read planes of opposite bank
+//     parity exactly like the fp32 kernel;
+//   * region geometry <2,16> only (the 12 x 20 px regions' window does not fit beside two 64 KB weight buffers).
+constexpr int WS_CH = 16;
+
+template <int NB>
+__global__ void wino_prep_weights_split(const float *__restrict__ w, unsigned *__restrict__ us, int Cc, int Kk, int mode, int nchunk,
+                                        int nz)
+{
+    constexpr int KS = 32 * NB;
+    const int n = nz * nchunk * KS * 2 * 4;                       // one thread per (z, chunk, kk, parity, dword): 16 positions x (hi, lo)
+    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+        int r = idx;
+        const int d = r & 3; r >>= 2;
+        const int h = r & 1; r >>= 1;
+        const int kk = r % KS; r /= KS;
+        const int ck = r % nchunk, z = r / nchunk;
+        const int k = z * KS + kk;
+        float u[2][16];
+#pragma unroll
+        for (int e = 0; e < 2; ++e) {
+            const int c = ck * WS_CH + 2 * (2 * d + e) + h;
+            float g[3][3];
+#pragma unroll
+            for (int a = 0; a < 3; ++a)
+#pragma unroll
+                for (int b = 0; b < 3; ++b) {
+                    float v = 0.f;
+                    if (k < Kk && c < Cc)
+                        v = mode == 0 ? w[(((size_t)k * Cc + c) * 3 + a) * 3 + b] : w[(((size_t)c * Kk + k) * 3 + (2 - a)) * 3 + (2 - b)];
+                    g[a][b] = v;
+                }
+            float t[4][3];
+#pragma unroll
+            for (int b = 0; b < 3; ++b) {
+                t[0][b] = g[0][b];
+                t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
+                t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
+                t[3][b] = g[2][b];
+            }
+#pragma unroll
+            for (int xi = 0; xi < 4; ++xi) {
+                u[e][xi * 4 + 0] = t[xi][0];
+                u[e][xi * 4 + 1] = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]);
+                u[e][xi * 4 + 2] = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]);
+                u[e][xi * 4 + 3] = t[xi][2];
+            }
+        }
+        const int ob = kk >> 5, lane = h * 32 + (kk & 31);
+        unsigned *dst = us + (size_t)(z * nchunk + ck) * (16 * NB * 2 * 256);
+#pragma unroll
+        for (int pos = 0; pos < 16; ++pos) {
+            unsigned hi, lo;
+            sp_split_pair(u[0][pos], u[1][pos], hi, lo);
+            dst[((pos * NB + ob) * 2 + 0) * 256 + lane * 4 + d] = hi;
+            dst[((pos * NB + ob) * 2 + 1) * 256 + lane * 4 + d] = lo;
+        }
+    }
+}
+
+template <int NB>
+__global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restrict__ x, const unsigned *__restrict__ us, float *y,
+                                                            float *__restrict__ part, const float *__restrict__ bias,
+                                                            const float *residual, int Cc, int H, int W, int Kk, int tiles_x,
+                                                            int nchunk, int nz)
+{
+    constexpr int TR = 2, TC = 16;
+    using G = WinoGeom<TR, TC, NB>;
+    constexpr int WN_ROWS = G::ROWS, WN_RS = G::RS, WN_PLANE = G::PLANE, WN_Q = G::Q, WN_KS = G::KS;
+    constexpr int WIN = (WS_CH * WN_PLANE + 3) & ~3;                  // floats of the window buffer (16-byte multiple)
+    constexpr int WSLAB = 16 * NB * 2 * 256;                          // dwords of one weight buffer
+    extern __shared__ __attribute__((aligned(16))) float lds[];       // [WIN][2][WSLAB] (epilogue: 8 x 32 x 64 exchange)
+    float *win = lds;
+    unsigned *wbuf = reinterpret_cast<unsigned *>(lds + WIN);
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int p = lane & 31, h = lane >> 5;
+    const int xi = wave & 3, tg = wave >> 2;
+    int bx = blockIdx.x, b = blockIdx.y;
+    xcd_remap(bx, b);
+    const int ty = bx / tiles_x, tx = bx - ty * tiles_x;
+    const int r0 = ty * (4 * TR), c0 = tx * (2 * TC);
+    const int z = blockIdx.z % nz, ks = blockIdx.z / nz, ksplit = gridDim.z / nz;
+    const int ck0 = (int)((int64_t)ks * nchunk / ksplit), ck1 = (int)((int64_t)(ks + 1) * nchunk / ksplit);
+    const int HW = H * W;
+    const int trow = p / TC, tcol = p - trow * TC;
+
+    const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
+    const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
+    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
+    const int base1 = lanebase + ra * WN_RS, base2 = lanebase + rb * WN_RS;
+
+    const float *x_b = x + (size_t)b * Cc * HW;
+    const unsigned *us_z = us + (size_t)z * nchunk * WSLAB;
+
+    // ---- window staging map (chunk invariant): 16 ch x ROWS x Q dwordx4
+    constexpr int NITEM = WS_CH * WN_ROWS * WN_Q;
+    constexpr int KIN = (NITEM + WN_NT - 1) / WN_NT;                  // 4
+    int sg[KIN], sl[KIN];
+#pragma unroll
+    for (int k = 0; k < KIN; ++k) {
+        const int e = tid + WN_NT * k;
+        const int ch = e / (WN_ROWS * WN_Q), rem = e - ch * (WN_ROWS * WN_Q);
+        const int row = rem / WN_Q, q = rem - row * WN_Q;
+        const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * q;
+        const bool ok = e < NITEM && yy >= 0 && yy < H && xx >= 0 && xx < W;
+        sg[k] = ok ? ch * HW + yy * W + xx : -1;
+        sl[k] = e < NITEM ? ch * WN_PLANE + row * WN_RS + 4 * q : -1;
+    }
+    f32x4 rin[KIN];
+    auto issue_in = [&](int ck) {
+        const float *src = x_b + (size_t)ck * WS_CH * HW;
+        const int cleft = Cc - ck * WS_CH;
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+            rin[k] = zero4;
+            if (sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * WN_Q) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
+        }
+    };
+    auto commit_in = [&]() {
+#pragma unroll
+        for (int k = 0; k < KIN; ++k)
+            if (sl[k] >= 0) {
+                float *d = win + sl[k];                       // odd plane stride: dword stores
+                d[0] = rin[k].x; d[1] = rin[k].y; d[2] = rin[k].z; d[3] = rin[k].w;
+            }
+    };
+    // weight slab of chunk ck -> buffer `buf`: straight copy, 16 bytes per lane per instruction, LDS address = wave base + 16 lane
+    auto issue_w = [&](int ck, int buf) {
+        const unsigned *src = us_z + (size_t)ck * WSLAB + tid * 4;
+        unsigned *dst = wbuf + buf * WSLAB + wave * 256;
+#pragma unroll
+        for (int q = 0; q < WSLAB / (WN_NT * 4); ++q)
+            __builtin_amdgcn_global_load_lds(src + q * (WN_NT * 4), (__attribute__((address_space(3))) void *)(dst + q * (WN_NT * 4)), 16, 0, 0);
+    };
+
+    f32x16 acc[4][NB];
+#pragma unroll
+    for (int nu = 0; nu < 4; ++nu)
+#pragma unroll
+        for (int mb = 0; mb < NB; ++mb)
+#pragma unroll
+            for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.f;
+
+    issue_w(ck0, 0);
+    issue_in(ck0);
+    commit_in();
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+
+    for (int ck = ck0; ck < ck1; ++ck) {
+        const int cur = (ck - ck0) & 1;
+        const bool more = ck + 1 < ck1;
+        if (more) {
+            issue_w(ck + 1, cur ^ 1);
+            issue_in(ck + 1);
+        }
+        const unsigned *wl = wbuf + cur * WSLAB + lane * 4;
+        const float *cp1 = win + base1, *cp2 = win + base2;
+        // transformed input of the lane's eight channels (2 i + parity): row transform, then the four column combinations
+        float vv[4][8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+            const float *q1 = cp1 + 2 * i * WN_PLANE, *q2 = cp2 + 2 * i * WN_PLANE;
+            const float t0 = sa * q1[0] + sb * q2[0], t1 = sa * q1[1] + sb * q2[1];
+            const float t2 = sa * q1[2] + sb * q2[2], t3 = sa * q1[3] + sb * q2[3];
+            vv[0][i] = t0 - t2; vv[1][i] = t1 + t2; vv[2][i] = t2 - t1; vv[3][i] = t1 - t3;
+        }
+#pragma unroll
+        for (int nu = 0; nu < 4; ++nu) {
+            const SpSplit8 bo = sp_split8(vv[nu]);
+#pragma unroll
+            for (int ob = 0; ob < NB; ++ob) {
+                const unsigned *wa = wl + (((xi * 4 + nu) * NB + ob) * 2) * 256;
+                const sp_bf16x8 ah = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa));
+                const sp_bf16x8 al = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa + 256));
+                acc[nu][ob] = sp_mfma_x3(ah, al, bo, acc[nu][ob]);
+            }
+        }
+        __syncthreads();                                      // every wave is done with the window
+        if (more) commit_in();
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");     // the next chunk's weights have landed
+        __syncthreads();
+    }
+
+    // ---- output transform: identical to the fp32 kernel's
+    float *ex = lds;
+    float *y_b = (ks == 0 ? y : part + (size_t)(ks - 1) * gridDim.y * Kk * HW) + (size_t)b * Kk * HW;
+    const float *r_b = (residual && ks == 0) ? residual + (size_t)b * Kk * HW : nullptr;
+    const int orow0 = r0 + 2 * TR * tg + 2 * trow, ocol = c0 + 2 * tcol;
+#pragma unroll
+    for (int mb = 0; mb < NB; ++mb) {
+        float *mine = ex + (size_t)wave * 32 * 64 + lane;
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+            mine[r * 64] = acc[0][mb][r] + acc[1][mb][r] + acc[2][mb][r];
+            mine[(16 + r) * 64] = acc[1][mb][r] - acc[2][mb][r] - acc[3][mb][r];
+        }
+        __syncthreads();
+        const float *t0 = ex + (size_t)(tg * 4 + 0) * 32 * 64 + lane, *t1 = t0 + 32 * 64, *t2 = t1 + 32 * 64, *t3 = t2 + 32 * 64;
+        if (ocol < W) {
+#pragma unroll
+            for (int rr = 0; rr < 4; ++rr) {
+                const int r = 4 * xi + rr;
+                const int k = z * WN_KS + mb * 32 + (r & 3) + 8 * (r >> 2) + 4 * h;
+                const float a0 = t0[r * 64], a1 = t1[r * 64], a2 = t2[r * 64], a3 = t3[r * 64];
+                const float b0 = t0[(16 + r) * 64], b1 = t1[(16 + r) * 64], b2 = t2[(16 + r) * 64], b3 = t3[(16 + r) * 64];
+                if (k < Kk) {
+                    const float bk = (bias && ks == 0) ? bias[k] : 0.f;
+                    const size_t o = (size_t)k * HW + (size_t)orow0 * W + ocol;
+                    float *dst = y_b + o;
+                    f32x2 q0 = {bk, bk}, q1 = {bk, bk};
+                    if (r_b) {
+                        if (orow0 < H) q0 += *reinterpret_cast<const f32x2 *>(r_b + o);
+                        if (orow0 + 1 < H) q1 += *reinterpret_cast<const f32x2 *>(r_b + o + W);
+                    }
+                    if (orow0 < H) *reinterpret_cast<f32x2 *>(dst) = f32x2{a0 + a1 + a2 + q0.x, b0 + b1 + b2 + q0.y};
+                    if (orow0 + 1 < H) *reinterpret_cast<f32x2 *>(dst + W) = f32x2{a1 - a2 - a3 + q1.x, b1 - b2 - b3 + q1.y};
                 }
             }
         }
@@ -669,6 +906,44 @@ static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *inpu
     return DCD_OK;
 }
 
+template <int NB>
+static int conv_launch_split(hipStream_t stream, const ConvPlan &pl, const float *input, const unsigned *us, float *output, float *part,
+                             const float *bias, const float *residual, int B, int Cc, int H, int W, int Kk)
+{
+    static LdsLimit lds_limit;
+    using G = WinoGeom<2, 16, NB>;
+    const size_t ldsb = ((size_t)((WS_CH * G::PLANE + 3) & ~3) + (size_t)2 * 16 * NB * 2 * 256) * sizeof(float);
+    if (!lds_limit.raise((int)ldsb, wino_conv3x3_split<NB>)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino_conv3x3_split<NB>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream, input,
+                       us, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    return DCD_OK;
+}
+
+// split-bf16 form: 8 x 32 px regions, chunks of 16 channels; the contraction is split while CUs would idle and a split keeps two chunks
+static ConvPlan conv_plan_split(int B, int Cc, int H, int W, int Kk)
+{
+    ConvPlan p;
+    p.geom = 0;
+    p.tiles_x = (W + 31) / 32;
+    p.tiles_y = (H + 7) / 8;
+    p.nchunk = (Cc + WS_CH - 1) / WS_CH;
+    p.nb = Kk <= 32 ? 1 : 2;
+    p.nz = (Kk + 32 * p.nb - 1) / (32 * p.nb);
+    const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
+    const int cus = device_cus();
+    int ks = 1;
+    while (ks < 8 && wgs * (ks * 2) <= cus && p.nchunk / (ks * 2) >= 2) ks *= 2;
+    p.ksplit = ks;
+    return p;
+}
+
+static size_t tw_dwords_split(int Cin, int Cout, int backward_data)
+{
+    const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
+    const int nb = Kk <= 32 ? 1 : 2;
+    return (size_t)((Cc + WS_CH - 1) / WS_CH) * ((Kk + 32 * nb - 1) / (32 * nb)) * 16 * nb * 2 * 256;
+}
+
 extern "C" {
 
 size_t dcd_conv3x3_workspace_bytes(int B, int Cin, int H, int W, int Cout)
@@ -781,6 +1056,62 @@ int dcd_conv3x3_prepared(void *stream_, const float *input, const float *transfo
 {
     return conv3x3_run((hipStream_t)stream_, input, transformed, 1, bias, residual, output, B, Cin, H, W, Cout, backward_data, workspace,
                        workspace_bytes);
+}
+
+size_t dcd_conv3x3_split_weights_bytes(int Cin, int Cout, int backward_data)
+{
+    return Cin > 0 && Cout > 0 ? tw_dwords_split(Cin, Cout, backward_data) * sizeof(unsigned) : 0;
+}
+
+int dcd_conv3x3_split_transform_weights(void *stream_, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!weight || Cin <= 0 || Cout <= 0 || (!forward_out && !backward_out)) return DCD_ERR_BAD_ARG;
+    for (int mode = 0; mode < 2; ++mode) {
+        unsigned *dst = (unsigned *)(mode ? backward_out : forward_out);
+        if (!dst) continue;
+        const int Cc = mode ? Cout : Cin, Kk = mode ? Cin : Cout;
+        const int nb = Kk <= 32 ? 1 : 2, nchunk = (Cc + WS_CH - 1) / WS_CH, nz = (Kk + 32 * nb - 1) / (32 * nb);
+        const int n = nz * nchunk * 32 * nb * 8;
+        const int grid = (n + 255) / 256 < 4096 ? (n + 255) / 256 : 4096;
+        if (nb == 2) hipLaunchKernelGGL(wino_prep_weights_split<2>, dim3(grid), dim3(256), 0, stream, weight, dst, Cc, Kk, mode, nchunk, nz);
+        else hipLaunchKernelGGL(wino_prep_weights_split<1>, dim3(grid), dim3(256), 0, stream, weight, dst, Cc, Kk, mode, nchunk, nz);
+    }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout)
+{
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    const ConvPlan f = conv_plan_split(B, Cin, H, W, Cout), d = conv_plan_split(B, Cout, H, W, Cin);
+    const size_t pf = (size_t)(f.ksplit - 1) * B * Cout * H * W, pd = (size_t)(d.ksplit - 1) * B * Cin * H * W;
+    return (pf > pd ? pf : pd) * sizeof(float) + 16;
+}
+
+int dcd_conv3x3_split_prepared(void *stream_, const float *input, const void *transformed, const float *bias, const float *residual,
+                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                               size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!input || !transformed || !output || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31) || (bias && backward_data)) return DCD_ERR_BAD_ARG;
+    const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
+    const ConvPlan pl = conv_plan_split(B, Cc, H, W, Kk);
+    const size_t img = (size_t)B * Kk * H * W;
+    const size_t need = (size_t)(pl.ksplit - 1) * img * sizeof(float);
+    if (need && (!workspace || workspace_bytes < need)) return DCD_ERR_WORKSPACE;
+    float *part = (float *)workspace;
+    const int st = pl.nb == 2 ? conv_launch_split<2>(stream, pl, input, (const unsigned *)transformed, output, part, bias, residual, B, Cc, H, W, Kk)
+                              : conv_launch_split<1>(stream, pl, input, (const unsigned *)transformed, output, part, bias, residual, B, Cc, H, W, Kk);
+    if (st != DCD_OK) return st;
+    if (pl.ksplit > 1) {
+        const size_t n4 = img / 4;
+        const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wino_sum_partials, dim3(nb), dim3(256), 0, stream, output, (const float *)part, n4, pl.ksplit - 1);
+    }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
 static void wrw_partition(int B, int Cin, int H, int W, int Cout, int &nog, int &ncg, int &S, int &strips_x, int &KO)

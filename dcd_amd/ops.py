@@ -737,10 +737,39 @@ def conv3x3_supported(x, weight):
             and x.shape[2] * x.shape[3] >= _CONV_MIN_MAP)
 
 
-def conv3x3_transform_weights(weight, forward=True, backward=True):
-    """Winograd-domain weights of a (Cout, Cin, 3, 3) filter for the forward and / or the backward-data call, ONE launch."""
+_CONV_SPLIT_MIN_MAP = int(os.environ.get("DCD_CONV_SPLIT_MIN_MAP", "7680"))
+
+
+def _conv_split(like=None):
+    """Split-bf16 products for the 3x3 convolutions: `_ext.set_precision("bf16x3")` (what `bench.py --precision bf16x3` sets) unless
+    DCD_CONV_SPLIT=0 keeps them exact fp32 (A/B timing).  like: the call's input -- the split kernel has the 8 x 32 px regions
+    only and pays from 48 x 160 maps on (64->64 @ 96x320 123 -> 83 us, 128->128 @ 48x160 101 -> 69; 256->256 @ 24x80 95 -> 120:
+    those stay on the fp32 kernel with its exact-cover 12 x 20 regions)."""
+    from . import _ext
+    if _ext.get_precision() != "bf16x3" or os.environ.get("DCD_CONV_SPLIT", "1") == "0":
+        return False
+    return like is None or like.shape[2] * like.shape[3] >= _CONV_SPLIT_MIN_MAP
+
+
+class SplitWeights:
+    """Winograd-domain weights in split-bf16 layout (dcd_conv3x3_split_transform_weights); a marker type so that the call knows
+    which kernel they belong to."""
+
+    def __init__(self, tensor):
+        self.tensor = tensor
+
+
+def conv3x3_transform_weights(weight, forward=True, backward=True, like=None):
+    """Winograd-domain weights of a (Cout, Cin, 3, 3) filter for the forward and / or the backward-data call, ONE launch
+    (split-bf16 form: one launch per direction).  like: the tensor the convolution will run on (decides the form, see _conv_split)."""
     L = _lib.lib()
     Co, Ci = weight.shape[0], weight.shape[1]
+    if _conv_split(like):
+        tf = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device) if forward else None
+        tb = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device) if backward else None
+        _lib.check(L.dcd_conv3x3_split_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
+                   "dcd_conv3x3_split_transform_weights")
+        return (SplitWeights(tf) if forward else None), (SplitWeights(tb) if backward else None)
     tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device) if forward else None
     tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device) if backward else None
     _lib.check(L.dcd_conv3x3_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
@@ -760,6 +789,16 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
         out = residual
     else:
         out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
+    if transformed is None and _conv_split(inp):
+        transformed = conv3x3_transform_weights(weight, not backward_data, backward_data, like=inp)[1 if backward_data else 0]
+    if isinstance(transformed, SplitWeights):
+        n = L.dcd_conv3x3_split_workspace_bytes(B, Ci, H, W, Co)
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=inp.device)
+        st = L.dcd_conv3x3_split_prepared(_lib.stream_of(inp), inp.data_ptr(), transformed.tensor.data_ptr(), _lib.ptr(bias),
+                                          _lib.ptr(residual), out.data_ptr(), B, Ci, H, W, Co, 1 if backward_data else 0,
+                                          ws.data_ptr(), n)
+        _lib.check(st, "dcd_conv3x3_split_prepared")
+        return out
     n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
     if transformed is not None:
         n = max(n - min(L.dcd_conv3x3_weights_bytes(Ci, Co, 0), L.dcd_conv3x3_weights_bytes(Ci, Co, 1)), 0)   # partial images only (upper bound)
@@ -805,7 +844,7 @@ class _Conv3x3(torch.autograd.Function):
         ctx.tw_back = None
         if _PREP_BOTH and ctx.needs_input_grad[0]:
             # the weights of this call and of its backward-data call in one launch (they do not change in between)
-            tw, ctx.tw_back = conv3x3_transform_weights(weight)
+            tw, ctx.tw_back = conv3x3_transform_weights(weight, like=x)
             return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw)
         return _conv3x3_call(x, weight, weight.shape[0], False)
 

@@ -406,6 +406,18 @@ int dcd_conv3x3_prepared(void *stream, const float *input, const float *transfor
                          float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
                          size_t workspace_bytes);
 
+/* The same convolution with the Winograd-domain products in split-bf16 (hi*hi + hi*lo + lo*hi on v_mfma_f32_32x32x16_bf16, fp32
+ * accumulate: ~2^-16 relative per product, the form DCD_PREC_BF16X3 names for the deformable convolution): transforms stay fp32,
+ * operands stay fp32 in HBM.  Weights are prepared in their own layout (dcd_conv3x3_split_weights_bytes /
+ * dcd_conv3x3_split_transform_weights: both directions, either pointer may be NULL); workspace holds the partial images of a
+ * split contraction only.  Same shape rules as dcd_conv3x3. */
+size_t dcd_conv3x3_split_weights_bytes(int Cin, int Cout, int backward_data);
+int dcd_conv3x3_split_transform_weights(void *stream, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out);
+size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int dcd_conv3x3_split_prepared(void *stream, const float *input, const void *transformed, const float *bias, const float *residual,
+                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                               size_t workspace_bytes);
+
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).

@@ -358,3 +358,37 @@ def test_conv1x1_of_cat_matches_cat_then_conv(cuda):
         _close(xg[i].grad.cpu(), xd[i].grad, "grad_input %d" % i, 1e-5)
     assert xg[2].grad is None
     _close(wg.grad.cpu(), wd.grad, "grad_weight", 2e-5)
+
+
+@pytest.mark.parametrize("B,C,K,H,W", CASES + [(2, 64, 27, 24, 64), (1, 128, 27, 12, 40)])
+def test_conv3x3_split_bf16_form(cuda, monkeypatch, B, C, K, H, W):
+    """`_ext.set_precision("bf16x3")`: forward and input gradient on wino_conv3x3_split (Winograd-domain products as
+    hi*hi + hi*lo + lo*hi on the bf16 matrix cores) against conv2d in fp64 at 1e-4 of the output scale (north_star's bound is 1e-3;
+    the split loses ~2^-16 per product), differs from the exact-fp32 kernel in the low bits (it is not the same kernel), with bias and
+    with an accumulated residual; the weight gradient stays on the fp32 kernel."""
+    from dcd_amd import _ext, ops
+    monkeypatch.setattr(ops, "_CONV_SPLIT_MIN_MAP", 0)          # the product uses this kernel from 48 x 160 maps on; here on every size
+    g = torch.Generator().manual_seed(C * 5 + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    bias = torch.randn(K, generator=g)
+    res = torch.randn(B, K, H, W, generator=g)
+    gy = torch.randn(B, K, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1) + res.double()
+    ref_gx = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    xd, wd, bd, gd = x.to(cuda), w.to(cuda), bias.to(cuda), gy.to(cuda)
+    y32 = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone())
+    _ext.set_precision("bf16x3")
+    try:
+        tf, tb = ops.conv3x3_transform_weights(wd)
+        assert isinstance(tf, ops.SplitWeights) and isinstance(tb, ops.SplitWeights)
+        y = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone(), transformed=tf)
+        gx = ops._conv3x3_call(gd, wd, C, True, transformed=tb)
+        y_unprepared = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone())
+    finally:
+        _ext.set_precision("f32")
+    _close(y.cpu(), ref, "split forward", 1e-4)
+    _close(gx.cpu(), ref_gx, "split grad_input", 1e-4)
+    assert torch.equal(y, y_unprepared)
+    assert not torch.equal(y, y32)
+    assert (y - y32).abs().max().item() <= 5e-5 * y32.abs().max().item()
