@@ -117,6 +117,20 @@ def test_whole_model_matches_reference(cuda, monkeypatch, trunk_form):
     H.check_model(cuda, 1e-4, 6e-3, truth="model_96x320_f64", loss_tol=3e-4)
 
 
+def test_whole_model_in_split_bf16_precision(cuda, monkeypatch):
+    """The same model with every split-bf16 kernel on (`_ext.set_precision("bf16x3")`: DCNv2 forward / backward incl. the dense
+    path's GEMMs, and the Winograd 3x3 convolutions on every map size) against the float64 reference run, at north_star's bound:
+    1e-3 on activations and losses (measured ~2e-5 / 1e-4), 2e-2 on the per-parameter gradient norms."""
+    from dcd_amd import _ext, ops
+    torch.backends.cudnn.benchmark = False
+    monkeypatch.setattr(ops, "_CONV_SPLIT_MIN_MAP", 0)
+    _ext.set_precision("bf16x3")
+    try:
+        H.check_model(cuda, 1e-3, 2e-2, truth="model_96x320_f64", loss_tol=1e-3)
+    finally:
+        _ext.set_precision("f32")
+
+
 def test_whole_model_close_to_reference_fp32_run(cuda):
     """Same model against the reference's fp32 CPU run: two fp32 runs each ~1.5e-5 from exact."""
     torch.backends.cudnn.benchmark = False
