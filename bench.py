@@ -20,6 +20,10 @@ One JSON line on rank 0.  Besides the driver's contract it carries
                   steps; peak = the fp32 matrix peak (the op is MFMA-bound: 196 FLOP/B).  `roofline_hbm` repeats it with
                   the algorithmic bytes against 8 TB/s (north_star's yardstick); `traffic` = HBM bytes from the PMC pass.
   cpu_baseline -- the same train step on the host cores with the CPU oracle (oracle/, "port") on a bounded sample.
+  split_bf16x3 -- (one GPU, default run only) the same job timed again with `_ext.set_precision("bf16x3")`: the DCNv2 products and the
+                  3x3 convolutions' forward / input gradient in split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32
+                  accumulate; <= 1e-4 of the output scale against the fp32 oracle, north_star's bound is 1e-3).  `value` is always
+                  the exact-fp32 run.
 """
 import argparse
 import json
