@@ -262,7 +262,9 @@ class DLASeg(nn.Module):
 
     def forward(self, x):
         x = self.dla_up(self.base(x))
-        y = [x[i].clone() for i in range(self.last_level - self.first_level)]
+        # the reference clones the three maps here (dla_dcn.py:56); IDAUp only REBINDS list entries (layers[i] = ...), it never
+        # writes into them, so the copies (110 MB at bs 8) are left out: same values, same gradients
+        y = [x[i] for i in range(self.last_level - self.first_level)]
         self.ida_up(y, 0, len(y))
         return y[-1]
 
