@@ -22,7 +22,7 @@ want = ("aten::copy_", "aten::add", "aten::add_", "aten::fill_", "aten::zero_", 
         "aten::mul", "aten::sum", "aten::_to_copy")
 agg = collections.defaultdict(lambda: [0, 0.0])
 for ev in prof.events():
-    if ev.name in want and ev.device_time_total > 0:
+    if ev.name.startswith("aten::") and ev.device_time_total > 0 and (os.environ.get("ALL") or ev.name in want):
         where = str([tuple(x) for x in (ev.input_shapes or []) if x][:3])
         k = (ev.name, where[:90])
         agg[k][0] += 1
@@ -30,5 +30,5 @@ for ev in prof.events():
 rows = sorted(agg.items(), key=lambda kv: -kv[1][1])
 tot = sum(v[1] for _, v in rows)
 print("selected ops: %.2f ms device time, %d calls" % (tot / 1e3, sum(v[0] for _, v in rows)))
-for (name, where), (n, us) in rows[:60]:
+for (name, where), (n, us) in rows[:int(os.environ.get('TOPN', '60'))]:
     print("%8.1f us %4d  %-16s %s" % (us, n, name, where))
