@@ -580,7 +580,7 @@ def _gen_build(args, device):
     return cfg, model, images, targets
 
 
-def _gen_pass(model, images, targets, torch):
+def _gen_pass(model, images, targets, torch, batched_eval=True):
     """Both halves of the pass over one batch; returns (objects written by the train half, detections of the eval half)."""
     from dcd_amd.engine.gen_data import infer_records
     lc = model.heads.loss_evaluator
@@ -595,9 +595,20 @@ def _gen_pass(model, images, targets, torch):
         n_train = sum(len(x) for x in lc.gen_data["pred_rot"])
         model.eval()
         n_det = 0
-        for i in range(images.shape[0]):
-            result, _, vis = model(images[i:i + 1], targets[i:i + 1])
-            n_det += len(infer_records(result, vis))
+        if batched_eval:
+            # The reference infers image by image (TEST.IMS_PER_BATCH = 1, DGDE/engine/inference.py:59-84) and its decode assumes one
+            # image (detector_infer.py:173,186,221).  Backbone and predictor in eval mode are per-sample independent, so they run
+            # ONCE on the batch here; the decode keeps its one-image form on slices of their outputs: same rows per image.
+            feats = model.backbone(images)
+            preds = model.heads.predictor(feats, targets)
+            for i in range(images.shape[0]):
+                one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
+                result, _, vis = model.heads.post_processor(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
+                n_det += len(infer_records(result, vis))
+        else:
+            for i in range(images.shape[0]):
+                result, _, vis = model(images[i:i + 1], targets[i:i + 1])
+                n_det += len(infer_records(result, vis))
     return n_train, n_det
 
 

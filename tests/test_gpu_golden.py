@@ -493,6 +493,18 @@ def test_generate_for_gmw_pass_full_size(cuda):
     assert (len(r["kpts_2d"]), len(r["kpts_2d"][0]), len(r["kpts_3d"][0]), len(r["box"]), len(r["dim"]), len(r["pred_location"])) == (73, 2, 3, 4, 3, 3)
     z = result[:, 11]
     assert float(z.min()) > 0.0 and float(z.max()) <= 101.0                    # decoded depths are clamped ([0.1, 100] direct, [2, 80] pair depths)
+    # the pass's eval half runs backbone + predictor once on the batch and decodes image by image on slices: same rows as the
+    # reference's one-image-at-a-time inference (eval mode is per-sample independent)
+    with torch.no_grad():
+        feats = model.backbone(images)
+        preds = model.heads.predictor(feats, targets)
+        for i in range(images.shape[0]):
+            one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
+            r_b, _, _ = model.heads.post_processor(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
+            r_1, _, _ = model(images[i:i + 1], targets[i:i + 1])
+            assert r_b.shape == r_1.shape
+            assert torch.equal(r_b[:, 0], r_1[:, 0])                                             # classes, in the same order
+            assert (r_b - r_1).abs().max().item() <= 1e-4 * max(r_1.abs().max().item(), 1.0)
 
 
 def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
