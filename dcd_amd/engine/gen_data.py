@@ -33,13 +33,10 @@ def infer_records(output, visualize_preds, cat="Car"):
     f32 = output.dtype
     packed = torch.cat((output.detach(), k2.detach().reshape(n, nk * 2).to(f32), k3.detach().reshape(n, nk * 3).to(f32)), dim=1).cpu().numpy()
     out, k2h, k3h = packed[:, :14], packed[:, 14:14 + nk * 2].reshape(n, nk, 2), packed[:, 14 + nk * 2:].reshape(n, nk, 3)
-    recs = []
-    for i in range(n):
-        recs.append({'kpts_2d': k2h[i].tolist(), 'kpts_3d': k3h[i].tolist(),
-                     'pred_rot': out[i][12:13].tolist(), 'box': out[i][2:6].tolist(),
-                     'dim': out[i][6:9].tolist(), 'pred_location': out[i][9:12].tolist(),
-                     'score': out[i][13:14].tolist(), 'cat': cat})
-    return recs
+    # three conversions for the whole image, then list slices (a `.tolist()` per field and detection was 350 calls, 3 ms per image)
+    k2l, k3l, rows = k2h.tolist(), k3h.tolist(), out.tolist()
+    return [{'kpts_2d': k2l[i], 'kpts_3d': k3l[i], 'pred_rot': rows[i][12:13], 'box': rows[i][2:6], 'dim': rows[i][6:9],
+             'pred_location': rows[i][9:12], 'score': rows[i][13:14], 'cat': cat} for i in range(n)]
 
 
 def dump_gen_data_infer(infer_data, out_dir="gen_data"):
