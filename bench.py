@@ -170,22 +170,21 @@ def run_gpu(args):
     if use_graph:
         from dcd_amd.engine.trainer import GraphedTrainStep, wrap_distributed
         graphed = GraphedTrainStep(model, optimizer, clip, distributed=data_parallel)
-        ok = True
-        try:
-            graphed(images, targets)                       # captures (after its own eager warm-up steps) and replays once
-            torch.cuda.synchronize()
-        except Exception as e:                             # noqa: BLE001 -- any failure means "use the eager step"
-            sys.stderr.write("[bench] whole-step graph unavailable (%r): eager step\n" % (e,))
-            ok = False
-        if data_parallel:
-            flag = torch.tensor([1 if ok else 0], device=device)
-            dist.all_reduce(flag, op=dist.ReduceOp.MIN)
-            ok = bool(flag.item())
+        # capture WITHOUT replaying, then one eager all-reduce of the outcome, then -- only if every rank captured -- replays.
+        # (A rank that replayed before the vote would sit in the graph's SyncBN all-reduces while a failed peer issues the
+        # 1-element flag all-reduce: mismatched collectives, a hang.  The capture itself issues none: its warm-up steps are
+        # common to all ranks and captured collectives are recorded, not run.)
+        ok = graphed.capture(images, targets)
+        if not ok:
+            sys.stderr.write("[bench] whole-step graph unavailable on rank %d (%r)\n" % (rank, graphed.capture_error))
+        ok = graphed.agree(ok)
+        if not ok:
+            sys.stderr.write("[bench] rank %d: all ranks take the eager step\n" % rank)
         if ok:
             step_launch = "one HIP graph per step" + (" (SyncBN + gradient all-reduce inside)" if data_parallel else "")
 
             def step():
-                graphed(images, targets)
+                graphed.replay(images, targets)
         else:
             use_graph = False
             if data_parallel:
@@ -362,7 +361,6 @@ def cpu_baseline_child(args):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
-    os.environ["DCD_LOSS_ROWS"] = "0"        # the loss's per-object rows op by op on the patched ops (the row kernel is HIP only)
     cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False])
     torch.manual_seed(0)
     model = KeypointDetector(cfg).train()

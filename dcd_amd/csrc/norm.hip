@@ -124,11 +124,11 @@ __global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ part
 
 // ---- per-channel sums in ONE launch (a bias gradient): the slices of bn_partial, and the block that arrives last at a
 // channel's counter adds the channel's S partials in bn_combine's order -- same value as bn_partial + bn_combine + a cast,
-// two launches fewer.  The counters are zero when the module is loaded and every last block leaves its own at zero again.
-__device__ unsigned g_channel_arrivals[65536];
-
+// two launches fewer.  The arrival counters live in the CALL's workspace (behind the partials; round 3 kept them in one
+// process-global array, which two launches on different streams would have shared: advisor r3): the caller hands them in
+// zeroed, every last block leaves its own at zero again.
 __global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict__ x, Plane g, int S, double *__restrict__ partial,
-                                                         float *__restrict__ out)
+                                                         unsigned *__restrict__ arrivals, float *__restrict__ out)
 {
     const int c = blockIdx.y, s = blockIdx.x;
     const int P = g.B * g.cpp;
@@ -154,7 +154,7 @@ __global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict
     if (threadIdx.x == 0) {
         partial[(long)c * S + s] = ds;
         __threadfence();
-        is_last = atomicAdd(&g_channel_arrivals[c], 1u) == (unsigned)(S - 1);
+        is_last = atomicAdd(&arrivals[c], 1u) == (unsigned)(S - 1);
     }
     __syncthreads();
     if (!is_last || threadIdx.x >= 64) return;
@@ -164,7 +164,7 @@ __global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict
     a = wave_sum(a);
     if (threadIdx.x == 0) {
         out[c] = (float)a;
-        g_channel_arrivals[c] = 0u;
+        arrivals[c] = 0u;
     }
 }
 
@@ -567,7 +567,9 @@ int dcd_channel_sums(void *stream_, const float *x, int B, int C, int64_t HW, fl
     if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
     const Plane g = make_plane(B, C, HW);
     const int S = slices(g);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, sums);
+    // partials: the first C * S doubles; arrival counters: C words at the start of the workspace's second half
+    unsigned *arrivals = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(ws) + (size_t)C * SMAX);
+    hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, arrivals, sums);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -118,6 +118,16 @@ def _reference_order(model, optimizer):
     return order
 
 
+def _host_state_value(key, v):
+    """A host copy of one optimizer-state entry (never the live tensor); device step counters are left for the caller's
+    single stacked copy."""
+    if not torch.is_tensor(v):
+        return v
+    if key == "step":
+        return v if v.is_cuda else v.detach().clone().to(torch.float32)
+    return v.detach().cpu().clone() if not v.is_cuda else v.detach().cpu()
+
+
 def optimizer_state_to_reference(model, optimizer):
     """Our pooled AdamW state (two groups: weights, biases) re-expressed in the reference's layout: one group per parameter in
     `named_parameters` order, state keyed by that index -- what `utils/check_point.py:31-43` saves and
@@ -130,7 +140,9 @@ def optimizer_state_to_reference(model, optimizer):
         else:
             g = {k: v for k, v in sd["param_groups"][loc[0]].items() if k != "params"}
             if loc[1] in sd["state"]:
-                state[ref_idx] = sd["state"][loc[1]]
+                # Optimizer.state_dict() hands out the LIVE per-parameter dicts: build new ones (host copies, float step
+                # counter) -- writing into them would turn the running optimizer's moments into CPU tensors (advisor r3)
+                state[ref_idx] = {k: _host_state_value(k, v) for k, v in sd["state"][loc[1]].items()}
         g["params"] = [ref_idx]
         # The reference's optimizer is the plain for-loop AdamW and adopts the saved groups verbatim after
         # torch.load(map_location=cpu) (DGDE/utils/check_point.py:138): device learning-rate tensors, `capturable` and the
@@ -142,10 +154,12 @@ def optimizer_state_to_reference(model, optimizer):
             if torch.is_tensor(g.get(k)):
                 g[k] = float(g[k])
         groups.append(g)
-    for st in state.values():
-        for k, v in list(st.items()):
-            if torch.is_tensor(v):
-                st[k] = v.detach().cpu() if k != "step" else torch.tensor(float(v), dtype=torch.float32)
+    # step counters: device tensors under capturable AdamW -> ONE stacked copy to the host instead of a sync per parameter
+    dev_steps = [(i, st["step"]) for i, st in state.items() if torch.is_tensor(st.get("step")) and st["step"].is_cuda]
+    if dev_steps:
+        host = torch.stack([t.detach().reshape(()).to(torch.float32) for _, t in dev_steps]).cpu()
+        for (i, _), v in zip(dev_steps, host):
+            state[i]["step"] = v.clone()
     return {"state": state, "param_groups": groups}
 
 
@@ -351,6 +365,8 @@ class GraphedTrainStep:
         self.distributed, self.group = distributed, group
         self._graphs = {}
         self._flat = None
+        self.capture_error = None
+        self._fail_capture = False
         if distributed:
             if isinstance(model, nn.parallel.DistributedDataParallel):
                 raise ValueError("GraphedTrainStep(distributed=True) takes the bare module (prepare_data_parallel), not a DDP wrapper")
@@ -367,16 +383,18 @@ class GraphedTrainStep:
 
     def _reduce_gradients(self):
         """grads -> flat buffer (multi-tensor copy), ONE all-reduce, mean; the parameters' .grad then ARE the flat views, so the
-        clip and the fused AdamW read the reduced values.  A parameter without a gradient in this step contributes zeros."""
+        clip and the fused AdamW read the reduced values.  A parameter that got no gradient in this step keeps `.grad = None`
+        -- the optimizer skips it, as eager DDP and the reference do (no weight decay / moment update on it; advisor r3); its
+        slice of the flat buffer stays zero.  Which parameters those are is a property of the model, the same on every rank."""
         import torch.distributed as dist
-        have = [(v, p.grad) for v, p in zip(self._dp_views, self._dp_params) if p.grad is not None]
+        have = [(v, p) for v, p in zip(self._dp_views, self._dp_params) if p.grad is not None]
         if len(have) != len(self._dp_params):
             self._flat.zero_()
-        torch._foreach_copy_([v for v, _ in have], [g for _, g in have])
+        torch._foreach_copy_([v for v, _ in have], [p.grad for _, p in have])
         dist.all_reduce(self._flat, group=self.group)
         if self._world > 1:
             self._flat.mul_(1.0 / self._world)
-        for v, p in zip(self._dp_views, self._dp_params):
+        for v, p in have:
             p.grad = v
 
     @staticmethod
@@ -449,22 +467,40 @@ class GraphedTrainStep:
         for m in self.model.modules():                   # the loss section's own graphs would nest inside this one
             if hasattr(getattr(m, "loss_evaluator", None), "use_graph"):
                 m.loss_evaluator.use_graph = False
+        on_gpu = st_images.is_cuda
         model_state = copy.deepcopy(self.model.state_dict())
         saved = {id(p): {k: (v.clone() if torch.is_tensor(v) else v) for k, v in st.items()} for p, st in self.optimizer.state.items()}
-        side = torch.cuda.Stream()
-        side.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(side):
-            for _ in range(max(self.warmup, 3 if self.distributed else 1)):     # >= 1: the optimizer's state tensors must exist before the
-                self._eager(st_images, st_targets)                                # capture; collectives: communicators set up eagerly first
-        torch.cuda.current_stream().wait_stream(side)
-        self.model.load_state_dict(model_state)            # in place: parameters and BN buffers keep their storage
-        with torch.no_grad():
-            for p_, st in self.optimizer.state.items():    # in place too: the graph will address these very tensors
-                old = saved.get(id(p_))
-                for k, v in st.items():
-                    if torch.is_tensor(v):
-                        v.copy_(old[k]) if old is not None and k in old else v.zero_()
-        self.optimizer.zero_grad(set_to_none=True)
+        try:
+            # warm-up: every rank runs the same eager steps (same collectives, in the same order) whatever happens later
+            n_warm = max(self.warmup, 3 if self.distributed else 1)   # >= 1: the optimizer's state tensors must exist before the
+            if on_gpu:                                                # capture; collectives: communicators set up eagerly first
+                side = torch.cuda.Stream()
+                side.wait_stream(torch.cuda.current_stream())
+                with torch.cuda.stream(side):
+                    for _ in range(n_warm):
+                        self._eager(st_images, st_targets)
+                torch.cuda.current_stream().wait_stream(side)
+            else:
+                for _ in range(n_warm):
+                    self._eager(st_images, st_targets)
+        finally:
+            self.model.load_state_dict(model_state)            # in place: parameters and BN buffers keep their storage
+            with torch.no_grad():
+                for p_, st in self.optimizer.state.items():    # in place too: the graph will address these very tensors
+                    old = saved.get(id(p_))
+                    for k, v in st.items():
+                        if torch.is_tensor(v):
+                            v.copy_(old[k]) if old is not None and k in old else v.zero_()
+            self.optimizer.zero_grad(set_to_none=True)
+        # from here on nothing is executed: a failure below leaves every rank with the same collective history
+        if self._fail_capture:                               # test hook: this rank's capture "fails" (after the common warm-up)
+            raise RuntimeError("capture failure requested (test hook)")
+        entry["graph"], entry["out"] = self._record_graph(st_images, st_targets)
+        return entry
+
+    def _record_graph(self, st_images, st_targets):
+        if not st_images.is_cuda:
+            raise RuntimeError("a HIP graph needs a GPU")
         graph = torch.cuda.CUDAGraph()
         if self.distributed:
             # the process group's watchdog thread polls the events of the warm-up collectives; in the default (global) capture
@@ -478,19 +514,58 @@ class GraphedTrainStep:
             ctx = torch.cuda.graph(graph)
         with ctx:
             loss_dict, log = self._eager(st_images, st_targets)
-        entry["graph"], entry["out"] = graph, (loss_dict, log)
-        return entry
+        return graph, (loss_dict, log)
 
-    def __call__(self, images, targets):
+    def capture(self, images, targets):
+        """Warm up and capture the step for this input signature WITHOUT replaying it; returns True when a graph is ready.
+        Nothing a failed capture did survives: model, BN buffers and optimizer state are the pre-call values either way, and no
+        collective has been issued by the capture itself (captured collectives are recorded, not run) -- so under data
+        parallelism the ranks can still agree on what to do next (`agree`) before any of them replays."""
         key = self._signature(images, targets)
-        entry = self._graphs.get(key)
-        if entry is None:
-            if len(self._graphs) >= 2:                     # e.g. the last, smaller batch of an epoch
-                self._graphs.pop(next(iter(self._graphs)))
-            entry = self._graphs[key] = self._capture(images, targets)
+        if key in self._graphs:
+            return True
+        if len(self._graphs) >= 2:                     # e.g. the last, smaller batch of an epoch
+            self._graphs.pop(next(iter(self._graphs)))
+        try:
+            self._graphs[key] = self._capture(images, targets)
+            return True
+        except Exception as e:                          # noqa: BLE001 -- whatever it was, the caller falls back to the eager step
+            self.capture_error = e
+            self._graphs.pop(key, None)
+            self.optimizer.zero_grad(set_to_none=True)  # the flat views must not stay behind as .grad for an eager / DDP step
+            return False
+
+    def agree(self, ok):
+        """Data parallel: True only if EVERY rank captured (one eager all-reduce of a flag, issued by all ranks at the same
+        point: after `capture`, before any replay).  A rank whose capture failed must not meet its peers inside the replayed
+        SyncBN all-reduces with a different collective -- that is a hang, not a fallback (advisor r3)."""
+        if not self.distributed:
+            return bool(ok)
+        import torch.distributed as dist
+        flag = torch.tensor([1 if ok else 0], dtype=torch.int32, device=self._flat.device)   # issued by every rank, capture or not
+        dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=self.group)
+        agreed = bool(flag.item())
+        if not agreed:
+            self._graphs.clear()
+        return agreed
+
+    def replay(self, images, targets):
+        entry = self._graphs[self._signature(images, targets)]
         self._copy_in(entry, images, targets)
         entry["graph"].replay()
         return entry["out"]
+
+    def __call__(self, images, targets):
+        """capture (first call per signature) + cross-rank agreement + replay.  Under data parallelism every rank must meet an
+        unseen signature in the SAME call (fixed shapes per rank: the synthetic batches, a drop-last loader): a rank that
+        captures while its peers replay issues different collectives.  Raises when the ranks did not all capture; the caller
+        then owns the fallback (bench.py: eager DDP step)."""
+        key = self._signature(images, targets)
+        if key not in self._graphs:
+            ok = self.agree(self.capture(images, targets))
+            if not ok:
+                raise RuntimeError("whole-step graph unavailable on at least one rank: %r" % (self.capture_error,))
+        return self.replay(images, targets)
 
 
 def init_like_trained(model, std=0.01, seed=0):

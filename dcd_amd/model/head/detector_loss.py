@@ -448,7 +448,10 @@ class Loss_Computation():
         hm_loss = lw['hm_loss'] * hm_loss / batch_weight
 
         reg_pois = predictions.get('reg_pois')
-        if (self.fused_rows and reg_pois is not None and reg_pois.dim() == 3 and targets_variables['keypoints'].shape[2] == 10
+        # the row kernel is HIP only: host tensors (MODEL.DEVICE=cpu, the oracle tools, the gloo tests) and other dtypes take
+        # the op-by-op rows, like detector_predictor's `features.is_cuda` test for the head rows (advisor r3)
+        if (self.fused_rows and reg_pois is not None and reg_pois.is_cuda and reg_pois.dtype == torch.float32
+                and reg_pois.dim() == 3 and targets_variables['keypoints'].shape[2] == 10
                 and targets_variables['orientations'].shape[-1] == 8):
             S_raw, ix = self._fused_rows(predictions, targets_variables, batch_weight)
         else:

@@ -1027,6 +1027,9 @@ _OFFSET_CONV_BWD = os.environ.get("DCD_OFFSET_CONV_BWD", "1") != "0"       # 0: 
 _OFFSET_CONV_FWD = os.environ.get("DCD_OFFSET_CONV_FWD", "1") != "0"       # 0: stock forward
 
 
+_CHANNEL_SUM_WS = {}
+
+
 def channel_sums(gy):
     """Per-channel sums of a (B, C, ...) fp32 tensor (a bias gradient) by the two-stage fp64 sums of csrc/norm.hip, one launch."""
     L = _lib.lib()
@@ -1034,8 +1037,14 @@ def channel_sums(gy):
     B, C = gy.shape[0], gy.shape[1]
     HW = gy.numel() // (B * C)
     sums = torch.empty(C, dtype=torch.float32, device=gy.device)
-    ws = _bn_ws(C, gy.device)
-    _lib.check(L.dcd_channel_sums(_lib.stream_of(gy), gy.data_ptr(), B, C, HW, sums.data_ptr(), ws.data_ptr(), ws.numel()),
+    st = _lib.stream_of(gy)
+    # the kernel's arrival counters sit in the workspace and must enter zeroed (it leaves them zeroed): one zero-filled buffer
+    # per (device, stream, size), never shared between streams
+    key = (gy.device, int(st or 0), C)
+    ws = _CHANNEL_SUM_WS.get(key)
+    if ws is None:
+        ws = _CHANNEL_SUM_WS[key] = torch.zeros(L.dcd_bn_workspace_bytes(C), dtype=torch.uint8, device=gy.device)
+    _lib.check(L.dcd_channel_sums(st, gy.data_ptr(), B, C, HW, sums.data_ptr(), ws.data_ptr(), ws.numel()),
                "dcd_channel_sums")
     return sums
 

@@ -335,7 +335,9 @@ int dcd_bn_stats(void *stream, const float *x, int B, int C, int64_t HW, double 
 
 /* sums[c] = sum over b and positions of x[b][c][...] (fp64 two-stage sum, rounded once): a bias gradient
  * (torch.autograd's grad_bias of the reference's nn.Conv2d, DGDE/model/backbone/DCNv2/dcn_v2.py:111-128 conv_offset_mask).
- * One launch; workspace as dcd_bn_stats. */
+ * One launch.  workspace: dcd_bn_workspace_bytes(C) bytes whose SECOND half starts with C arrival counters (unsigned) that must
+ * be ZERO on entry; the call leaves them zero, so a buffer zeroed once can be reused by later calls ON THE SAME STREAM (calls on
+ * different streams need different buffers). */
 int dcd_channel_sums(void *stream, const float *x, int B, int C, int64_t HW, float *sums, void *workspace, size_t workspace_bytes);
 int dcd_bn_train_apply(void *stream, const float *x, const float *residual, const float *weight, const float *bias,
                        const double *stats, double count, float *running_mean, float *running_var,

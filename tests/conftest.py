@@ -39,5 +39,4 @@ def cpu_backend(monkeypatch, oracle_dcn):
                  "select_point_of_interest", "iou_3d"):
         monkeypatch.setattr(ops, name, getattr(torch_ops, name))
     monkeypatch.setattr(dcn_v2, "_backend", oracle_dcn)
-    monkeypatch.setenv("DCD_LOSS_ROWS", "0")      # the loss's per-object rows op by op (on the patched ops), not the HIP kernel
     return torch_ops

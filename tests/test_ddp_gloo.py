@@ -31,7 +31,6 @@ def _worker(rank, world, port, out_dir):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
-    os.environ["DCD_LOSS_ROWS"] = "0"          # per-object loss rows op by op on the patched ops
     from dcd_amd.config import get_cfg
     from dcd_amd.data.synthetic import make_batch
     from dcd_amd.engine.trainer import build_optimizer, init_like_trained, train_step, wrap_distributed
@@ -107,6 +106,100 @@ def test_ddp_world_size_2_gloo(tmp_path, oracle_dcn):
         assert res["err_graph_body"] < 1e-5, "flat-buffer all-reduce of the graphed step != mean of local gradients (%g)" % res["err_graph_body"]
 
 
+def _fallback_worker(rank, world, port, out_dir):
+    """Rank 1's graph capture fails (after the warm-up steps every rank runs), rank 0's succeeds: both must learn it from the
+    vote BEFORE anybody replays, and both finish on the eager DDP step from the pre-capture state."""
+    sys.path.insert(0, ROOT)
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
+    torch.set_num_threads(2)
+    from dcd_amd import ops
+    from dcd_amd.model.backbone.DCNv2 import dcn_v2
+    from oracle import dcn_oracle, torch_ops
+    for name in ("pairs_kpts_depth", "compute_z", "focal_loss", "giou_loss", "nms_hm", "select_topk",
+                 "select_point_of_interest", "iou_3d"):
+        setattr(ops, name, getattr(torch_ops, name))
+    dcn_v2._backend = dcn_oracle
+    from dcd_amd.config import get_cfg
+    from dcd_amd.data.synthetic import make_batch
+    from dcd_amd.engine.trainer import (GraphedTrainStep, build_optimizer, init_like_trained, prepare_data_parallel, train_step,
+                                        wrap_distributed)
+    from dcd_amd.model.detector import KeypointDetector
+
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+    cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", "cpu", "MODEL.USE_SYNC_BN", False,
+                        "INPUT.WIDTH_TRAIN", 320, "INPUT.HEIGHT_TRAIN", 96])
+    images, targets = make_batch(1, seed=30 + rank, n_objects=3, input_size=(320, 96))
+
+    def fresh():
+        torch.manual_seed(0)
+        m = KeypointDetector(cfg).train()
+        init_like_trained(m)
+        return m
+
+    # (A) the bench's sequence: bare module, capture, vote, fall back
+    model = prepare_data_parallel(fresh(), cfg)
+    opt = build_optimizer(model, cfg)
+    gstep = GraphedTrainStep(model, opt, cfg.SOLVER.GRAD_NORM_CLIP, warmup=1, distributed=True)
+    replays = []
+
+    class _FakeGraph:                                      # stands in for the HIP graph on rank 0 (no GPU here)
+        def replay(self):
+            replays.append(1)
+    if rank == 1:
+        gstep._fail_capture = True
+    else:
+        gstep._record_graph = lambda im, tg: (_FakeGraph(), ({}, {}))
+    captured = gstep.capture(images, targets)
+    agreed = gstep.agree(captured)
+    raised = False
+    try:                                                    # the one-call form reports the disagreement instead of replaying
+        if not agreed:
+            gstep2 = GraphedTrainStep(model, opt, cfg.SOLVER.GRAD_NORM_CLIP, warmup=1, distributed=True)
+            gstep2._fail_capture = rank == 1
+            gstep2._record_graph = lambda im, tg: (_FakeGraph(), ({}, {}))
+            gstep2(images, targets)
+    except RuntimeError:
+        raised = True
+    no_grads_left = all(p.grad is None for p in model.parameters())
+    ddp = wrap_distributed(model, cfg, local_rank=rank)
+    for _ in range(2):
+        train_step(ddp, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    got = torch.cat([p.detach().flatten() for p in ddp.parameters()])
+
+    # (B) the same two eager DDP steps without any capture attempt
+    ref_model = fresh()
+    ref = wrap_distributed(ref_model, cfg, local_rank=rank)
+    ref_opt = build_optimizer(ref, cfg)
+    for _ in range(2):
+        train_step(ref, ref_opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    want = torch.cat([p.detach().flatten() for p in ref.parameters()])
+    stats_got = torch.cat([b.detach().flatten().float() for n, b in ddp.named_buffers() if "running" in n])
+    stats_want = torch.cat([b.detach().flatten().float() for n, b in ref.named_buffers() if "running" in n])
+    others = [torch.zeros_like(got) for _ in range(world)]
+    dist.all_gather(others, got)
+    torch.save({"captured": captured, "agreed": agreed, "raised": raised, "replays": len(replays), "no_grads_left": no_grads_left,
+                "same": all(torch.equal(others[0], o) for o in others),
+                "dist_to_eager": (got - want).abs().max().item(), "stats_dist": (stats_got - stats_want).abs().max().item()},
+               os.path.join(out_dir, "f%d.pt" % rank))
+    dist.barrier()
+    dist.destroy_process_group()
+
+
+@pytest.mark.timeout(900)
+def test_capture_failure_on_one_rank_falls_back_on_all(tmp_path, oracle_dcn):
+    """Advisor r3 / VERDICT r3 item 4: `GraphedTrainStep.capture` + `agree` + `replay` -- a rank whose capture fails votes
+    before any rank replays, every rank ends on the eager data-parallel step, from the state the capture attempt found."""
+    port = _free_port()
+    mp.spawn(_fallback_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
+    res = [torch.load(os.path.join(str(tmp_path), "f%d.pt" % r)) for r in range(2)]
+    assert res[0]["captured"] and not res[1]["captured"]
+    for r in res:
+        assert not r["agreed"] and r["raised"] and r["replays"] == 0 and r["no_grads_left"], r
+        assert r["same"], "replicas diverged after the fallback"
+        # the capture attempt's warm-up steps left no trace: same weights and running statistics as two plain eager steps
+        assert r["dist_to_eager"] <= 1e-6 and r["stats_dist"] <= 1e-6, r
+
+
 def _syncbn_worker(rank, world, port, out_dir):
     sys.path.insert(0, ROOT)
     os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(port), RANK=str(rank), WORLD_SIZE=str(world))
@@ -169,7 +262,6 @@ def _config3_worker(rank, world, port, out_dir):
                  "select_point_of_interest", "iou_3d"):
         setattr(ops, name, getattr(torch_ops, name))
     dcn_v2._backend = dcn_oracle
-    os.environ["DCD_LOSS_ROWS"] = "0"          # per-object loss rows op by op on the patched ops
     cpu_syncbn.install()
     from dcd_amd.config import get_cfg
     from dcd_amd.data.synthetic import make_batch

@@ -534,8 +534,19 @@ def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
     for g in opt.param_groups:
         g["lr"].fill_(1.25e-4)
     path = str(tmp_path / "ck.pth")
+    live = {id(st): {k: v for k, v in st.items()} for st in opt.state.values()}
     torch.save(checkpoint_state(model, opt, sched, iteration=1, iter_per_epoch=10), path)
+    # advisor r3: writing a checkpoint must not touch the RUNNING optimizer (state_dict() hands out its live dicts): same
+    # tensor objects, still on the device, and the same optimizer takes another fused step afterwards
+    for st in opt.state.values():
+        for k, v in st.items():
+            assert v is live[id(st)][k] and (not torch.is_tensor(v) or v.is_cuda)
+    w_before = [p.detach().clone() for p in model.parameters()]
+    train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+    assert any(not torch.equal(a, p) for a, p in zip(w_before, model.parameters()))
+    assert all(abs(float(st["step"]) - 2.0) < 1e-6 for st in opt.state.values())
     data = torch.load(path, map_location="cpu", weights_only=False)
+    assert all(abs(float(st["step"]) - 1.0) < 1e-6 for st in data["optimizer"]["state"].values())
     for g in data["optimizer"]["param_groups"]:
         assert isinstance(g["lr"], float) and abs(g["lr"] - 1.25e-4) < 1e-9 and g["capturable"] is False and g["fused"] is None
         assert not torch.is_tensor(g.get("initial_lr", 0.0))

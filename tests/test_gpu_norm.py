@@ -176,3 +176,24 @@ def test_channel_sums_one_launch_equals_fp64_sum_and_repeats(cuda, shape):
         assert torch.equal(sx, first)
         assert (sx.double() - ref_x).abs().max().item() <= 1e-6 * max(ref_x.abs().max().item(), 1.0)
         assert (sy.double() - ref_y).abs().max().item() <= 1e-6 * max(ref_y.abs().max().item(), 1.0)
+
+
+def test_channel_sums_on_two_streams_at_once(cuda):
+    """Advisor r3: the arrival counters of the one-launch channel sums live in the call's workspace (one zeroed buffer per
+    stream), not in a process-global array -- launches interleaved on two streams must not see each other's arrivals."""
+    from dcd_amd import ops
+    g = torch.Generator().manual_seed(4)
+    xs = [torch.randn(8, 27, 96, 320, generator=g).to(cuda) for _ in range(2)]
+    refs = [x.double().sum(dim=(0, 2, 3)) for x in xs]
+    streams = [torch.cuda.Stream(), torch.cuda.Stream()]
+    torch.cuda.synchronize()
+    outs = [[], []]
+    for _ in range(20):
+        for i, st in enumerate(streams):
+            with torch.cuda.stream(st):
+                outs[i].append(ops.channel_sums(xs[i]))
+    torch.cuda.synchronize()
+    for i in range(2):
+        for o in outs[i]:
+            assert torch.equal(o, outs[i][0])
+            assert (o.double() - refs[i]).abs().max().item() <= 1e-6 * max(refs[i].abs().max().item(), 1.0)

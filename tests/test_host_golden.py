@@ -313,7 +313,13 @@ def test_solver_schedule_and_step_match_reference(tmp_path):
     np.testing.assert_allclose(got, g["params_after_3_steps"], rtol=2e-6, atol=1e-7)
     # checkpoint layout round trip
     path = tmp_path / "model_checkpoint.pth"
-    torch.save(checkpoint_state(net, opt, sched, iteration=2999, iter_per_epoch=100), path)
+    live = {id(st): dict(st) for st in opt.state.values()}
+    ck = checkpoint_state(net, opt, sched, iteration=2999, iter_per_epoch=100)
+    for st in opt.state.values():                          # the running optimizer's state objects are not replaced ...
+        assert all(v is live[id(st)][k] for k, v in st.items())
+    for i, st in ck["optimizer"]["state"].items():         # ... and the checkpoint holds copies, not the live tensors
+        assert all(not any(v is w for w in l.values()) for l in live.values() for v in st.values() if torch.is_tensor(v))
+    torch.save(ck, path)
     data = torch.load(path, weights_only=False)
     assert set(data) == {"model", "optimizer", "scheduler", "iteration", "iter_per_epoch"}
     net2 = torch.nn.Sequential(torch.nn.Linear(6, 5), torch.nn.ReLU(), torch.nn.Linear(5, 3))
