@@ -100,6 +100,89 @@ class DcnTimer:
         return out
 
 
+class OffsetStats:
+    """What sampling offsets the DCN number was measured at: one extra eager forward, outside the timed region,
+    with the offset argument of every `dcn_v2_forward` call reduced on the device -- mean |d|, max |d| and the fraction of samples
+    with a coordinate displaced by >= 3 px (what the one-pass backward's LDS window does not hold: `far`)."""
+
+    def __init__(self, torch, ext):
+        self.torch, self.ext = torch, ext
+        self.rows = []
+        self._f = ext.dcn_v2_forward
+
+    def __enter__(self):
+        def hooked(*a, **k):
+            off = a[3].detach()
+            n = off.shape[1] // 2
+            ab = off.abs()
+            pair = ab.view(off.shape[0], n, 2, -1).amax(dim=2)                     # per sample: the larger of |dy|, |dx|
+            self.rows.append(self.torch.stack([ab.sum(), ab.amax(), (pair >= 3.0).sum().float(),
+                                               self.torch.tensor(float(ab.numel()), device=off.device),
+                                               self.torch.tensor(float(pair.numel()), device=off.device)]))
+            return self._f(*a, **k)
+        self.ext.dcn_v2_forward = hooked
+        return self
+
+    def __exit__(self, *exc):
+        self.ext.dcn_v2_forward = self._f
+
+    def summary(self):
+        if not self.rows:
+            return None
+        t = self.torch.stack(self.rows).double().cpu()
+        return {"mean_abs_px": round(float(t[:, 0].sum() / t[:, 3].sum()), 4), "max_abs_px": round(float(t[:, 1].max()), 3),
+                "far_fraction": float(t[:, 2].sum() / t[:, 4].sum()), "far_threshold_px": 3.0, "calls": len(self.rows),
+                "source": "offset tensors of the 16 DCN calls of one eager forward of the benchmarked model and batch "
+                          "(conv_offset_mask ~ N(0, 0.01^2), SURVEY 8d)"}
+
+
+def op_level_dcn(torch, ext, batch, sigma, prec, iters=3):
+    """SURVEY 8(d)'s op-level DCN bench: the 16 layers through the C ABI (dcd_amd._ext), input randn, offsets sigma * randn px
+    (DGDE/model/backbone/DCNv2/DCN/testcuda.py:74 uses 2), mask sigmoid(randn), weight ~ 1 / sqrt(9 Cin).  (fwd ms, bwd ms)
+    over the 16 layers, event-timed on the launch stream."""
+    dev = torch.device("cuda", torch.cuda.current_device())
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    g = torch.Generator(device=dev).manual_seed(1234)
+    tf = tb = 0.0
+    for cin, cout, h, w, n in DCN_LAYERS:
+        x = torch.randn(batch, cin, h, w, device=dev, generator=g)
+        off = torch.randn(batch, 18, h, w, device=dev, generator=g) * sigma
+        m = torch.sigmoid(torch.randn(batch, 9, h, w, device=dev, generator=g))
+        wt = torch.randn(cout, cin, 3, 3, device=dev, generator=g) / (cin * 9) ** 0.5
+        b = torch.zeros(cout, device=dev)
+        gy = torch.randn(batch, cout, h, w, device=dev, generator=g)
+        for _ in range(2):
+            ext.dcn_v2_forward(x, wt, b, off, m, *a, precision=prec)
+            ext.dcn_v2_backward(x, wt, b, off, m, gy, *a, precision=prec)
+        e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
+        e[0].record()
+        for _ in range(iters):
+            ext.dcn_v2_forward(x, wt, b, off, m, *a, precision=prec)
+        e[1].record()
+        for _ in range(iters):
+            ext.dcn_v2_backward(x, wt, b, off, m, gy, *a, precision=prec)
+        e[2].record()
+        torch.cuda.synchronize()
+        tf += n * e[0].elapsed_time(e[1]) / iters
+        tb += n * e[1].elapsed_time(e[2]) / iters
+    return tf, tb
+
+
+def op_level_lines(torch, ext, batch, prec):
+    """`roofline_op_2px` (+ the same layers at 0.5 px, the ratio the review asks for)."""
+    by, fl = dcn_algorithmic(batch)
+    out = {}
+    for key, sigma in (("roofline_op_0p5px", 0.5), ("roofline_op_2px", 2.0)):
+        tf, tb = op_level_dcn(torch, ext, batch, sigma, prec)
+        t = tf + tb
+        out[key] = {"bound": "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers through the C ABI, batch %d, offsets %g * randn px" % (batch, sigma),
+                    "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3), "ms": round(t, 3), "achieved": fl / 1e9 / t, "peak": MFMA_PEAK_TFLOPS[prec],
+                    "unit": "TFLOP/s", "frac": fl / 1e9 / t / MFMA_PEAK_TFLOPS[prec], "hbm_frac": by / 1e6 / t / HBM_PEAK_GBS,
+                    "offset_sigma_px": sigma}
+    out["roofline_op_2px"]["ratio_to_0p5px"] = round(out["roofline_op_2px"]["ms"] / out["roofline_op_0p5px"]["ms"], 3)
+    return out
+
+
 def build_everything(args, device, world, local_rank):
     import torch
     from dcd_amd import _ext
@@ -224,6 +307,12 @@ def run_gpu(args):
         torch.cuda.synchronize()
         timer.enabled = False
         dcn_source = "event pairs around every DCN call in %d eager steps run right after the timed (graph-replayed) region" % args.dcn_steps
+    offsets = None
+    if rank == 0 and not (isinstance(model, torch.nn.parallel.DistributedDataParallel) or data_parallel):
+        # one eager FORWARD of the same model and batch, outside the timed region (no collectives involved: single-process runs only)
+        with OffsetStats(torch, _ext) as st, torch.no_grad():
+            model(images, targets)
+        offsets = st.summary()
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -261,11 +350,14 @@ def run_gpu(args):
                          # is the SUM of matrix and vector issue cycles, not the matrix pipe alone
                          "bound_measured": "valu+mfma issue (f32 MFMA shares the VALU lanes)", "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
                          "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source,
+                         "offsets": offsets,
                          "layers": timer.per_layer(max(dcn_count, 1), per_rank)},
             "roofline_hbm": {"bound": "hbm", "achieved": by / 1e9 / (dcn_ms / 1e3) if dcn_ms > 0 else None, "peak": HBM_PEAK_GBS,
                              "unit": "GB/s", "frac": (by / 1e9 / (dcn_ms / 1e3)) / HBM_PEAK_GBS if dcn_ms > 0 else None,
                              "algorithmic_bytes": by},
         }
+    if out is not None and world == 1 and not args.amp and not args.no_op_line:
+        out.update(op_level_lines(torch, _ext, per_rank, args.precision))
     # The same job with the DCN contractions in split-bf16 (DCD_PREC_BF16X3: hi*hi + hi*lo + lo*hi on the bf16 matrix cores, fp32
     # accumulate, ~2^-16 relative per product against north_star's 1e-3 bound) as an EXTRA object: `value` above stays the exact
     # fp32 run.  One GPU, eager step only (a captured graph has the fp32 kernels baked in).
@@ -289,6 +381,8 @@ def run_gpu(args):
                                "steps": s_steps, "dcn_precision": "bf16x3", "dcn_ms_per_step": s_dcn,
                                "dcn_tflops": fl / 1e12 / (s_dcn / 1e3) if s_dcn > 0 else None,
                                "dcn_frac_of_fp32_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if s_dcn > 0 else None,
+                               # against its OWN peak: three bf16 products per fp32 one on the 2.5 PF matrix cores
+                               "dcn_frac_of_split_bf16_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["bf16x3"] if s_dcn > 0 else None,
                                "dcn_hbm_frac": (by / 1e9 / (s_dcn / 1e3)) / HBM_PEAK_GBS if s_dcn > 0 else None,
                                "note": "same model, data and step as `value`; only the DCN weight contractions change precision"}
     # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
@@ -763,6 +857,7 @@ def main():
     ap.add_argument("--no-weak", action="store_true", help="N > 1: skip the extra weak-scaling measurement")
     ap.add_argument("--objects", type=int, default=6)
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 measurement of the default run")
+    ap.add_argument("--no-op-line", action="store_true", help="skip the op-level DCN lines (roofline_op_2px / _0p5px)")
     ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
                     help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")
     ap.add_argument("--amp", action="store_true", help="MODEL.FP16: bf16 autocast around the backbone + split-bf16 DCN "

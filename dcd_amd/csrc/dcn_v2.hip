@@ -761,9 +761,19 @@ constexpr float TL_NEAR = 3.f;   // tiled kernels: |offset| below this stays ins
 // Device-side choice between "tiled kernel + far-only pass" and "generic kernel alone", taken identically by every kernel of
 // a call from the offset scan's result: when more than half of the 32-pixel tiles hold a far sample (large learned offsets),
 // the tiled kernels would mostly produce zeros and the far-only pass would redo nearly everything.
+//
+// One-pass backward (round 4): its kernel takes the far samples itself, one by one (dcn_bwd_sweep.inc: global loads and atomics
+// instead of the LDS window), so what decides is the NUMBER of far samples, not the tiles they sit in: the call's zero-fill
+// kernel marks far_scal[3] with FAR_BY_COUNT, the offset scan adds the far coordinates to it, and the generic kernels take over
+// when more than 1 in 64 coordinates is far (~3 % of the samples; a far sample costs the one-pass kernel ~8 near ones and four
+// global atomics per channel).
+constexpr unsigned FAR_BY_COUNT = 0x80000000u;
 __device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int total_tiles)
 {
-    return far_scal && (int64_t)far_scal[1] * 2 > (int64_t)total_tiles;
+    if (!far_scal) return false;
+    const unsigned c = far_scal[3];
+    if (c & FAR_BY_COUNT) return (int64_t)(c & ~FAR_BY_COUNT) * 64 > (int64_t)total_tiles * 32 * 18;
+    return (int64_t)far_scal[1] * 2 > (int64_t)total_tiles;
 }
 
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
@@ -799,10 +809,13 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
                                   int *__restrict__ far_list)
 {
     float m = 0.f;
+    unsigned nfar = 0u;                                            // coordinates displaced by TL_NEAR px or more -> scal[3]
     auto visit = [&](int64_t i, float raw) {
         const float v = fabsf(raw);
         m = fmaxf(m, v);
         if (!(v < TL_NEAR)) {                                      // rare
+            ++nfar;
+            if (!far_flag) return;                                 // one-pass backward: its kernel owns the far samples, no tile list
             const int64_t plane = i / HoWo;
             const int P = (int)(i - plane * HoWo), b = (int)(plane / ch_per_img);
             const int tid_ = b * tiles_per_img + (P >> 5);
@@ -825,12 +838,16 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
     // one atomic per block: thousands of same-address atomics serialise in L2 (the earlier per-wave version spent most of
     // its 40 us there)
 #pragma unroll
-    for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+    for (int o = 32; o > 0; o >>= 1) { m = fmaxf(m, __shfl_xor(m, o)); nfar += __shfl_xor(nfar, o); }
     __shared__ float part[4];
-    if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = m;
+    __shared__ unsigned partn[4];
+    if ((threadIdx.x & 63) == 0) { part[threadIdx.x >> 6] = m; partn[threadIdx.x >> 6] = nfar; }
     __syncthreads();
-    if (threadIdx.x == 0)
+    if (threadIdx.x == 0) {
         atomicMax(scal, __float_as_uint(fmaxf(fmaxf(part[0], part[1]), fmaxf(part[2], part[3]))));   // non-negative floats order like their bits
+        const unsigned nf = partn[0] + partn[1] + partn[2] + partn[3];
+        if (nf) atomicAdd(scal + 3, nf);
+    }
 }
 
 // ceil(max(|dh|, |dw|)) over each 8x8 block of output pixels, per (image, tap segment): lets dcn_build_inverse search a
@@ -2084,9 +2101,12 @@ __global__ void dcn_dw_reduce(const float *__restrict__ part, float *__restrict_
 struct ZeroRanges {
     unsigned *p[8];
     unsigned n[8];        // dwords
+    unsigned *mark_p = nullptr;   // one word set to mark_v (must lie outside the ranges)
+    unsigned mark_v = 0u;
 };
 __global__ void dcn_zero_ranges(ZeroRanges z)
 {
+    if (z.mark_p && blockIdx.x == 0 && threadIdx.x == 0) *z.mark_p = z.mark_v;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         unsigned *p = z.p[r];
@@ -2389,9 +2409,16 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     inv.flag_ty = (H + 3) / 4;
     const dim3 bm_grid(((g.Ho + 7) / 8) * ((g.Wo + 7) / 8), dg * g.KK, B);
 
-    // one-pass backward wherever it applies (Cout <= 64), the dense path included: 256->64 @ 24x80 0.36 vs 0.50 ms.
-    // DCD_BWD_SWEEP=2 keeps the dense path for the layers it takes (A/B)
-    const bool use_sweep = sweep_ok(g) && g.Cop <= 64 && dense_mode() != 1 && (sweep_mode() == 1 || !dense_ok(g, true));
+    // one-pass backward wherever it applies (3x3 / stride 1 / pad 1, Cout <= 256; round 3: Cout <= 64 only), the dense path's
+    // layers included: 256->64 @ 24x80 0.36 vs 0.50 ms.  DCD_BWD_SWEEP=2 keeps the dense path for the layers it takes,
+    // DCD_SWEEP_WIDE=0 keeps round 3's limit of 64 outputs (A/B)
+    const char *sw_e = getenv("DCD_SWEEP_WIDE");              // read per call: the tests switch it inside one process
+    const bool sweep_wide = !(sw_e && atoi(sw_e) == 0);
+    // Cout 256 (the two deepest DGDE layers, Cin 512 / 256 on 12x40 / 24x80 maps) stays on the dense path when it applies: the
+    // one-pass kernel gains little there (0.68 vs 0.73 ms, 0.46 vs 0.44) and those layers' offsets (fan-in 9 Cin) are large enough in
+    // the train step to hand the call to the generic kernels (1.9 vs 0.8 ms), which the dense path does not care about
+    const bool use_sweep = sweep_ok(g) && (g.Cop <= 64 || (sweep_wide && (g.Cop <= 128 || !dense_ok(g, true)))) && dense_mode() != 1 &&
+                           (sweep_mode() == 1 || !dense_ok(g, true));
     if (!use_sweep && dense_ok(g, true)) {
         ZeroRanges z;
         for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
@@ -2437,7 +2464,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         {
             ZeroRanges z;
             for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
-            z.p[0] = absmax; z.n[0] = 4;
+            z.p[0] = absmax; z.n[0] = 3;                     // [max |offset| bits, listed tiles (stays 0), overflowed lists]
+            z.mark_p = absmax + 3; z.mark_v = FAR_BY_COUNT;  // far-coordinate counter: the call is decided by its count (far_dominated)
             z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
             z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
             z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
@@ -2446,27 +2474,41 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         }
         if (split)
             hipLaunchKernelGGL(dcn_sweep_prep_weights_bf16, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight,
-                               (unsigned *)swp, g, sp.nck);
+                               (unsigned *)swp, g, sp.nck, sp.nob);
         else
-            hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g, sp.nck);
+            hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g,
+                               sp.nck, sp.nob);
         {
             const int64_t noff = (int64_t)B * 18 * g.HoWo;
             int gsz = (int)((noff + 4095) / 4096);
             if (gsz > 512) gsz = 512;
+            // no tile list: the sweep takes its far samples itself; the far-only launches below then find nothing listed and
+            // return at once unless the call is handed to the generic kernels altogether
             hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, 18, (g.HoWo + 31) / 32,
-                               far_flag, far_list);
+                               (unsigned char *)nullptr, far_list);
         }
         {
             SweepArgs a;
             a.in = input; a.off = offset; a.msk = mask; a.wp = swp; a.gy = grad_output; a.gin = grad_input; a.cpart = cpart;
             a.dwpart = dwpart; a.far_scal = fs; a.g = g; a.nstrip = sp.nstrip; a.nseg = sp.nseg; a.seg_rows = sp.seg_rows;
             a.nck = sp.nck; a.nv = sp.nv; a.nslot = sp.nslot;
+            a.col = dwpart + sp.dw_floats;                   // nob > 1: [grad_weight product partials | col]
             static LdsLimit sw_lds_limit;
             const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
-            if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep<DCD_PREC_F32>, dcn_bwd_sweep<DCD_PREC_BF16X3>)) return DCD_ERR_LAUNCH;
-            const dim3 sgrid(sp.nslot / SW_WAVES);
-            if (split) hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_BF16X3>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
-            else hipLaunchKernelGGL(dcn_bwd_sweep<DCD_PREC_F32>, sgrid, dim3(64 * SW_WAVES), ldsb, stream, a);
+            if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep<DCD_PREC_F32, 1, true>, dcn_bwd_sweep<DCD_PREC_BF16X3, 1, true>,
+                                    dcn_bwd_sweep<DCD_PREC_F32, 2, false>, dcn_bwd_sweep<DCD_PREC_BF16X3, 2, false>,
+                                    dcn_bwd_sweep<DCD_PREC_F32, 4, false>, dcn_bwd_sweep<DCD_PREC_BF16X3, 4, false>))
+                return DCD_ERR_LAUNCH;
+            const dim3 sgrid(sp.nslot / SW_WAVES), sblock(64 * SW_WAVES);
+#define DCD_LAUNCH_SWEEP(NOBV, DWKV)                                                                                     \
+    do {                                                                                                                \
+        if (split) hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_BF16X3, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a);    \
+        else hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_F32, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a);             \
+    } while (0)
+            if (sp.nob == 1) DCD_LAUNCH_SWEEP(1, true);
+            else if (sp.nob == 2) DCD_LAUNCH_SWEEP(2, false);
+            else DCD_LAUNCH_SWEEP(4, false);
+#undef DCD_LAUNCH_SWEEP
         }
         {
             const int64_t n4 = (int64_t)B * 27 * g.HoWo / 4;
@@ -2476,14 +2518,34 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                 int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
                 if (splits > 32) splits = 32;
                 if (splits < 1) splits = 1;
-                hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo, fs);
+                // nob == 1: the sweep's chunk-0 waves sum dY themselves (this launch then only acts when the generic kernels take over)
+                hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo,
+                                   sp.nob == 1 ? fs : (const unsigned *)nullptr);
             }
-            // grad_weight and grad_bias (the sweep's chunk-0 waves summed dY over their pixels) from the per-wave partials
-            const int nred = sp.nck * SW_DW_FLOATS + 64;
-            const int nvp = sp.nslot / sp.nck;
-            const int rg = nvp >= 64 ? 16 : (nvp >= 8 ? 4 : 1);
-            hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, grad_bias, g,
-                               sp.nck, nvp, fs, B * tiles);
+            if (sp.nob == 1) {
+                // grad_weight and grad_bias (the sweep's chunk-0 waves summed dY over their pixels) from the per-wave partials
+                const int nred = sp.nck * SW_DW_FLOATS + 64;
+                const int nvp = sp.nslot / sp.nck;
+                const int rg = nvp >= 64 ? 16 : (nvp >= 8 ? 4 : 1);
+                hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, grad_bias, g,
+                                   sp.nck, nvp, fs, B * tiles);
+            } else {
+                // grad_weight = sum_b dY[b] (Cout x HoWo) col[b]^T (HoWo x 9 Cin): ONE batched product, both operands pixel-contiguous,
+                // partials per (image, pixel chunk) summed in a fixed order -- the near samples' part; the far-only pass below adds
+                // the rest with atomics.  Its row index c * 9 + t IS grad_weight's layout.
+                static_assert(SW_GEMM_T == SG_T && SW_GEMM_K == SG_K, "sweep_plan sizes the product's partials with these");
+                const int K9 = Cin * 9, n = Cout * K9;
+                SgemmArgs ga;
+                ga.A = grad_output; ga.B = dwpart + sp.dw_floats; ga.C = dwpart; ga.bias = nullptr; ga.M = Cout; ga.N = K9; ga.K = g.HoWo;
+                ga.lda = g.HoWo; ga.ldb = g.HoWo; ga.ldc = K9;
+                ga.strideA = (long long)Cout * g.HoWo; ga.strideB = (long long)K9 * g.HoWo;
+                ga.strideC = (long long)sp.dw_split * n; ga.strideCs = n;
+                ga.nsplit = sp.dw_split; ga.kchunk = sp.dw_kchunk; ga.ct = 0; ga.b_off = nullptr;
+                if (split) sgemm_bf16x3(stream, true, true, ga, B);
+                else sgemm_f32(stream, true, true, ga, B);
+                hipLaunchKernelGGL(dcn_sweep_reduce_gemm, dim3((n / 4 + 255) / 256 < 512 ? (n / 4 + 255) / 256 : 512), dim3(256), 0, stream,
+                                   dwpart, grad_weight, n, B * sp.dw_split, fs, B * tiles);
+            }
         }
         // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
         inv.packed = 0;
@@ -2502,17 +2564,20 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         }
         {
             dim3 grid((tiles + 3) / 4, B, nsplit), block(256);
-            if (g.Cop == 64)
-                hipLaunchKernelGGL(dcn_bwd_data_f32<32>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
-                                   grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
-            else
-                hipLaunchKernelGGL(dcn_bwd_data_f32<16>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input, grad_offset,
-                                   grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1);
+#define DCD_LAUNCH_BD_FAR(NS)                                                                                            \
+    hipLaunchKernelGGL(dcn_bwd_data_f32<NS>, grid, block, 0, stream, input, offset, mask, wb, grad_output, grad_input,  \
+                       grad_offset, grad_mask, grad_bias, g, nsplit, inv, fs, (const int *)far_list, 1)
+            if (g.Cop == 32) DCD_LAUNCH_BD_FAR(16);
+            else if (g.Cop == 64) DCD_LAUNCH_BD_FAR(32);
+            else if (g.Cop == 128) DCD_LAUNCH_BD_FAR(64);
+            else if (g.Cop == 256) DCD_LAUNCH_BD_FAR(128);
+            else DCD_LAUNCH_BD_FAR(0);
+#undef DCD_LAUNCH_BD_FAR
         }
         {
             const int RB = 9 * nblk;
             const int nb = g.Cop / 32;
-            const int mb = nb >= 2 ? 2 : 1;
+            const int mb = nb >= 8 ? 8 : nb >= 4 ? 4 : nb >= 2 ? 2 : 1;
             const int gx = (RB + 3) / 4, gz = (nb + mb - 1) / mb;
             const int total = B * tiles;
             int S = 512 / (gx * gz);
@@ -2520,12 +2585,14 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             if (S > total) S = total;
             dim3 grid(gx, S, gz), block(256);
             const size_t lds = (size_t)(4 * 32 * 33 + mb * 32 * 33) * sizeof(float);
-            if (mb == 2)
-                hipLaunchKernelGGL(dcn_bwd_weight_f32<2>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, tiles, S,
-                                   fs, (const int *)far_list);
-            else
-                hipLaunchKernelGGL(dcn_bwd_weight_f32<1>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, tiles, S,
-                                   fs, (const int *)far_list);
+#define DCD_LAUNCH_BW_FAR(MBV)                                                                                           \
+    hipLaunchKernelGGL(dcn_bwd_weight_f32<MBV>, grid, block, lds, stream, input, offset, mask, grad_output, grad_weight, g, \
+                       tiles, S, fs, (const int *)far_list)
+            if (mb == 8) DCD_LAUNCH_BW_FAR(8);
+            else if (mb == 4) DCD_LAUNCH_BW_FAR(4);
+            else if (mb == 2) DCD_LAUNCH_BW_FAR(2);
+            else DCD_LAUNCH_BW_FAR(1);
+#undef DCD_LAUNCH_BW_FAR
         }
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }

@@ -286,6 +286,59 @@ def test_one_pass_backward_equals_three_pass(cuda, monkeypatch):
             close(g_, r_, 2e-5, "one-pass vs three-pass %s %s" % (name, (B, C, Co, H, W)))
 
 
+WIDE_SWEEP_CASES = [
+    # B, C, Co, H, W, off_scale: one-pass backward with Cout > 64 (round 4): dcol over 2 / 4 blocks of 64 outputs, the masked
+    # samples through the col buffer, grad_weight as one product
+    (2, 32, 128, 12, 36, 0.5),       # two output blocks, partial strip (36 = 2 x 16 + 4)
+    (1, 48, 200, 10, 40, 1.2),       # 200 outputs -> four blocks with zero-padded weights; some far samples
+    (1, 16, 256, 9, 32, 0.7),        # four full blocks, one channel chunk, a map barely taller than the ring
+    (2, 40, 72, 19, 44, 2.0),        # ragged channels (40 = 2.5 chunks), 72 outputs, many far samples + quarter collisions
+]
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16x3"])
+@pytest.mark.parametrize("case", WIDE_SWEEP_CASES)
+def test_one_pass_backward_wide_outputs(cuda, oracle_dcn, monkeypatch, case, prec):
+    """the one-pass backward for Cout 128 / 256 (the layers rounds 2-3 ran through the column buffer).
+    All five gradients against the oracle, and against the three-pass / dense path of the same library (DCD_SWEEP_WIDE=0)."""
+    from dcd_amd import _ext
+    B, C, Co, H, W, osc = case
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=osc, seed=31)
+    off[:, :, :, 1::4] += 1.4              # neighbouring pixel groups pushed towards each other: quarter collisions
+    off[:, :, :, 3::4] -= 1.4
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    ref = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    dev = [t.to(cuda) for t in (x, w, b, off, m, gy)]
+    monkeypatch.setenv("DCD_SWEEP_WIDE", "1")
+    got = _ext.dcn_v2_backward(*dev, *a, precision=prec)
+    tol = 5e-5 if prec == "f32" else BF16X3_TOL
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+        close(g_, r_, tol, "wide one-pass %s %s %s" % (prec, name, case))
+    if prec == "f32":
+        again = _ext.dcn_v2_backward(*dev, *a, precision=prec)
+        assert torch.equal(got[1], again[1]) and torch.equal(got[2], again[2])      # per-chunk planes summed in a fixed order
+        close(again[3], got[3], 2e-6, "grad_weight run to run")                     # product partials in a fixed order; far pass: atomics
+        monkeypatch.setenv("DCD_SWEEP_WIDE", "0")                                   # rounds 2-3: dense / three-pass backward
+        old = _ext.dcn_v2_backward(*dev, *a, precision=prec)
+        for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, old):
+            close(g_, r_, 2e-5, "wide one-pass vs round-3 path %s %s" % (name, case))
+
+
+def test_wide_outputs_take_the_one_pass_kernel(cuda, monkeypatch):
+    """The A/B switch must switch something: with DCD_SWEEP_WIDE=0 a 128-output layer runs the round-3 paths, whose grad_input
+    (inverse lists / dense col2im: plain stores, a different summation order) differs from the one-pass result in the low bits."""
+    from dcd_amd import _ext
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, 128, 128, 16, 48, off_scale=0.5, seed=3))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    monkeypatch.setenv("DCD_SWEEP_WIDE", "1")
+    one = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    monkeypatch.setenv("DCD_SWEEP_WIDE", "0")              # read per call
+    three = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), one, three):
+        close(g_, r_, 2e-5, "wide one-pass vs round-3 path " + name)
+    assert not torch.equal(one[0], three[0])
+
+
 # the seven distinct DCN geometries of DLA-34 at 384x1280 (bench.py::DCN_LAYERS; SURVEY.md section 8 a1), at the BASELINE batch
 DGDE_GEOMETRIES = [(512, 256, 12, 40), (256, 256, 24, 80), (256, 128, 24, 80), (128, 128, 48, 160), (128, 64, 48, 160),
                    (64, 64, 96, 320), (256, 64, 24, 80)]

@@ -93,6 +93,19 @@ def test_loss_computation_matches_reference(cuda):
     H.check_loss_computation(cuda, 1e-4)
 
 
+def test_loss_computation_through_the_row_kernel_matches_reference(cuda, monkeypatch):
+    """the reference's Loss_Computation fixture DIRECTLY through csrc/loss_rows.hip (the regression map gathered
+    at the object centres, as the predictor hands it over in training): 13 losses, log dict and both gradients at 1e-4 -- not
+    only transitively (kernel == op-by-op rows == reference)."""
+    monkeypatch.setenv("DCD_LOSS_ROWS", "1")
+    from dcd_amd import ops
+    calls = []
+    real = ops.loss_rows
+    monkeypatch.setattr(ops, "loss_rows", lambda *a, **k: (calls.append(1), real(*a, **k))[1])
+    H.check_loss_computation(cuda, 1e-4, through_row_kernel=True)
+    assert calls, "the loss did not go through ops.loss_rows"
+
+
 def test_gen_data_for_gmw_matches_reference(cuda):
     H.check_gen_data(cuda, 2e-3)      # the normalised keypoints pass through the solver's mean depth: 2e-3 of the value range
 

@@ -47,13 +47,26 @@ def check_anno_encoder(device):
                                  t["pad"][t["batch_idxs"]].unsqueeze(1).expand_as(t["kp73"])), "kpts_2d_img")
 
 
-def check_loss_computation(device, tol):
+def check_loss_computation(device, tol, through_row_kernel=False):
+    """The reference's Loss_Computation fixture (13 losses, log dict, gradients w.r.t. both head maps).
+    through_row_kernel: hand the loss what the predictor hands it in training -- the regression map gathered at the object
+    centres, `reg_pois` (B, M, 415) -- so that the per-object rows run through csrc/loss_rows.hip (GPU only) instead of the
+    op-by-op rows; the gradient flows back through the gather into the dense map and is compared with the same fixture."""
     from dcd_amd.model.head.detector_loss import Loss_Computation
     g = load("loss_computation")
     preds, targets = gi.loss_inputs()
     cls = torch.from_numpy(preds["cls"]).to(device).requires_grad_()
     reg = torch.from_numpy(preds["reg"]).to(device).requires_grad_()
-    loss_dict, log = Loss_Computation(small_cfg(str(device)))({"cls": cls, "reg": reg}, [t.to(device) for t in targets])
+    targets = [t.to(device) for t in targets]
+    loss = Loss_Computation(small_cfg(str(device)))
+    if through_row_kernel:
+        assert loss.fused_rows, "the row kernel is switched off (DCD_LOSS_ROWS)"
+        cx = torch.stack([t.get_field("target_centers") for t in targets]).long()
+        bidx = torch.arange(cx.shape[0], device=cx.device).view(-1, 1).expand(-1, cx.shape[1])
+        predictions = {"cls": cls, "reg": None, "reg_pois": reg[bidx, :, cx[:, :, 1], cx[:, :, 0]]}      # B x M x 415
+    else:
+        predictions = {"cls": cls, "reg": reg}
+    loss_dict, log = loss(predictions, targets)
     assert list(loss_dict.keys()) == LOSS_KEYS
     for k in LOSS_KEYS:
         ref = float(g["loss_" + k])

@@ -1,10 +1,12 @@
-"""Idle gaps between consecutive kernels in the last train step of a rocprofv3 rocpd db (steps delimited by the fused-Adam
-launches): prof_gaps.py <dir> [min_gap_us]"""
+"""Idle gaps between consecutive kernels in the last train step of a rocprofv3 rocpd db: prof_gaps.py <dir> [min_gap_us]
+Steps are delimited by the fused-AdamW launches, the same rule as prof_summary.py (round 3 delimited them by every
+`multi_tensor_apply` launch; the BN running-statistics updates and the gradient-norm reductions are multi-tensor launches in
+the MIDDLE of a step, so the window was cut short: 38.2 ms / 1 041 kernels next to a summary of 43.1 ms / 1 460)."""
 import glob, sqlite3, sys
 f = glob.glob(sys.argv[1] + "/**/*.db", recursive=True)[0]
 thr = float(sys.argv[2]) if len(sys.argv) > 2 else 20.0
 cur = sqlite3.connect(f).cursor()
-adam = [r[0] for r in cur.execute("select end from kernels where name like '%multi_tensor_apply%' order by end")]
+adam = [r[0] for r in cur.execute("select end from kernels where name like '%adam%' or name like '%Adam%' or name like '%FusedOptimizer%' order by end")]
 groups = []
 for e in adam:
     if not groups or e - groups[-1] > 5e6:

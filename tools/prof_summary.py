@@ -8,7 +8,7 @@ f = glob.glob(src + "/*.db")[0] if not src.endswith(".db") else src
 cur = sqlite3.connect(f).cursor()
 t0, t1 = cur.execute("select min(start), max(end) from kernels").fetchone()
 if steps:
-    adam = [r[0] for r in cur.execute("select end from kernels where name like '%adam%' or name like '%Adam%' order by end")]
+    adam = [r[0] for r in cur.execute("select end from kernels where name like '%adam%' or name like '%Adam%' or name like '%FusedOptimizer%' order by end")]
     groups = []
     for e in adam:
         if not groups or e - groups[-1] > 5e6:      # > 5 ms apart -> next step
