@@ -693,10 +693,11 @@ def _gen_pass(model, images, targets, torch, batched_eval=True):
             # ONCE on the batch here; the decode keeps its one-image form on slices of their outputs: same rows per image.
             feats = model.backbone(images)
             preds = model.heads.predictor(feats, targets)
-            for i in range(images.shape[0]):
-                one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
-                result, _, vis = model.heads.post_processor(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
-                n_det += len(infer_records(result, vis))
+            # ... and since round 4 the decode too (PostProcessor.forward_batch: one NMS / top-K, one gather, one solver call, every
+            # row with its own image's padding and intrinsics -> the rows of the image-by-image loop), records from ONE packed copy
+            from dcd_amd.engine.gen_data import infer_records_batch
+            rows, _, vis, image_of = model.heads.post_processor.forward_batch(preds, targets, test=model.test, features=feats)
+            n_det += sum(len(r) for r in infer_records_batch(rows, vis, image_of, images.shape[0]))
         else:
             for i in range(images.shape[0]):
                 result, _, vis = model(images[i:i + 1], targets[i:i + 1])

@@ -77,10 +77,13 @@ __host__ inline bool make_geom(Geom &g, int B, int C, int H, int W, int Co, int 
 // ---------------------------------------------------------------------------------------------
 // Weight re-layout: W[o][c][t] -> Wf[k'][Cop], Wb[Cop][Kp], zero padded.
 // ---------------------------------------------------------------------------------------------
-__global__ void dcn_prep_weights(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, Geom g)
+// (bid, nb: the block's index and the number of blocks doing this job -- the fused prologue kernels of the one-pass backward give a
+// launch's blocks different jobs)
+__device__ __forceinline__ void prep_weights_body(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, const Geom &g,
+                                                  int bid, int nb)
 {
     const int n = g.Kp * g.Cop;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    for (int idx = bid * blockDim.x + threadIdx.x; idx < n; idx += nb * blockDim.x) {
         // idx enumerates Wb (o-major) so that reads of w are roughly coalesced over k'
         const int o = idx / g.Kp, kp = idx - o * g.Kp;
         const int seg = kp / g.cpgp, cc = kp - seg * g.cpgp;  // seg = group*KK + tap
@@ -90,6 +93,10 @@ __global__ void dcn_prep_weights(const float *__restrict__ w, float *__restrict_
         wb[idx] = v;
         wf[(size_t)kp * g.Cop + o] = v;
     }
+}
+__global__ void dcn_prep_weights(const float *__restrict__ w, float *__restrict__ wf, float *__restrict__ wb, Geom g)
+{
+    prep_weights_body(w, wf, wb, g, blockIdx.x, gridDim.x);
 }
 
 // Per-(pixel, tap) sampling state shared by all channels of a deformable group.
@@ -804,9 +811,9 @@ __device__ __forceinline__ int inv_radius(const unsigned *absmax_bits)
 // Also lists the 32-pixel tiles (image-major tile ids, the generic kernels' tiling) that hold at least one sample displaced
 // by TL_NEAR px or more: the workgroup-tiled kernels leave exactly those samples to the generic kernels' far-only mode,
 // which then visits the listed tiles only (usually none).  scal[0] = max bits, scal[1] = number of listed tiles.
-__global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsigned *__restrict__ scal, int HoWo,
-                                  int ch_per_img, int tiles_per_img, unsigned char *__restrict__ far_flag,
-                                  int *__restrict__ far_list)
+__device__ __forceinline__ void offset_absmax_body(const float *__restrict__ off, int64_t n, unsigned *__restrict__ scal, int HoWo,
+                                                   int ch_per_img, int tiles_per_img, unsigned char *__restrict__ far_flag,
+                                                   int *__restrict__ far_list, int bid, int nb)
 {
     float m = 0.f;
     unsigned nfar = 0u;                                            // coordinates displaced by TL_NEAR px or more -> scal[3]
@@ -829,11 +836,11 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
         }
     };
     const int64_t n4 = ((uintptr_t)off & 15) == 0 ? n >> 2 : 0;     // 16-byte loads when the tensor allows it
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n4; i += (int64_t)gridDim.x * blockDim.x) {
+    for (int64_t i = (int64_t)bid * blockDim.x + threadIdx.x; i < n4; i += (int64_t)nb * blockDim.x) {
         const f32x4 v = *reinterpret_cast<const f32x4 *>(off + 4 * i);
         visit(4 * i, v.x); visit(4 * i + 1, v.y); visit(4 * i + 2, v.z); visit(4 * i + 3, v.w);
     }
-    for (int64_t i = 4 * n4 + (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x)
+    for (int64_t i = 4 * n4 + (int64_t)bid * blockDim.x + threadIdx.x; i < n; i += (int64_t)nb * blockDim.x)
         visit(i, off[i]);
     // one atomic per block: thousands of same-address atomics serialise in L2 (the earlier per-wave version spent most of
     // its 40 us there)
@@ -848,6 +855,12 @@ __global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsi
         const unsigned nf = partn[0] + partn[1] + partn[2] + partn[3];
         if (nf) atomicAdd(scal + 3, nf);
     }
+}
+__global__ void dcn_offset_absmax(const float *__restrict__ off, int64_t n, unsigned *__restrict__ scal, int HoWo,
+                                  int ch_per_img, int tiles_per_img, unsigned char *__restrict__ far_flag,
+                                  int *__restrict__ far_list)
+{
+    offset_absmax_body(off, n, scal, HoWo, ch_per_img, tiles_per_img, far_flag, far_list, blockIdx.x, gridDim.x);
 }
 
 // ceil(max(|dh|, |dw|)) over each 8x8 block of output pixels, per (image, tap segment): lets dcn_build_inverse search a
@@ -1269,26 +1282,26 @@ __global__ __launch_bounds__(BI_TR * 64) void dcn_bwd_input_tile_f32(const float
 
 // grad_bias[o] = sum_{b,p} dY[b,o,p].  grid = (Cout, splits); one float atomic per block (same-address atomics from
 // every wave of the data kernel serialised in L2 and cost more than the whole MFMA work).
-__global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo,
-                                                     const unsigned *__restrict__ only_if_far = nullptr)
+// (o, sp, nsp: the block's output channel, its slice and the number of slices)
+__device__ __forceinline__ void bias_grad_body(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo,
+                                               const unsigned *__restrict__ only_if_far, int o, int sp, int nsp)
 {
     // one-pass backward: its chunk-0 waves sum dY themselves (dcn_sweep_reduce_dw adds the partials); this kernel then runs only
     // when the generic kernels take the call over
     if (only_if_far && !far_dominated(only_if_far, B * ((HoWo + 31) / 32))) return;
     // block (o, split): split s walks its slice of every image's plane with 16-byte loads, no per-element index division
-    const int o = blockIdx.x;
     const int nq = HoWo >> 2;                                  // float4 per plane (planes are 16-byte aligned when HoWo % 4 == 0)
     const bool vec = (HoWo & 3) == 0;
     float acc = 0.f;
     for (int b = 0; b < B; ++b) {
         const float *p = gy + ((size_t)b * Co + o) * HoWo;
         if (vec) {
-            for (int i = blockIdx.y * 256 + threadIdx.x; i < nq; i += gridDim.y * 256) {
+            for (int i = sp * 256 + threadIdx.x; i < nq; i += nsp * 256) {
                 const f32x4 v = *reinterpret_cast<const f32x4 *>(p + 4 * i);
                 acc += (v.x + v.y) + (v.z + v.w);
             }
         } else {
-            for (int i = blockIdx.y * 256 + threadIdx.x; i < HoWo; i += gridDim.y * 256) acc += p[i];
+            for (int i = sp * 256 + threadIdx.x; i < HoWo; i += nsp * 256) acc += p[i];
         }
     }
 #pragma unroll
@@ -1297,6 +1310,11 @@ __global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ g
     if ((threadIdx.x & 63) == 0) part[threadIdx.x >> 6] = acc;
     __syncthreads();
     if (threadIdx.x == 0) atomicAdd(gbias + o, part[0] + part[1] + part[2] + part[3]);
+}
+__global__ __launch_bounds__(256) void dcn_bias_grad(const float *__restrict__ gy, float *__restrict__ gbias, int B, int Co, int HoWo,
+                                                     const unsigned *__restrict__ only_if_far = nullptr)
+{
+    bias_grad_body(gy, gbias, B, Co, HoWo, only_if_far, blockIdx.x, blockIdx.y, gridDim.y);
 }
 
 // ---------------------------------------------------------------------------------------------
@@ -2104,16 +2122,17 @@ struct ZeroRanges {
     unsigned *mark_p = nullptr;   // one word set to mark_v (must lie outside the ranges)
     unsigned mark_v = 0u;
 };
-__global__ void dcn_zero_ranges(ZeroRanges z)
+__device__ __forceinline__ void zero_ranges_body(const ZeroRanges &z, unsigned bid, unsigned nb)
 {
-    if (z.mark_p && blockIdx.x == 0 && threadIdx.x == 0) *z.mark_p = z.mark_v;
+    if (z.mark_p && bid == 0 && threadIdx.x == 0) *z.mark_p = z.mark_v;
 #pragma unroll
     for (int r = 0; r < 8; ++r) {
         unsigned *p = z.p[r];
         const unsigned n = z.n[r];
-        for (unsigned i = blockIdx.x * blockDim.x + threadIdx.x; i < n; i += gridDim.x * blockDim.x) p[i] = 0u;
+        for (unsigned i = bid * blockDim.x + threadIdx.x; i < n; i += nb * blockDim.x) p[i] = 0u;
     }
 }
+__global__ void dcn_zero_ranges(ZeroRanges z) { zero_ranges_body(z, blockIdx.x, gridDim.x); }
 
 inline int pick_mb(int nb, int tiles_total)
 {
@@ -2442,50 +2461,45 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                        (float *)((char *)workspace + base_workspace_bytes(g)), split);
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
-    hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
-                       0, stream, weight, wf, wb, g);
-
     const int tiles = (g.HoWo + 31) / 32;
     const int nblk = g.cpgp / 32;
+    if (!use_sweep)
+        hipLaunchKernelGGL(dcn_prep_weights, dim3((unsigned)((nw + 255) / 256 < 2048 ? (nw + 255) / 256 : 2048)), dim3(256),
+                           0, stream, weight, wf, wb, g);
     if (use_sweep) {
-        // ---- one-pass backward (dcn_bwd_sweep.inc).  Near samples: dcn_bwd_sweep_f32 + its two reductions.  Far samples
-        // (>= TL_NEAR px): the generic kernels' far-only pass over the listed tiles, grad_input by atomics.  Far samples
-        // dominating the call (device-side decision): the sweep returns at once, the inverse lists are built after all and the
-        // generic kernels do everything, as in the three-pass path.
+        // ---- one-pass backward (dcn_bwd_sweep.inc).  Near samples AND the (few) far ones: dcn_bwd_sweep.  Far samples dominating the
+        // call (device-side decision from the offset scan's count): the sweep returns at once, the inverse lists are built after all
+        // and the generic kernels do everything, as in the three-pass path (their launches below find nothing to do otherwise).
+        // Launches: prologue A (weight layouts, scalars), prologue B (zero fill, offset scan), sweep, [product], epilogue (three
+        // reductions), five guarded generic kernels = 9 (round 3: 13).
         const SweepPlan sp = sweep_plan(g);
         float *swp = (float *)((char *)workspace + base_workspace_bytes(g) + dense_workspace_bytes(g));
         float *cpart = swp + sp.wp_floats, *dwpart = cpart + sp.cpart_floats;
         const unsigned *fs = (const unsigned *)absmax;
-        // the generic data kernel's channel blocks over grid.z (its far-only pass is latency: a few listed tiles); with more than
-        // one block it accumulates grad_offset / grad_mask with atomics onto what dcn_sweep_reduce_coord wrote (zeros for the
-        // samples it owns)
+        // the generic data kernel's channel blocks over grid.z (when it runs it does the whole call); with more than
+        // one block it accumulates grad_offset / grad_mask with atomics onto what the epilogue wrote (zeros then)
         int nsplit = 1;
         while (nsplit * 2 <= nblk) nsplit *= 2;
         {
+            const int nb_gen = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
+            const int nb_sw = (int)((sp.wp_floats + 255) / 256 < 2048 ? (sp.wp_floats + 255) / 256 : 2048);
+            hipLaunchKernelGGL(dcn_sweep_prologue_a, dim3(nb_gen + nb_sw), dim3(256), 0, stream, weight, wf, wb, swp, absmax, g, sp.nck, sp.nob,
+                               split ? 1 : 0, nb_gen);
+        }
+        {
             ZeroRanges z;
             for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
-            z.p[0] = absmax; z.n[0] = 3;                     // [max |offset| bits, listed tiles (stays 0), overflowed lists]
-            z.mark_p = absmax + 3; z.mark_v = FAR_BY_COUNT;  // far-coordinate counter: the call is decided by its count (far_dominated)
-            z.p[1] = (unsigned *)far_flag; z.n[1] = (unsigned)((ntile + 3) / 4);
             z.p[2] = (unsigned *)grad_weight; z.n[2] = (unsigned)((size_t)Cout * Cin * g.KK);
             z.p[3] = (unsigned *)grad_bias; z.n[3] = (unsigned)Cout;
             z.p[4] = (unsigned *)grad_input; z.n[4] = (unsigned)((size_t)B * Cin * H * W);
-            hipLaunchKernelGGL(dcn_zero_ranges, dim3((unsigned)(z.n[4] / 1024 + 1 < 4096 ? z.n[4] / 1024 + 1 : 4096)), dim3(256), 0, stream, z);
-        }
-        if (split)
-            hipLaunchKernelGGL(dcn_sweep_prep_weights_bf16, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight,
-                               (unsigned *)swp, g, sp.nck, sp.nob);
-        else
-            hipLaunchKernelGGL(dcn_sweep_prep_weights, dim3((unsigned)((sp.wp_floats + 255) / 256)), dim3(256), 0, stream, weight, swp, g,
-                               sp.nck, sp.nob);
-        {
+            const int nb_zero = (int)(z.n[4] / 1024 + 1 < 4096 ? z.n[4] / 1024 + 1 : 4096);
             const int64_t noff = (int64_t)B * 18 * g.HoWo;
-            int gsz = (int)((noff + 4095) / 4096);
-            if (gsz > 512) gsz = 512;
-            // no tile list: the sweep takes its far samples itself; the far-only launches below then find nothing listed and
-            // return at once unless the call is handed to the generic kernels altogether
-            hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, 18, (g.HoWo + 31) / 32,
-                               (unsigned char *)nullptr, far_list);
+            int nb_scan = (int)((noff + 4095) / 4096);
+            if (nb_scan > 512) nb_scan = 512;
+            // no tile list (far_flag = null inside): the sweep takes its far samples itself; the far-only launches below then find
+            // nothing listed and return at once unless the call is handed to the generic kernels altogether
+            hipLaunchKernelGGL(dcn_sweep_prologue_b, dim3(nb_zero + nb_scan), dim3(256), 0, stream, z, nb_zero, offset, noff, absmax, g.HoWo,
+                               (g.HoWo + 31) / 32);
         }
         {
             SweepArgs a;
@@ -2511,28 +2525,31 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
 #undef DCD_LAUNCH_SWEEP
         }
         {
+            SweepEpilogueArgs e;
+            e.cpart = cpart; e.gy = grad_output; e.dwpart = dwpart; e.goff = grad_offset; e.gmsk = grad_mask; e.gw = grad_weight;
+            e.gbias = grad_bias; e.far_scal = fs; e.g = g; e.nck = sp.nck; e.total_tiles = B * tiles;
+            // nob == 1: the sweep's chunk-0 waves sum dY themselves (dcn_bias_grad's blocks then only act when the generic kernels
+            // take the call over)
+            e.bias_only_if_far = sp.nob == 1 ? fs : (const unsigned *)nullptr;
             const int64_t n4 = (int64_t)B * 27 * g.HoWo / 4;
-            hipLaunchKernelGGL(dcn_sweep_reduce_coord, dim3((unsigned)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096)), dim3(256), 0, stream,
-                               cpart, grad_offset, grad_mask, B, g.HoWo, sp.nck, fs, B * tiles);
-            {
-                int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
-                if (splits > 32) splits = 32;
-                if (splits < 1) splits = 1;
-                // nob == 1: the sweep's chunk-0 waves sum dY themselves (this launch then only acts when the generic kernels take over)
-                hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo,
-                                   sp.nob == 1 ? fs : (const unsigned *)nullptr);
-            }
+            e.nb_coord = (int)((n4 + 255) / 256 < 4096 ? (n4 + 255) / 256 : 4096);
+            int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
+            if (splits > 32) splits = 32;
+            if (splits < 1) splits = 1;
+            e.bias_splits = splits;
+            int nb_dw;
             if (sp.nob == 1) {
                 // grad_weight and grad_bias (the sweep's chunk-0 waves summed dY over their pixels) from the per-wave partials
                 const int nred = sp.nck * SW_DW_FLOATS + 64;
-                const int nvp = sp.nslot / sp.nck;
-                const int rg = nvp >= 64 ? 16 : (nvp >= 8 ? 4 : 1);
-                hipLaunchKernelGGL(dcn_sweep_reduce_dw, dim3((nred + 255) / 256, rg), dim3(256), 0, stream, dwpart, grad_weight, grad_bias, g,
-                                   sp.nck, nvp, fs, B * tiles);
+                e.nvp = sp.nslot / sp.nck;
+                e.dw_bx = (nred + 255) / 256;
+                e.dw_by = e.nvp >= 64 ? 16 : (e.nvp >= 8 ? 4 : 1);
+                e.gemm_n = 0; e.gemm_S = 0;
+                nb_dw = e.dw_bx * e.dw_by;
             } else {
                 // grad_weight = sum_b dY[b] (Cout x HoWo) col[b]^T (HoWo x 9 Cin): ONE batched product, both operands pixel-contiguous,
-                // partials per (image, pixel chunk) summed in a fixed order -- the near samples' part; the far-only pass below adds
-                // the rest with atomics.  Its row index c * 9 + t IS grad_weight's layout.
+                // partials per (image, pixel chunk) summed in a fixed order -- the near samples' part (the sweep's far loop wrote the
+                // far samples' masked values into col as well).  Its row index c * 9 + t IS grad_weight's layout.
                 static_assert(SW_GEMM_T == SG_T && SW_GEMM_K == SG_K, "sweep_plan sizes the product's partials with these");
                 const int K9 = Cin * 9, n = Cout * K9;
                 SgemmArgs ga;
@@ -2543,9 +2560,11 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                 ga.nsplit = sp.dw_split; ga.kchunk = sp.dw_kchunk; ga.ct = 0; ga.b_off = nullptr;
                 if (split) sgemm_bf16x3(stream, true, true, ga, B);
                 else sgemm_f32(stream, true, true, ga, B);
-                hipLaunchKernelGGL(dcn_sweep_reduce_gemm, dim3((n / 4 + 255) / 256 < 512 ? (n / 4 + 255) / 256 : 512), dim3(256), 0, stream,
-                                   dwpart, grad_weight, n, B * sp.dw_split, fs, B * tiles);
+                e.nvp = 0; e.dw_bx = 0; e.dw_by = 0;
+                e.gemm_n = n; e.gemm_S = B * sp.dw_split;
+                nb_dw = (n / 4 + 255) / 256 < 512 ? (n / 4 + 255) / 256 : 512;
             }
+            hipLaunchKernelGGL(dcn_sweep_epilogue, dim3(e.nb_coord + Cout * splits + nb_dw), dim3(256), 0, stream, e);
         }
         // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
         inv.packed = 0;

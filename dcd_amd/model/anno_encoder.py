@@ -126,14 +126,16 @@ class Anno_Encoder():
         xy = ((pts - tab[:, 0:2]) * depths.unsqueeze(1)) / tab[:, 2:4] + tab[:, 4:6]
         return torch.cat((xy, depths.unsqueeze(1)), dim=1)
 
-    def decode_depth_from_keypoints_batch(self, pred_keypoints, pred_dimensions, calibs, batch_idxs=None):
+    def decode_depth_from_keypoints_batch(self, pred_keypoints, pred_dimensions, calibs, batch_idxs=None, f_u=None):
         """Depth from the projected height of the centre line and the two corner groups (anno_encoder.py:193-224).
         Quirk kept: the reference indexes `calibs` by the RANK of the image among the images that own objects
         (`calibs[idx]`, :206-207), which differs from the image index only if some image has no object."""
         pred_height_3D = pred_dimensions[:, 1]
         n_img = len(calibs)
         tab = self._calib_table(calibs, pred_keypoints.device)
-        if n_img == 1 or batch_idxs is None:
+        if f_u is not None:                                      # the caller's per-row focal lengths (PostProcessor.forward_batch)
+            pass
+        elif n_img == 1 or batch_idxs is None:
             f_u = tab[0, 2]
         else:
             bi = batch_idxs.long()

@@ -58,15 +58,18 @@ class PostProcessor(nn.Module):
     # ---- stage 1: which cells are detections ------------------------------------------------------------------------
     def _detections(self, heat, reg):
         """3x3 max-pool NMS + per-image top-K in one launch (nms_hm -> select_topk, detector_infer.py:101-106), score
-        threshold (the one host sync of the decode), regression vectors of the kept cells."""
+        threshold (the one host sync of the decode), regression vectors of the kept cells.  Any batch: `image_of` is the image
+        each kept row came from (rows stay in (image, rank) order)."""
         scores, cell_idx, classes, ys, xs = select_topk(heat, K=self.max_detection, fuse_nms=True)
         vectors = select_point_of_interest(heat.shape[0], cell_idx, reg).view(-1, reg.shape[1])
+        per_image = scores.shape[1]
         scores = scores.view(-1)
         keep = (scores >= self.det_threshold).nonzero(as_tuple=True)[0]
         if keep.numel() == 0:
             return None
         centres = torch.stack((xs.view(-1), ys.view(-1)), dim=1)
-        return {"scores": scores[keep], "classes": classes.view(-1)[keep], "centres": centres[keep], "vectors": vectors[keep]}
+        return {"scores": scores[keep], "classes": classes.view(-1)[keep], "centres": centres[keep], "vectors": vectors[keep],
+                "image_of": torch.div(keep, per_image, rounding_mode="floor")}
 
     @staticmethod
     def _nothing_detected(like, vis):
@@ -77,11 +80,20 @@ class PostProcessor(nn.Module):
         return empty(0, 14), info, vis
 
     # ---- stage 2: per-head decodes -----------------------------------------------------------------------------------
-    def _decode_heads(self, det, ctx, reg, vis):
+    def _decode_heads(self, det, ctx, reg, vis, image_of=None):
+        """image_of = None: the reference's one-image decode (first image's padding / size / calibration for every row);
+        image_of given (forward_batch): every row with its own image's."""
         enc, sl, vec = self.anno_encoder, self.key2channel, det["vectors"]
         out = {"offset_3d": vec[:, sl('3d_offset')]}
         vis['proj_center'] = det["centres"] + out["offset_3d"]
-        out["box2d"] = enc.decode_box2d_fcos(det["centres"], F.relu(vec[:, sl('2d_dim')]), ctx["pad_size"], ctx["size"])
+        if image_of is None:
+            out["box2d"] = enc.decode_box2d_fcos(det["centres"], F.relu(vec[:, sl('2d_dim')]), ctx["pad_size"], ctx["size"])
+        else:                                                  # the same arithmetic with per-row padding and image size (:82-89)
+            off2d = F.relu(vec[:, sl('2d_dim')])
+            c2 = det["centres"].view(-1, 2)
+            box2d = torch.cat((c2 - off2d[:, :2], c2 + off2d[:, 2:]), dim=1) * enc.down_ratio - ctx["pad_size"][image_of].repeat(1, 2)
+            lim = ctx["size"][image_of].to(box2d).repeat(1, 2) - 1
+            out["box2d"] = torch.min(box2d.clamp(min=0), lim)
         out["dims"] = enc.decode_dimension(det["classes"], vec[:, sl('3d_dim')])
         out["orientation"] = torch.cat((vec[:, sl('ori_cls')], vec[:, sl('ori_offset')]), dim=1)
         if self.pred_direct_depth:
@@ -91,7 +103,11 @@ class PostProcessor(nn.Module):
             vis['depth_uncertainty'] = reg[:, sl('depth_uncertainty'), ...].squeeze(1)
         if self.regress_keypoints:
             out["corner_offsets"] = vec[:, sl('corner_offset')].view(-1, 10, 2)
-            out["corner_depths"] = enc.decode_depth_from_keypoints_batch(out["corner_offsets"], out["dims"], ctx["calib"])
+            if image_of is None:
+                out["corner_depths"] = enc.decode_depth_from_keypoints_batch(out["corner_offsets"], out["dims"], ctx["calib"])
+            else:                                              # each row with its own image's focal length (no rank quirk: :206-207
+                f_u = enc._calib_table(ctx["calib"], vec.device)[image_of, 2]        # only bites when one call holds several images)
+                out["corner_depths"] = enc.decode_depth_from_keypoints_batch(out["corner_offsets"], out["dims"], ctx["calib"], f_u=f_u)
             vis['keypoints'] = out["corner_offsets"]
         if self.keypoint_depth_with_uncertainty:
             out["corner_sigma"] = vec[:, sl('corner_uncertainty')].exp()
@@ -110,6 +126,18 @@ class PostProcessor(nn.Module):
         return (depths * weights).sum(dim=1), (weights * sigma).sum(dim=1)
 
     def forward(self, predictions, targets, features=None, test=False, refine_module=None):
+        return self._decode(predictions, targets, test, batched=False)
+
+    def forward_batch(self, predictions, targets, features=None, test=False):
+        """The decode for a whole batch at once (round 4; BASELINE config 4 runs it on 16 images): ONE NMS + top-K launch, one
+        POI gather, one threshold (one host sync), one edge-solver call, every row decoded with ITS OWN image's padding, size and
+        intrinsics -- i.e. exactly what `forward` gives when called image by image (the reference's loop,
+        DGDE/engine/inference.py:59-84, TEST.IMS_PER_BATCH = 1), row for row, in (image, rank) order.  Returns
+        (rows (N, 14), info, vis, image_of (N,)); `engine.gen_data.infer_records_batch` splits the records per image after ONE
+        device-to-host copy."""
+        return self._decode(predictions, targets, test, batched=True)
+
+    def _decode(self, predictions, targets, test, batched):
         if self.eval_dis_iou or self.eval_depth:
             raise NotImplementedError("TEST.EVAL_DIS_IOUS / TEST.EVAL_DEPTH call functions the reference never defines "
                                       "(detector_infer.py:95,98)")
@@ -119,12 +147,16 @@ class PostProcessor(nn.Module):
         vis = {'heat_map': heat.clone()}
         det = self._detections(heat, reg)
         if det is None:
-            return self._nothing_detected(heat, vis)
-        dec = self._decode_heads(det, ctx, reg, vis)
+            out = self._nothing_detected(heat, vis)
+            return out + (heat.new_zeros(0).long(),) if batched else out
+        rows_image = det["image_of"] if batched else None
+        dec = self._decode_heads(det, ctx, reg, vis, rows_image)
         fused_depth, depth_error = self._fuse_depths(dec, vis)
 
         centres, offset = det["centres"], dec["offset_3d"]
-        image_of = fused_depth.new_zeros(fused_depth.shape[0]).long()          # batch size 1, like the reference (:173)
+        # one-image form: batch size 1, like the reference (:173)
+        image_of = rows_image if batched else fused_depth.new_zeros(fused_depth.shape[0]).long()
+        ctx["rows_image"] = rows_image
         coarse = enc.decode_location_flatten(centres, offset, fused_depth, ctx["calib"], ctx["pad_size"], image_of)
         rotys, alphas = enc.decode_axes_orientation(dec["orientation"], coarse)
         rotys, alphas = rotys.view(-1, 1), alphas.view(-1, 1)
@@ -149,19 +181,34 @@ class PostProcessor(nn.Module):
         rows = torch.cat([det["classes"].view(-1, 1), alphas, dec["box2d"], dims_hwl, locations, rotys, scores], dim=1)
         info = {'dis_ious': None, 'depth_errors': None, 'uncertainty_conf': confidence, 'estimated_depth_error': depth_error,
                 'vis_scores': raw_scores}
-        return rows, info, vis
+        return (rows, info, vis, rows_image) if batched else (rows, info, vis)
 
     def _image_kpts(self, targets, pois, pred_bbox_points, pred_offset_3D):
         k2c = self.key2channel
         kp2d = pois[:, k2c('extra_kpts_2d')].reshape((-1, self.extra_kpts_num + 10, 2))
-        real_2d = (kp2d + (pred_bbox_points + pred_offset_3D).unsqueeze(1).expand_as(kp2d)) * 4 - targets["pad_size"]
+        rows_image = targets.get("rows_image")
+        pad = targets["pad_size"] if rows_image is None else targets["pad_size"][rows_image].unsqueeze(1)
+        real_2d = (kp2d + (pred_bbox_points + pred_offset_3D).unsqueeze(1).expand_as(kp2d)) * 4 - pad
         kp3d = pois[:, k2c('extra_kpts_3d')].reshape((kp2d.shape[0], -1, 3))
         return real_2d, kp3d
 
+    def _rows_P(self, targets, like):
+        """(n, 3, 4) projection matrices of the rows: image 0's for all (one-image decode, detector_infer.py:186,237) or each
+        row's own image's (forward_batch).  One host-to-device copy per distinct set of intrinsics."""
+        import numpy as np
+        rows_image = targets.get("rows_image")
+        if rows_image is None:
+            P = torch.as_tensor(targets['calib'][0].P, dtype=torch.float32, device=like.device)
+            return P.unsqueeze(0).expand(like.shape[0], -1, -1)
+        key = tuple(np.asarray(c.P, dtype=np.float32).tobytes() for c in targets['calib'])
+        if getattr(self, "_P_cache", (None, None))[0] != (key, str(like.device)):
+            tab = torch.as_tensor(np.stack([np.asarray(c.P, dtype=np.float32) for c in targets['calib']]), device=like.device)
+            self._P_cache = ((key, str(like.device)), tab)
+        return self._P_cache[1][rows_image]
+
     def compute_pairs_kpts_depth(self, targets, pois, pred_bbox_points, pred_offset_3D, pred_rots, vis_pred):
         real_2d, kp3d = self._image_kpts(targets, pois, pred_bbox_points, pred_offset_3D)
-        P = torch.as_tensor(targets['calib'][0].P, dtype=torch.float32, device=real_2d.device)
-        P = P.unsqueeze(0).expand(real_2d.shape[0], -1, -1)
+        P = self._rows_P(targets, real_2d)
         pairs_depths, _ = self.anno_encoder.decode_pairs_kpts_depth(real_2d, kp3d, pred_rots, P)
         vis_pred['pred_extra_kpts_2d'] = real_2d
         vis_pred['pred_extra_kpts_3d'] = kp3d
@@ -173,8 +220,12 @@ class PostProcessor(nn.Module):
         object, as in the reference (:237).  The records (SURVEY.md section 8f-2 schema) are kept on device in
         `vis_pred['gen_*']`; the caller serialises them."""
         real_2d, kp3d = self._image_kpts(targets, pois, pred_bbox_points, pred_offset_3D)
-        K = torch.as_tensor(targets['calib'][0].P[:, :3], dtype=real_2d.dtype, device=real_2d.device)
-        kn = torch.stack(((real_2d[:, :, 0] - K[0, 2]) / K[0, 0], (real_2d[:, :, 1] - K[1, 2]) / K[1, 1]), dim=-1)
+        if targets.get("rows_image") is None:
+            K = torch.as_tensor(targets['calib'][0].P[:, :3], dtype=real_2d.dtype, device=real_2d.device)
+            kn = torch.stack(((real_2d[:, :, 0] - K[0, 2]) / K[0, 0], (real_2d[:, :, 1] - K[1, 2]) / K[1, 1]), dim=-1)
+        else:                                                  # every row with its own image's intrinsics
+            P = self._rows_P(targets, real_2d)
+            kn = torch.stack(((real_2d[:, :, 0] - P[:, 0, 2:3]) / P[:, 0, 0:1], (real_2d[:, :, 1] - P[:, 1, 2:3]) / P[:, 1, 1:2]), dim=-1)
         vis_pred['gen_pred_extra_kpts_2d'] = kn
         vis_pred['gen_pred_extra_kpts_3d'] = kp3d
         if pred_box2d is not None:

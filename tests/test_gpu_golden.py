@@ -520,6 +520,54 @@ def test_generate_for_gmw_pass_full_size(cuda):
             assert (r_b - r_1).abs().max().item() <= 1e-4 * max(r_1.abs().max().item(), 1.0)
 
 
+def test_batched_post_processor_equals_the_image_by_image_decode(cuda):
+    """VERDICT r3 item 5 -- BASELINE config 4's batch (16 images): `PostProcessor.forward_batch` (one NMS / top-K, one gather, one
+    solver call, one packed copy for the records) against the reference's loop of one-image decodes (DGDE/engine/inference.py:59-84,
+    detector_infer.py:86-243) on the same predictions: identical rows in (image, rank) order -- with intrinsics and image sizes that
+    DIFFER between the images, so a row decoded with another image's calibration would show -- and identical GMW records."""
+    import argparse
+    import sys
+    root = __import__("os").path.dirname(__import__("os").path.dirname(__import__("os").path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from dcd_amd.engine.gen_data import infer_records, infer_records_batch
+    args = argparse.Namespace(batch=16, objects=6)
+    cfg, model, images, targets = bench._gen_build(args, cuda)
+    for i, t in enumerate(targets):                                # per-image intrinsics (KITTI sequences differ slightly), padding, size
+        from dcd_amd.data.calibration import Calibration
+        P = np.array(t.get_field("calib").P, dtype=np.float64).copy()
+        s_ = 1.0 + 0.01 * i
+        P[0, 0] *= s_; P[1, 1] *= s_; P[0, 2] += i; P[1, 2] -= 0.5 * i
+        t.add_field("calib", Calibration(P))
+        t.add_field("pad_size", t.get_field("pad_size") + (i % 3))
+        t.size = (t.size[0] - 2 * (i % 4), t.size[1] - (i % 2))
+    model.eval()
+    pp = model.heads.post_processor
+    with torch.no_grad():
+        feats = model.backbone(images)
+        preds = model.heads.predictor(feats, targets)
+        rows, _, vis, image_of = pp.forward_batch(preds, targets, test=model.test, features=feats)
+        recs_b = infer_records_batch(rows, vis, image_of, images.shape[0])
+        assert rows.shape == (16 * cfg.TEST.DETECTIONS_PER_IMG, 14) and bool(torch.isfinite(rows).all())
+        assert image_of.tolist() == sorted(image_of.tolist())
+        for i in range(images.shape[0]):
+            one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
+            r_1, _, vis_1 = pp(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
+            r_b = rows[image_of == i]
+            assert r_b.shape == r_1.shape
+            assert torch.equal(r_b[:, 0], r_1[:, 0]) and torch.equal(r_b[:, 13], r_1[:, 13])     # classes and scores: same cells, same order
+            assert (r_b - r_1).abs().max().item() <= 1e-5 * max(r_1.abs().max().item(), 1.0), i
+            recs_1 = infer_records(r_1, vis_1)
+            assert len(recs_1) == len(recs_b[i])
+            for a_, b_ in zip(recs_1, recs_b[i]):
+                assert a_.keys() == b_.keys()
+                for k in a_:
+                    if k != "cat":
+                        assert np.allclose(np.array(a_[k]), np.array(b_[k]), rtol=1e-5, atol=1e-5), (i, k)
+
+
+
 def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
     """Advisor r2: a checkpoint written from the GPU optimizer (tensor learning rates, capturable fused AdamW) must be the
     reference's plain layout on disk (floats, capturable off: the reference adopts the saved groups verbatim after
@@ -576,3 +624,51 @@ def test_checkpoint_round_trip_keeps_device_learning_rates(cuda, tmp_path):
     for g in opt2.param_groups:
         g["lr"].fill_(7e-5)                                                         # what a scheduler step does to a tensor rate
     assert all(g["lr"] is t and abs(float(t) - 7e-5) < 1e-10 for g, t in zip(opt2.param_groups, lr_objs))
+
+
+def test_whole_train_step_at_baseline_size(cuda):
+    """VERDICT r3 item 8a -- BASELINE configs[1] as a test: one whole train step (forward, 13-term loss, backward, clip, fused
+    AdamW) at bs 8, 384x1280, the size `bench.py` times.  Three steps each of (a) the eager step, (b) the whole-step HIP graph and
+    (c) the eager step with the DCN products / 3x3 convolutions in split-bf16 (`bf16x3`), all from the same seed on the same
+    batch.  Losses finite and falling; on the first step (same weights) graph == eager at 1e-4 and split-bf16 within north_star's
+    1e-3 of the fp32 total loss; later steps within the run-to-run spread of the eager step itself (see below)."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from dcd_amd import _ext
+    from dcd_amd.engine import trainer
+
+    def run(mode):
+        args = argparse.Namespace(batch=8, objects=6, precision="bf16x3" if mode == "split" else "f32", scaling="weak", amp=False)
+        cfg, model, optimizer, images, targets = bench.build_everything(args, cuda, 1, 0)[:5]
+        clip = cfg.SOLVER.GRAD_NORM_CLIP
+        step = trainer.GraphedTrainStep(model, optimizer, clip) if mode == "graph" else None
+        losses = []
+        try:
+            for _ in range(3):
+                ld, _ = step(images, targets) if step else trainer.train_step(model, optimizer, images, targets, clip)
+                total = getattr(ld, "total", None)
+                losses.append(float(total if total is not None else sum(ld.values())))
+                assert len(ld) == 13
+        finally:
+            _ext.set_precision("f32")
+        torch.cuda.synchronize()
+        return losses
+
+    eager, graph, split = run("eager"), run("graph"), run("split")
+    for ls in (eager, graph, split):
+        assert all(l == l and 0.0 < l < 1e4 for l in ls), ls
+        assert ls[2] < ls[0], ls                                   # three steps on one batch: the loss comes down
+    # step 1 starts from identical weights: graph == eager to fp32 noise, split-bf16 within north_star's 1e-3.  Steps 2-3 follow
+    # AdamW's first updates, which move every weight by ~lr whatever the size of its gradient -- the sign of a near-zero gradient
+    # component is noise (fp32 atomics), so two runs of the SAME eager code are a few per cent apart by step 3 (measured here:
+    # 21.82 / 19.48 against 21.76 / 20.21); the later steps are therefore held to 10 %, the trend to "falling".
+    assert abs(graph[0] - eager[0]) <= 1e-4 * eager[0], (eager, graph)
+    assert abs(split[0] - eager[0]) <= 1e-3 * eager[0], (eager, split)
+    for other in (graph, split):
+        for a, b in zip(eager[1:], other[1:]):
+            assert abs(a - b) <= 0.1 * a, (eager, other)
