@@ -668,6 +668,9 @@ def _gen_build(args, device):
     model = KeypointDetector(cfg)
     init_like_trained(model, std=0.01, seed=0)
     model = model.to(device)
+    # inference heads at the top-K cells only (the decode reads nothing else, detector_infer.py:101-110); DCD_GEN_DENSE_HEADS=1 keeps
+    # the reference's dense 415-channel map
+    model.heads.predictor.sparse_eval_heads = device.type == "cuda" and os.environ.get("DCD_GEN_DENSE_HEADS", "0") != "1"
     images, targets = make_batch(args.batch, seed=100, n_objects=args.objects, device=device if device.type == "cuda" else None)
     return cfg, model, images, targets
 

@@ -56,12 +56,19 @@ class PostProcessor(nn.Module):
         return out
 
     # ---- stage 1: which cells are detections ------------------------------------------------------------------------
-    def _detections(self, heat, reg):
+    def _detections(self, heat, reg, predictions=None):
         """3x3 max-pool NMS + per-image top-K in one launch (nms_hm -> select_topk, detector_infer.py:101-106), score
         threshold (the one host sync of the decode), regression vectors of the kept cells.  Any batch: `image_of` is the image
-        each kept row came from (rows stay in (image, rank) order)."""
-        scores, cell_idx, classes, ys, xs = select_topk(heat, K=self.max_detection, fuse_nms=True)
-        vectors = select_point_of_interest(heat.shape[0], cell_idx, reg).view(-1, reg.shape[1])
+        each kept row came from (rows stay in (image, rank) order).  A predictor with `sparse_eval_heads` has done the top-K
+        itself and hands over the heads at those cells (`reg_pois`, `topk`)."""
+        if predictions is not None and predictions.get('topk') is not None:
+            scores, cell_idx, classes, ys, xs = predictions['topk']
+            vectors = predictions['reg_pois'].reshape(-1, predictions['reg_pois'].shape[-1])
+            if vectors.shape[0] != scores.numel():
+                raise ValueError("predictions['topk'] holds %d cells, predictions['reg_pois'] %d rows" % (scores.numel(), vectors.shape[0]))
+        else:
+            scores, cell_idx, classes, ys, xs = select_topk(heat, K=self.max_detection, fuse_nms=True)
+            vectors = select_point_of_interest(heat.shape[0], cell_idx, reg).view(-1, reg.shape[1])
         per_image = scores.shape[1]
         scores = scores.view(-1)
         keep = (scores >= self.det_threshold).nonzero(as_tuple=True)[0]
@@ -100,7 +107,7 @@ class PostProcessor(nn.Module):
             out["direct_depth"] = enc.decode_depth(vec[:, sl('depth')].squeeze(-1))
         if self.depth_with_uncertainty:
             out["direct_sigma"] = vec[:, sl('depth_uncertainty')].exp()
-            vis['depth_uncertainty'] = reg[:, sl('depth_uncertainty'), ...].squeeze(1)
+            vis['depth_uncertainty'] = reg[:, sl('depth_uncertainty'), ...].squeeze(1) if reg is not None else None   # (dense map: visualiser only)
         if self.regress_keypoints:
             out["corner_offsets"] = vec[:, sl('corner_offset')].view(-1, 10, 2)
             if image_of is None:
@@ -145,7 +152,7 @@ class PostProcessor(nn.Module):
         enc = self.anno_encoder
         ctx = self.prepare_targets(targets, test=test)
         vis = {'heat_map': heat.clone()}
-        det = self._detections(heat, reg)
+        det = self._detections(heat, reg, predictions)
         if det is None:
             out = self._nothing_detected(heat, vis)
             return out + (heat.new_zeros(0).long(),) if batched else out

@@ -99,6 +99,12 @@ class _predictor(nn.Module):
         # zero-filled 415-channel gradient map, its 12 slices, 12 dense 1x1 data/weight gradients all disappear.  The result
         # is `reg_pois` (B, MAX_OBJECTS, 415); `reg` is then None.  False restores the reference's dense training output.
         self.sparse_training_heads = True
+        # Inference needs the regression heads at the TEST.DETECTIONS_PER_IMG top-scoring cells only (detector_infer.py:101-110).
+        # True: the class map is computed densely, NMS + top-K run HERE, and the trunks / output layers are evaluated at those
+        # cells (`reg_pois` (B, K, 415) + the top-K result under 'topk'; `reg` is None) -- the PostProcessor takes both as they
+        # are.  False (default): the reference's dense (B, 415, H, W) map.
+        self.sparse_eval_heads = False
+        self.max_detection = cfg.TEST.DETECTIONS_PER_IMG
         if self.enable_edge_fusion:
             norm1d = nn.BatchNorm1d if cfg.MODEL.HEAD.EDGE_FUSION_NORM == 'BN' else nn.Identity
             k = self.edge_fusion_kernel_size
@@ -214,13 +220,18 @@ class _predictor(nn.Module):
         outs = []
         # All trunks at once from the Gram matrix of the shared input's 3x3 patches: no dense trunk output exists (trunk_moments.py)
         moments = None
-        if not self.deeper_head and all(isinstance(fl[2], nn.Identity) for fl in self.reg_features) \
-                and trunk_moments.usable(self.reg_features, reg_inputs[0]):
+        frozen_bn = (not self.deeper_head and _HEAD_ROWS and features.is_cuda and features.dtype == torch.float32
+                     and not torch.is_grad_enabled() and self._head_rows_ok() and trunk_moments.frozen(self.reg_features, reg_inputs[0]))
+        if frozen_bn or (not self.deeper_head and all(isinstance(fl[2], nn.Identity) for fl in self.reg_features)
+                         and trunk_moments.usable(self.reg_features, reg_inputs[0])):
             extra = (self.offset_index[0], edge_lin) if self.enable_edge_fusion else None
-            if _HEAD_ROWS and features.is_cuda and features.dtype == torch.float32 and self._head_rows_ok():
+            if frozen_bn or (_HEAD_ROWS and features.is_cuda and features.dtype == torch.float32 and self._head_rows_ok()):
                 # every 1x1 output layer at the object centres in ONE launch (ops.head_rows) instead of a GEMM per head, their
                 # concatenation and -- backward -- two GEMMs, a bias sum and a slice copy per head
-                at_centres, at_extra = trunk_moments.trunks_at(reg_inputs[0], self.reg_features, centers_lin, extra, stacked=True)
+                if frozen_bn:      # --generate_for_GMW pass: BatchNorm frozen, no gradients -> no statistics, no dense trunk output
+                    at_centres, at_extra = trunk_moments.trunks_at_frozen(reg_inputs[0], self.reg_features, centers_lin, extra)
+                else:
+                    at_centres, at_extra = trunk_moments.trunks_at(reg_inputs[0], self.reg_features, centers_lin, extra, stacked=True)
                 heads = [(i, h) for i, hs in enumerate(self.reg_heads) for h in hs]
                 reg_pois = ops.head_rows(at_centres.reshape(n_reg, b * M, self.head_conv), [i for i, _ in heads],
                                          [h.weight for _, h in heads], [h.bias for _, h in heads]).view(b, M, -1)
@@ -286,10 +297,45 @@ class _predictor(nn.Module):
         output_cls.index_put_((bi, co, yi, xi), edge_cls_output * valid.unsqueeze(1), accumulate=True)
         return output_cls
 
+    def _forward_sparse_eval(self, features, targets):
+        """Inference forward with the regression heads at the top-K cells only (see `sparse_eval_heads`)."""
+        from dcd_amd.model.layers.utils import select_topk
+        feature_cls = self.class_head[:-1](features)
+        output_cls = self.class_head[-1](feature_cls)
+        b, _, h, w = feature_cls.shape
+        if self.enable_edge_fusion:
+            output_cls = self._edge_fusion_cls(feature_cls, output_cls, targets)
+        heat = sigmoid_hm(output_cls).float()
+        topk = select_topk(heat, K=self.max_detection, fuse_nms=True)                 # scores, cell index, classes, ys, xs: (B, K) each
+        centers_lin = topk[1].long().view(b, -1)
+        M = centers_lin.shape[1]
+        extra = None
+        if self.enable_edge_fusion:
+            edge_indices = stack_field(targets, "edge_indices")
+            edge_lens = stack_field(targets, "edge_len").view(b, 1)
+            K = edge_indices.shape[1]
+            edge_lin = edge_indices[:, :, 1].long() * w + edge_indices[:, :, 0].long()
+            edge_valid = torch.arange(K, device=edge_lin.device).view(1, K) < edge_lens
+            extra = (self.offset_index[0], edge_lin)
+        at_centres, at_extra = trunk_moments.trunks_at_frozen(features, self.reg_features, centers_lin, extra)
+        heads = [(i, hd) for i, hs in enumerate(self.reg_heads) for hd in hs]
+        reg_pois = ops.head_rows(at_centres.reshape(len(self.reg_features), b * M, self.head_conv), [i for i, _ in heads],
+                                 [hd.weight for _, hd in heads], [hd.bias for _, hd in heads]).view(b, M, -1)
+        if self.enable_edge_fusion:
+            first = sum(len(hs) for hs in self.reg_heads[:self.offset_index[0]]) + self.offset_index[1]
+            ch0 = sum(hd.out_channels for _, hd in heads[:first])
+            edge = self._edge_fusion_at_pois(at_extra.transpose(1, 2), edge_lin, edge_valid, centers_lin)
+            reg_pois = reg_pois + F.pad(edge, (ch0, reg_pois.shape[2] - ch0 - edge.shape[2]))
+        return {'cls': heat, 'reg': None, 'reg_pois': reg_pois.float(), 'topk': topk}
+
     def forward(self, features, targets):
         if (self.training and self.sparse_training_heads and targets is not None and self.exact_edge_gather
                 and self.output_width == features.shape[3] and self.output_height == features.shape[2]):
             return self._forward_sparse(features, targets)
+        if (not self.training and self.sparse_eval_heads and not self.deeper_head and features.is_cuda and features.dtype == torch.float32
+                and not torch.is_grad_enabled() and self._head_rows_ok() and trunk_moments.frozen(self.reg_features, features)
+                and self.output_width == features.shape[3] and self.output_height == features.shape[2]):
+            return self._forward_sparse_eval(features, targets)
         feat_cls_in = self.cls_head_pre(features) if self.deeper_head else features
         feature_cls = self.class_head[:-1](feat_cls_in)
         output_cls = self.class_head[-1](feature_cls)

@@ -358,3 +358,51 @@ def trunks_at(x, trunks, centers, extra=None, stacked=False):
     if at_extra is not None:
         out[extra[0]] = torch.cat((out[extra[0]], at_extra), dim=1)
     return out
+
+
+def frozen(trunks, x):
+    """The eleven-trunk shape with the BatchNorm layers in EVAL mode (running statistics: the --generate_for_GMW pass freezes
+    them, DGDE/engine/trainer.py:62-67, and inference uses them): `trunks_at_frozen` then needs no statistics at all."""
+    from dcd_amd.model.layers.norm import BatchNorm2d
+    if x.dim() != 4 or x.dtype not in (torch.float32, torch.float64):
+        return False
+    for t in trunks:
+        conv, bn = t[0], t[1]
+        if not (isinstance(bn, BatchNorm2d) and bn.fuse_relu and not bn.training and bn.track_running_stats
+                and conv.kernel_size == (3, 3) and conv.stride == (1, 1) and conv.padding == (1, 1) and conv.dilation == (1, 1)
+                and conv.groups == 1 and conv.bias is None and conv.in_channels == x.shape[1] and isinstance(t[2], torch.nn.Identity)):
+            return False
+    return True
+
+
+def trunks_at_frozen(x, trunks, centers, extra=None):
+    """`trunks_at(..., stacked=True)` for BatchNorm layers that normalise with their RUNNING statistics: conv3x3 + BN + ReLU of every
+    trunk at `centers` (B, M) linear pixel indices only -- the 3x3 patches gathered from the zero-padded input, one einsum against the
+    stacked weights -- instead of eleven dense convolutions whose outputs are read at a few dozen cells (config 4: 16 images x 50
+    detections of 30 720 cells).  Returns ((T, B, M, Cout), the `extra` trunk at its positions (B, Ke, Cout) or None)."""
+    B, C, H, W = x.shape
+    T, K = len(trunks), 9 * C
+    Wall = torch.stack([t[0].weight.reshape(t[0].out_channels, K) for t in trunks])            # (T, O, 9C)
+    rm = torch.stack([t[1].running_mean for t in trunks]).to(x.dtype)
+    rv = torch.stack([t[1].running_var for t in trunks]).to(x.dtype)
+    gamma = torch.stack([t[1].weight for t in trunks]).to(x.dtype)
+    beta = torch.stack([t[1].bias for t in trunks]).to(x.dtype)
+    scale = gamma * torch.rsqrt(rv + trunks[0][1].eps)
+    shift = beta - rm * scale
+    xp = F.pad(x, (1, 1, 1, 1)).flatten(2)                                                     # (B, C, (H+2)(W+2))
+    taps = _taps(W, x.device)
+
+    def patches(pos):                                                                          # (B, n) -> (B, 9C, n), row c*9 + tap
+        pos = pos.long()
+        base = (pos // W) * (W + 2) + pos % W
+        n = pos.shape[1]
+        idx = (base.unsqueeze(1) + taps.view(1, 9, 1)).reshape(B, 1, 9 * n).expand(B, C, 9 * n)
+        return xp.gather(2, idx).reshape(B, K, n)
+    y = torch.einsum('bkm,tok->tbmo', patches(centers), Wall)
+    at_centres = torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1))
+    at_extra = None
+    if extra is not None:
+        i, pos = extra
+        ye = torch.einsum('bkm,ok->bmo', patches(pos), Wall[i])
+        at_extra = torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))
+    return at_centres, at_extra

@@ -11,6 +11,17 @@ import test_host_golden as H
 pytestmark = pytest.mark.gpu
 
 
+def _one_image(preds, i):
+    """Image i of a predictor output: tensors sliced, the top-K tuple of a `sparse_eval_heads` predictor slice by slice."""
+    def cut(v):
+        if torch.is_tensor(v):
+            return v[i:i + 1]
+        if isinstance(v, tuple):
+            return tuple(cut(u) for u in v)
+        return v
+    return {k: cut(v) for k, v in preds.items()}
+
+
 def test_native_library_is_loaded(cuda):
     from dcd_amd import _lib
     L = _lib.lib()
@@ -139,7 +150,10 @@ def test_whole_model_in_split_bf16_precision(cuda, monkeypatch):
     monkeypatch.setattr(ops, "_CONV_SPLIT_MIN_MAP", 0)
     _ext.set_precision("bf16x3")
     try:
-        H.check_model(cuda, 1e-3, 2e-2, truth="model_96x320_f64", loss_tol=1e-3)
+        # (decode: which of the nearly-equal scores of a random net make the top 50 moves with the 1e-5 of the split products AND
+        # with the atomics of the edge-fusion scatter from run to run: 39-45 of 50 rows seen; the decode itself is pinned exactly
+        # on fixed maps by check_post_processor)
+        H.check_model(cuda, 1e-3, 2e-2, truth="model_96x320_f64", loss_tol=1e-3, decode_min_match=0.7)
     finally:
         _ext.set_precision("f32")
 
@@ -512,7 +526,7 @@ def test_generate_for_gmw_pass_full_size(cuda):
         feats = model.backbone(images)
         preds = model.heads.predictor(feats, targets)
         for i in range(images.shape[0]):
-            one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
+            one = _one_image(preds, i)
             r_b, _, _ = model.heads.post_processor(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
             r_1, _, _ = model(images[i:i + 1], targets[i:i + 1])
             assert r_b.shape == r_1.shape
@@ -544,15 +558,23 @@ def test_batched_post_processor_equals_the_image_by_image_decode(cuda):
         t.size = (t.size[0] - 2 * (i % 4), t.size[1] - (i % 2))
     model.eval()
     pp = model.heads.post_processor
+    assert model.heads.predictor.sparse_eval_heads                 # bench._gen_build: heads at the top-K cells only ...
     with torch.no_grad():
         feats = model.backbone(images)
+        sparse = model.heads.predictor(feats, targets)
+        assert sparse['reg'] is None and sparse['reg_pois'].shape == (16, cfg.TEST.DETECTIONS_PER_IMG, 415)
+        rows_s, _, _, image_of_s = pp.forward_batch(sparse, targets, test=model.test, features=feats)
+        model.heads.predictor.sparse_eval_heads = False            # ... against the reference's dense map: same cells, same rows
         preds = model.heads.predictor(feats, targets)
+        assert preds['reg'].shape == (16, 415, 96, 320)
         rows, _, vis, image_of = pp.forward_batch(preds, targets, test=model.test, features=feats)
+        assert torch.equal(image_of, image_of_s) and torch.equal(rows[:, 0], rows_s[:, 0]) and torch.equal(rows[:, 13], rows_s[:, 13])
+        assert (rows - rows_s).abs().max().item() <= 1e-4 * max(rows.abs().max().item(), 1.0)
         recs_b = infer_records_batch(rows, vis, image_of, images.shape[0])
         assert rows.shape == (16 * cfg.TEST.DETECTIONS_PER_IMG, 14) and bool(torch.isfinite(rows).all())
         assert image_of.tolist() == sorted(image_of.tolist())
         for i in range(images.shape[0]):
-            one = {k: (v[i:i + 1] if torch.is_tensor(v) else v) for k, v in preds.items()}
+            one = _one_image(preds, i)
             r_1, _, vis_1 = pp(one, targets[i:i + 1], test=model.test, features=feats[i:i + 1])
             r_b = rows[image_of == i]
             assert r_b.shape == r_1.shape

@@ -85,7 +85,7 @@ def check_loss_computation(device, tol, through_row_kernel=False):
     assert rel(reg.grad.abs().sum((0, 2, 3)).cpu().numpy(), g["grad_reg_abs_per_channel"]) <= tol
 
 
-def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2):
+def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2, decode_min_match=0.8):
     """Whole KeypointDetector vs a fixture of the reference's run: `truth` = "model_96x320" (the reference in fp32 on the CPU)
     or "model_96x320_f64" (the reference in float64: the exact result up to ~1e-12).  tol: activations; loss_tol: the 13
     losses (default tol); gtol: per-parameter gradient norms, relative to the norm (floored at 1e-4 of the largest)."""
@@ -158,7 +158,7 @@ def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_t
         if d[j] <= 0.5 and (np.abs(row - ref[j]) / scale).max() <= decode_tol:
             matched += 1
     # 80 %: on the GPU 44-46 of the 50 rows match depending on the run (which of the nearly-equal scores make the cut)
-    assert matched >= 0.8 * len(ref), "only %d of %d decoded rows match the reference" % (matched, len(ref))
+    assert matched >= decode_min_match * len(ref), "only %d of %d decoded rows match the reference" % (matched, len(ref))
     # TEST.GENERATE_GMW eval pass -> gen_data_infer.json records (DGDE/engine/inference.py:59-84)
     from dcd_amd.engine.gen_data import infer_records
     model.heads.post_processor.generate_data = True
@@ -175,7 +175,7 @@ def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_t
         if (d[j] <= 0.5 and np.abs(np.array(r['kpts_2d']) - k2).max() <= decode_tol * (np.abs(k2).max() + 1e-6)
                 and np.abs(np.array(r['kpts_3d']) - k3).max() <= decode_tol * (np.abs(k3).max() + 1e-6)):
             matched += 1
-    assert matched >= 0.8 * len(recs), "only %d of %d GMW inference records match the reference" % (matched, len(recs))
+    assert matched >= decode_min_match * len(recs), "only %d of %d GMW inference records match the reference" % (matched, len(recs))
 
 
 def check_post_processor(device, tol=1e-4):
