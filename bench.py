@@ -424,10 +424,10 @@ def run_gpu(args):
 
 def load_pmc(per_rank):
     """Counter evidence for the DCN kernels, from separate `rocprofv3 --pmc` passes over THIS command (tools/pmc_kernels.py ->
-    profiles/dcn_pmc_r03.json, falling back to round 2's file): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
+    profiles/dcn_pmc_r04.json, falling back to the earlier rounds' files): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes) and the time-weighted matrix-pipe busy fraction, plus the commit the passes were made from.
     (None, None, "absent", None) when the passes have not been made for this batch."""
-    for name in ("dcn_pmc_r03.json", "dcn_pmc_r02.json"):
+    for name in ("dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -475,8 +475,9 @@ def cpu_baseline_child(args):
                       "kind": "port", "host_cpus": os.cpu_count(), "batch": args.cpu_batch, "warmup_steps": 1, "timed_steps": n_timed,
                       "s_per_step": dt, "warmup_s": warm,
                       "sample": "DGDE train step (fwd+loss+bwd+AdamW) at bs=%d, 384x1280, %d objects/image, oracle DCNv2 (C, OpenMP) + "
-                                "PyTorch CPU convs: 1 warm-up step (%.1f s) + %d timed step(s) of %.1f s" % (
-                                    args.cpu_batch, args.objects, warm, n_timed, dt)}))
+                                "PyTorch CPU convs: 1 warm-up step (%.1f s) + %d timed step(s) of %.1f s.  Batch %d only: BASELINE.md "
+                                "section 3 also names bs 8 (the metric's batch), ~4x this step's time, outside the bench's budget "
+                                "for the baseline" % (args.cpu_batch, args.objects, warm, n_timed, dt, args.cpu_batch)}))
 
 
 def cpu_serial_dcn_child(args):

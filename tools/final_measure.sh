@@ -11,8 +11,9 @@ DCD_FORCE_DDP=1 python bench.py --steps 10 --warmup 4 --no-cpu-baseline > gpurun
 python bench.py --workload gmw --steps 10 --warmup 3 --no-cpu-baseline > gpurun_out/${tag}_gmw.json 2> /dev/null
 python bench.py --workload gen --batch 16 --steps 5 --warmup 2 --no-cpu-baseline > gpurun_out/${tag}_gen.json 2> /dev/null
 bash tools/prof_step.sh ${tag} > gpurun_out/${tag}_prof.log 2>&1
+bash tools/prof_step.sh ${tag}_b1 --batch 1 > gpurun_out/${tag}_prof_b1.log 2>&1
 cd $R
-PMC_STEPS=4 python3 tools/pmc_kernels.py gpurun_out/${tag}_dcn_pmc.json "dcn_|128, false>" -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-split-line > gpurun_out/${tag}_pmc.log 2>&1
+PMC_STEPS=4 python3 tools/pmc_kernels.py gpurun_out/${tag}_dcn_pmc.json "dcn_|128, false>" -- python3 bench.py --steps 2 --warmup 2 --no-cpu-baseline --no-split-line --no-op-line > gpurun_out/${tag}_pmc.log 2>&1
 for f in f32 amp bf16x3 b1 ddp_b1 ddp_b8 gmw gen; do python3 - <<P
 import json
 try:
