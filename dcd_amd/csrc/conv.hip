@@ -41,21 +41,45 @@ constexpr int WN_NT = 512;
 //   <2,16>: 8 x 32 px (the maps whose width is a multiple of 32)
 //   <3,10>: 12 x 20 px, 30 of 32 lanes live: 24x80 and 12x40 maps divide exactly (no padded columns, and 256 workgroups = one
 //           per CU for 256 -> 256 @ 24x80 x 8 images where the 8 x 32 regions give 288 = two rounds)
-// Window row stride RS: 2 RS mod 64 is the bank step between tile rows -- 32 for 16 tile columns (16 even banks each), 20 for
-// 10 (banks 0-18 / 20-38 / 40-58); the plane stride is odd so the other lane half (next channel) takes the odd banks.
+// Window reads are ds_read_b64 (bank = dword address mod 64, the two lane halves are separate groups; ds_read2_b32 banks mod 32,
+// where the tile rows of a half collide pairwise -- measured as 46 % of the LDS cycles of round 3's kernel being conflict cycles):
+// a lane's four values d[3 + 2 tcol .. 6 + 2 tcol] of a window row come from three aligned pairs starting at 2 + 2 tcol.  Window
+// row stride RS: 2 RS mod 64 is the bank step between tile rows -- 32 for 16 tile columns (32 banks each), 20 for 10 (banks
+// 2-21 / 22-41 / 42-61).  Plane and row strides are even (pairs stay aligned); with RS a multiple of 4 the staging stores are
+// ds_write_b128, otherwise two ds_write_b64.
 template <int TR, int TC, int NB>
 struct WinoGeom {
     static constexpr int KS = 32 * NB;
-    static constexpr int U = 16 * KS * WN_CH;                 // 8192 / 4096 floats: [pos][k][h][4 steps]
+    static constexpr int U = 16 * KS * WN_CH;                 // 8192 / 4096 floats: [pos][h][k][4 steps]
     static constexpr int NTILE = TR * TC;
     static constexpr int ROWS = 4 * TR + 2;                   // window rows r0-1 .. r0+4TR
     static constexpr int Q = (2 * TC + 8) / 4;                // staged dwordx4 per row: columns c0-4 .. c0+2TC+3
     static constexpr int RS = TC == 16 ? 48 : 42;
-    static constexpr int PLANE = ROWS * RS + 1;
+    static constexpr int PLANE = ROWS * RS;
     static constexpr int IN = WN_CH * PLANE;
     static constexpr int BUF = IN + U;
-    static_assert(NTILE <= 32 && 4 * Q <= RS && (ROWS * RS) % 2 == 0 && (2 * TC) % 4 == 0, "region geometry");
+    static_assert(NTILE <= 32 && 4 * Q <= RS && RS % 2 == 0 && (2 * TC) % 4 == 0, "region geometry");
 };
+
+// Four consecutive window values starting at the ODD dword e + 1 (e even): three aligned ds_read_b64.
+__device__ __forceinline__ void win_read4(const float *e, float (&q)[4])
+{
+    const f32x2 a = *reinterpret_cast<const f32x2 *>(e), b = *reinterpret_cast<const f32x2 *>(e + 2),
+                c = *reinterpret_cast<const f32x2 *>(e + 4);
+    q[0] = a.y; q[1] = b.x; q[2] = b.y; q[3] = c.x;
+}
+
+// One staged dwordx4 into a window row (16-byte aligned when the row stride is a multiple of 4, else 8).
+template <int RS>
+__device__ __forceinline__ void win_store4(float *d, const f32x4 v)
+{
+    if constexpr (RS % 4 == 0) {
+        *reinterpret_cast<f32x4 *>(d) = v;
+    } else {
+        *reinterpret_cast<f32x2 *>(d) = f32x2{v.x, v.y};
+        *reinterpret_cast<f32x2 *>(d + 2) = f32x2{v.z, v.w};
+    }
+}
 
 // Workgroups are dealt to the 8 XCDs round-robin: walk contiguous runs of regions per XCD (L2 locality of the halos).
 __device__ __forceinline__ void xcd_remap(int &bx, int &by)
@@ -70,7 +94,8 @@ __device__ __forceinline__ void xcd_remap(int &bx, int &by)
 }
 
 // U = G g G^T, G = [[1,0,0],[.5,.5,.5],[.5,-.5,.5],[0,0,1]].
-// ul[z][chunk][pos = 4 xi + nu][kk (KS)][h (2)][s (4)] for output channel z*KS+kk and contraction channel chunk*8 + 2s + h.
+// ul[z][chunk][pos = 4 xi + nu][h (2)][kk (KS)][s (4)] for output channel z*KS+kk and contraction channel chunk*8 + 2s + h
+// (a lane half's ds_read_b128 of its A operands walks 16-byte slots at stride 1: no two lanes of a 16-lane group on one bank).
 // mode 0: forward        (contraction over Cin:  g = w[k][c][a][b])
 // mode 1: backward-data  (contraction over Cout: g = w[c][k][2-a][2-b], i.e. output channel = input channel of w)
 __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz,
@@ -109,7 +134,7 @@ __global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict
             const float u[4] = {u0, u1, u2, u3};
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
-                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * WN_KS + kk) * 2 + h) * 4 + s] = u[nu];
+                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * 2 + h) * WN_KS + kk) * 4 + s] = u[nu];
         }
     }
 }
@@ -161,7 +186,7 @@ __global__ void wino_prep_weights_both(const float *__restrict__ w, PrepBoth p)
             const float u[4] = {t[xi][0], 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]), t[xi][2]};
 #pragma unroll
             for (int nu = 0; nu < 4; ++nu)
-                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * WN_KS + kk) * 2 + h) * 4 + s] = u[nu];
+                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * 2 + h) * WN_KS + kk) * 4 + s] = u[nu];
         }
     }
 }
@@ -196,7 +221,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     // B^T row pair and signs of this wave's xi:  0: d0 - d2   1: d1 + d2   2: -d1 + d2   3: d1 - d3
     const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
     const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
-    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
+    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 2 + 2 * tcol + h * WN_PLANE;      // even: the pair below the lane's first value
     const int base1 = lanebase + ra * WN_RS, base2 = lanebase + rb * WN_RS;
 
     const float *x_b = x + (size_t)b * Cc * HW;
@@ -234,10 +259,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k)
-            if (sv_[k]) {
-                float *d = buf + sl[k];                       // odd plane stride: dword stores
-                d[0] = rin[k].x; d[1] = rin[k].y; d[2] = rin[k].z; d[3] = rin[k].w;
-            }
+            if (sv_[k]) win_store4<WN_RS>(buf + sl[k], rin[k]);
 #pragma unroll
         for (int k = 0; k < KW; ++k) *reinterpret_cast<f32x4 *>(buf + WN_IN + 4 * (tid + WN_NT * k)) = rw[k];
     };
@@ -259,21 +281,21 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #ifndef WN_ABL_NOSTAGE
         if (ck + 1 < ck1) issue(ck + 1);
 #endif
-        const float *ub = buf + WN_IN + ((xi * 4 * WN_KS + p) * 2 + h) * 4;
+        const float *ub = buf + WN_IN + ((xi * 4 * 2 + h) * WN_KS + p) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
         // A operands of the chunk: 4 nu x 2 output blocks x 4 channel steps
         f32x4 a0[4], a1[4];
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
             a0[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8);
-            if (NB == 2) a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS + 32) * 8);
+            if (NB == 2) a1[nu] = *reinterpret_cast<const f32x4 *>(ub + (nu * WN_KS) * 8 + 32 * 4);
         }
         // software pipeline over the four channel steps: the eight LDS values of step s+1 are requested before the eight
         // MFMAs of step s are issued (in-order issue: otherwise their latency is exposed once the matrix pipe drains)
         float qa[4], qb[4];
 #ifndef WN_ABL_NOLDS
-#pragma unroll
-        for (int j = 0; j < 4; ++j) { qa[j] = cp1[j]; qb[j] = cp2[j]; }
+        win_read4(cp1, qa);
+        win_read4(cp2, qb);
 #endif
 #pragma unroll
         for (int s = 0; s < 4; ++s) {
@@ -285,9 +307,8 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             const float t0 = sa * qa[0] + sb * qb[0], t1 = sa * qa[1] + sb * qb[1];
             const float t2 = sa * qa[2] + sb * qb[2], t3 = sa * qa[3] + sb * qb[3];
             if (s + 1 < 4) {
-                const float *q1 = cp1 + 2 * (s + 1) * WN_PLANE, *q2 = cp2 + 2 * (s + 1) * WN_PLANE;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) { qa[j] = q1[j]; qb[j] = q2[j]; }
+                win_read4(cp1 + 2 * (s + 1) * WN_PLANE, qa);
+                win_read4(cp2 + 2 * (s + 1) * WN_PLANE, qb);
             }
 #endif
             const float v[4] = {t0 - t2, t1 + t2, t2 - t1, t1 - t3};
@@ -448,7 +469,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restr
 
     const int ra = xi == 0 ? 0 : 1, rb = xi == 3 ? 3 : 2;
     const float sa = xi == 2 ? -1.f : 1.f, sb = (xi == 0 || xi == 3) ? -1.f : 1.f;
-    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 3 + 2 * tcol + h * WN_PLANE;
+    const int lanebase = (2 * TR * tg + 2 * trow) * WN_RS + 2 + 2 * tcol + h * WN_PLANE;      // even: the pair below the lane's first value
     const int base1 = lanebase + ra * WN_RS, base2 = lanebase + rb * WN_RS;
 
     const float *x_b = x + (size_t)b * Cc * HW;
@@ -482,10 +503,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restr
     auto commit_in = [&]() {
 #pragma unroll
         for (int k = 0; k < KIN; ++k)
-            if (sl[k] >= 0) {
-                float *d = win + sl[k];                       // odd plane stride: dword stores
-                d[0] = rin[k].x; d[1] = rin[k].y; d[2] = rin[k].z; d[3] = rin[k].w;
-            }
+            if (sl[k] >= 0) win_store4<WN_RS>(win + sl[k], rin[k]);
     };
     // weight slab of chunk ck -> buffer `buf`: straight copy, 16 bytes per lane per instruction, LDS address = wave base + 16 lane
     auto issue_w = [&](int ck, int buf) {
@@ -523,7 +541,9 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restr
         float vv[4][8];
 #pragma unroll
         for (int i = 0; i < 8; ++i) {
-            const float *q1 = cp1 + 2 * i * WN_PLANE, *q2 = cp2 + 2 * i * WN_PLANE;
+            float q1[4], q2[4];
+            win_read4(cp1 + 2 * i * WN_PLANE, q1);
+            win_read4(cp2 + 2 * i * WN_PLANE, q2);
             const float t0 = sa * q1[0] + sb * q2[0], t1 = sa * q1[1] + sb * q2[1];
             const float t2 = sa * q1[2] + sb * q2[2], t3 = sa * q1[3] + sb * q2[3];
             vv[0][i] = t0 - t2; vv[1][i] = t1 + t2; vv[2][i] = t2 - t1; vv[3][i] = t1 - t3;
@@ -726,8 +746,11 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 
     // lane = (channel p, strip half h): it walks the eight consecutive tiles 8h .. 8h+7, whose 4x4 input patches overlap by
     // two columns -- the row-transformed columns u2,u3 of one tile are u0,u1 of the next, so a step reads two new columns
-    // per transform row (one ds_read2_b32 each) and the 2x2 dY tiles of its two output blocks.
-    const int lane_in = (cb * 32 + p) * WW_IPLANE + 3 + 16 * h;
+    // per transform row and the 2x2 dY tiles of its two output blocks.  The two columns start at an odd dword; they are read
+    // as the ALIGNED pair above them (ds_read_b64: banks mod 64, the plane stride 162 puts 32 lanes on 32 bank pairs), half
+    // of which is carried to the next step -- ds_read2_b32 banks mod 32, where lanes p and p + 16 collide (32 % of this
+    // kernel's LDS cycles in round 3's counters).
+    const int lane_in = (cb * 32 + p) * WW_IPLANE + 2 + 16 * h;
     const int lane_dy = p * WW_DPLANE + 16 * h;
 
     // Two LDS buffers, one barrier per strip: while strip t is multiplied out of buffer t&1, the registers holding strip
@@ -748,8 +771,12 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 #ifdef WW_ABL_NOLDS
         float u0 = sa, u1 = sb;
 #else
-        float u0 = sa * ia[0] + sb * ib[0], u1 = sa * ia[1] + sb * ib[1];
-        float qa2 = ia[2], qa3 = ia[3], qb2 = ib[2], qb3 = ib[3];
+        // window columns E[1..4] of the first tile from the pairs (E0,E1) (E2,E3) (E4,E5); (E4,E5) is carried
+        const f32x2 pa0 = *reinterpret_cast<const f32x2 *>(ia), pa1 = *reinterpret_cast<const f32x2 *>(ia + 2);
+        const f32x2 pb0 = *reinterpret_cast<const f32x2 *>(ib), pb1 = *reinterpret_cast<const f32x2 *>(ib + 2);
+        f32x2 ca = *reinterpret_cast<const f32x2 *>(ia + 4), cb2 = *reinterpret_cast<const f32x2 *>(ib + 4);
+        float u0 = sa * pa0.y + sb * pb0.y, u1 = sa * pa1.x + sb * pb1.x;
+        float qa2 = pa1.y, qa3 = ca.x, qb2 = pb1.y, qb3 = cb2.x;
         f32x2 g00 = *reinterpret_cast<const f32x2 *>(d0), g01 = *reinterpret_cast<const f32x2 *>(d0 + 32);
         f32x2 g10 = *reinterpret_cast<const f32x2 *>(d1), g11 = *reinterpret_cast<const f32x2 *>(d1 + 32);
 #endif
@@ -770,7 +797,9 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
             const float a0 = ea * g00.x + eb * g01.x, a1 = ea * g00.y + eb * g01.y;
             const float b0 = ea * g10.x + eb * g11.x, b1 = ea * g10.y + eb * g11.y;
             if (s + 1 < 8) {
-                qa2 = ia[2 * s + 4]; qa3 = ia[2 * s + 5]; qb2 = ib[2 * s + 4]; qb3 = ib[2 * s + 5];
+                qa2 = ca.y; qb2 = cb2.y;
+                ca = *reinterpret_cast<const f32x2 *>(ia + 2 * s + 6); cb2 = *reinterpret_cast<const f32x2 *>(ib + 2 * s + 6);
+                qa3 = ca.x; qb3 = cb2.x;
                 g00 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 2); g01 = *reinterpret_cast<const f32x2 *>(d0 + 2 * s + 34);
                 g10 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 2); g11 = *reinterpret_cast<const f32x2 *>(d1 + 2 * s + 34);
             }
