@@ -98,65 +98,11 @@ __device__ __forceinline__ void xcd_remap(int &bx, int &by)
 // (a lane half's ds_read_b128 of its A operands walks 16-byte slots at stride 1: no two lanes of a 16-lane group on one bank).
 // mode 0: forward        (contraction over Cin:  g = w[k][c][a][b])
 // mode 1: backward-data  (contraction over Cout: g = w[c][k][2-a][2-b], i.e. output channel = input channel of w)
-__global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz,
-                                  int WN_KS)
+__device__ __forceinline__ void wino_prep_body(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk,
+                                               int nz, int WN_KS, int first, int step)
 {
-    const int n = nz * nchunk * WN_KS * WN_CH;                    // one thread per (z, chunk, kk, h, s): writes 16 positions
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
-        int r = idx;
-        const int s = r & 3; r >>= 2;
-        const int h = r & 1; r >>= 1;
-        const int kk = r % WN_KS; r /= WN_KS;
-        const int ck = r % nchunk, z = r / nchunk;
-        const int k = z * WN_KS + kk, c = ck * WN_CH + 2 * s + h;
-        float g[3][3];
-#pragma unroll
-        for (int a = 0; a < 3; ++a)
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                float v = 0.f;
-                if (k < Kk && c < Cc)
-                    v = mode == 0 ? w[(((size_t)k * Cc + c) * 3 + a) * 3 + b] : w[(((size_t)c * Kk + k) * 3 + (2 - a)) * 3 + (2 - b)];
-                g[a][b] = v;
-            }
-        float t[4][3];                       // G g
-#pragma unroll
-        for (int b = 0; b < 3; ++b) {
-            t[0][b] = g[0][b];
-            t[1][b] = 0.5f * (g[0][b] + g[1][b] + g[2][b]);
-            t[2][b] = 0.5f * (g[0][b] - g[1][b] + g[2][b]);
-            t[3][b] = g[2][b];
-        }
-#pragma unroll
-        for (int xi = 0; xi < 4; ++xi) {
-            const float u0 = t[xi][0], u1 = 0.5f * (t[xi][0] + t[xi][1] + t[xi][2]), u2 = 0.5f * (t[xi][0] - t[xi][1] + t[xi][2]),
-                        u3 = t[xi][2];
-            const float u[4] = {u0, u1, u2, u3};
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu)
-                ul[((((size_t)(z * nchunk + ck) * 16 + xi * 4 + nu) * 2 + h) * WN_KS + kk) * 4 + s] = u[nu];
-        }
-    }
-}
-
-// grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
-// ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
-// partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
-// Both directions of one layer in one launch (blockIdx.y = mode): the forward call of a training step prepares the weights of its
-// own backward-data call as well -- they do not change in between, and a prep launch costs a dispatch however small it is.
-struct PrepBoth {
-    float *ul[2];
-    int Cc[2], Kk[2], nchunk[2], nz[2], ks[2];
-};
-
-__global__ void wino_prep_weights_both(const float *__restrict__ w, PrepBoth p)
-{
-    const int mode = blockIdx.y;
-    if (!p.ul[mode]) return;
-    const int WN_KS = p.ks[mode], nchunk = p.nchunk[mode], Cc = p.Cc[mode], Kk = p.Kk[mode];
-    float *ul = p.ul[mode];
-    const int n = p.nz[mode] * nchunk * WN_KS * WN_CH;
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    const int n = nz * nchunk * WN_KS * WN_CH;                    // one item per (z, chunk, kk, h, s): writes 16 positions
+    for (int idx = first; idx < n; idx += step) {
         int r = idx;
         const int s = r & 3; r >>= 2;
         const int h = r & 1; r >>= 1;
@@ -191,6 +137,47 @@ __global__ void wino_prep_weights_both(const float *__restrict__ w, PrepBoth p)
     }
 }
 
+__global__ void wino_prep_weights(const float *__restrict__ w, float *__restrict__ ul, int Cc, int Kk, int mode, int nchunk, int nz,
+                                  int WN_KS)
+{
+    wino_prep_body(w, ul, Cc, Kk, mode, nchunk, nz, WN_KS, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// Both directions of one layer in one launch (blockIdx.y = mode): the forward call of a training step prepares the weights of its
+// own backward-data call as well -- they do not change in between, and a prep launch costs a dispatch however small it is.
+struct PrepBoth {
+    float *ul[2];
+    int Cc[2], Kk[2], nchunk[2], nz[2], ks[2];
+};
+
+__global__ void wino_prep_weights_both(const float *__restrict__ w, PrepBoth p)
+{
+    const int mode = blockIdx.y;
+    if (!p.ul[mode]) return;
+    wino_prep_body(w, p.ul[mode], p.Cc[mode], p.Kk[mode], mode, p.nchunk[mode], p.nz[mode], p.ks[mode],
+                   blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The same transform for MANY layers in one launch (blockIdx.z = table entry, blockIdx.y = direction): a train step prepares the
+// weights of all its 3x3 convolutions right after the optimizer step that changed them -- 37 launches of a few microseconds each
+// become one.  Table entry = five 64-bit words {weight, forward_out, backward_out, Cin, Cout} (include/dcd_hip.h).
+__global__ void wino_prep_weights_table(const long long *__restrict__ table)
+{
+    const long long *e = table + 5 * (size_t)blockIdx.z;
+    const float *w = reinterpret_cast<const float *>(e[0]);
+    const int mode = blockIdx.y;
+    float *ul = reinterpret_cast<float *>(e[1 + mode]);
+    if (!w || !ul) return;
+    const int Cin = (int)e[3], Cout = (int)e[4];
+    const int Cc = mode ? Cout : Cin, Kk = mode ? Cin : Cout;
+    const int WN_KS = Kk <= 32 ? 32 : 64;
+    wino_prep_body(w, ul, Cc, Kk, mode, (Cc + WN_CH - 1) / WN_CH, (Kk + WN_KS - 1) / WN_KS, WN_KS,
+                   blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// grid = (regions, B, K/64 * ksplit); block = 512.  x: (B, Cc, H, W) -> y: (B, Kk, H, W).
+// ksplit > 1: split ks contracts the chunks [ks nchunk / ksplit, (ks+1) nchunk / ksplit); split 0 writes y, split ks >= 1 the
+// partial image part + (ks-1) B Kk H W, wino_sum_partials adds them in a fixed order.
 // bias (may be null): added to the output channels by split 0; residual (may be null, may be y itself): a (B, Kk, H, W) image
 // added to the result by split 0 (a gradient that is already there: the caller's accumulation without a separate pass).
 template <int TR, int TC, int NB>
@@ -1076,6 +1063,15 @@ int dcd_conv3x3_transform_weights(void *stream_, const float *weight, int Cin, i
     }
     const int nb = (nmax + 255) / 256 < 4096 ? (nmax + 255) / 256 : 4096;
     hipLaunchKernelGGL(wino_prep_weights_both, dim3(nb, 2), dim3(256), 0, (hipStream_t)stream_, weight, p);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3_transform_weights_table(void *stream_, const long long *table, int entries)
+{
+    (void)hipGetLastError();
+    if (!table || entries <= 0 || entries > 65535) return DCD_ERR_BAD_ARG;
+    // 64 blocks x 256 threads per (layer, direction): the largest DGDE layer (512 -> 512) has 262 144 items = 16 per thread
+    hipLaunchKernelGGL(wino_prep_weights_table, dim3(64, 2, entries), dim3(256), 0, (hipStream_t)stream_, table);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -2558,6 +2558,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                 ga.strideA = (long long)Cout * g.HoWo; ga.strideB = (long long)K9 * g.HoWo;
                 ga.strideC = (long long)sp.dw_split * n; ga.strideCs = n;
                 ga.nsplit = sp.dw_split; ga.kchunk = sp.dw_kchunk; ga.ct = 0; ga.b_off = nullptr;
+                // far samples dominate (far_dominated, count form): the sweep wrote no columns, the generic kernels produce grad_weight
+                ga.skip_count = fs + 3; ga.skip_above = (unsigned)(((int64_t)B * ((g.HoWo + 31) / 32) * 32 * 18) / 64);
                 if (split) sgemm_bf16x3(stream, true, true, ga, B);
                 else sgemm_f32(stream, true, true, ga, B);
                 e.nvp = 0; e.dw_bx = 0; e.dw_by = 0;

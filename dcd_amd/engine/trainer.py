@@ -12,6 +12,7 @@ import weakref
 import torch
 from torch import nn
 
+from dcd_amd import ops
 from dcd_amd.utils import comm
 
 
@@ -323,6 +324,7 @@ def guard_nonfinite_step(optimizer, total_norm):
 def train_step(model, optimizer, images, targets, grad_norm_clip=15.0, scheduler=None, iteration=None):
     """One optimisation step; returns (loss_dict, log_loss_dict)."""
     optimizer.zero_grad(set_to_none=True)        # before the forward: nothing on the host between the loss and its backward
+    ops.refresh_conv_weights()                   # Winograd-domain weights of all 3x3 convolutions: one launch per step
     loss_dict, log_loss_dict = model(images, targets)
     losses = getattr(loss_dict, "total", None)
     if losses is None:
@@ -365,6 +367,7 @@ class GraphedTrainStep:
         self.distributed, self.group = distributed, group
         self._graphs = {}
         self._flat = None
+        self._side = None
         self.capture_error = None
         self._fail_capture = False
         if distributed:
@@ -447,6 +450,7 @@ class GraphedTrainStep:
 
     def _eager(self, images, targets):
         self.optimizer.zero_grad(set_to_none=True)
+        ops.refresh_conv_weights()
         loss_dict, log = self.model(images, targets)
         total = getattr(loss_dict, "total", None)
         if total is None:
@@ -474,7 +478,9 @@ class GraphedTrainStep:
             # warm-up: every rank runs the same eager steps (same collectives, in the same order) whatever happens later
             n_warm = max(self.warmup, 3 if self.distributed else 1)   # >= 1: the optimizer's state tensors must exist before the
             if on_gpu:                                                # capture; collectives: communicators set up eagerly first
-                side = torch.cuda.Stream()
+                # ONE side stream for the warm-up and the capture: per-stream scratch our ops keep (zeroed arrival counters)
+                # is then created by the warm-up, not inside the graph
+                side = self._side = self._side or torch.cuda.Stream()
                 side.wait_stream(torch.cuda.current_stream())
                 with torch.cuda.stream(side):
                     for _ in range(n_warm):
@@ -509,9 +515,9 @@ class GraphedTrainStep:
             import time
             torch.cuda.synchronize()
             time.sleep(0.2)
-            ctx = torch.cuda.graph(graph, capture_error_mode="thread_local")
+            ctx = torch.cuda.graph(graph, stream=self._side, capture_error_mode="thread_local")
         else:
-            ctx = torch.cuda.graph(graph)
+            ctx = torch.cuda.graph(graph, stream=self._side)
         with ctx:
             loss_dict, log = self._eager(st_images, st_targets)
         return graph, (loss_dict, log)

@@ -95,7 +95,7 @@ class _DCNWithOffsets(Function):
     def forward(ctx, input, w_off, b_off, weight, bias, geometry):
         from dcd_amd import ops
         input, w_off, weight = input.contiguous(), w_off.contiguous(), weight.contiguous()
-        tw, ctx.tw_back = (ops.conv3x3_transform_weights(w_off, like=input) if ops._PREP_BOTH and ctx.needs_input_grad[0] else (None, None))
+        tw, ctx.tw_back = (ops.conv3x3_step_weights(w_off, input) if ops._PREP_BOTH and ctx.needs_input_grad[0] else (None, None))
         out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous(), transformed=tw)
         offset, mask = _offset_mask_split(out)
         ctx.geometry = geometry

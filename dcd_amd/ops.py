@@ -816,6 +816,95 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
 
 
 _PREP_BOTH = os.environ.get("DCD_CONV_PREP_BOTH", "1") != "0"      # 0: every call transforms its own weights (A/B timing)
+_PREP_TABLE = os.environ.get("DCD_CONV_PREP_TABLE", "1") != "0"    # 0: one transform launch per layer and step (A/B timing)
+
+
+class _PreparedWeights:
+    """Winograd-domain weights of every 3x3 convolution a train step has run, transformed by ONE launch per step
+    (`refresh_conv_weights`, called by the trainer right before the forward) instead of one launch per layer: 37 launches
+    of ~5 us at DGDE's size, which is 0.2 ms of a 14 ms one-image step.
+
+    A layer enters the table the first time `_Conv3x3.forward` sees its weight (that call still transforms its own copy).
+    An entry is only used while it is provably current: same storage, and `weight._version` equal to the version the last
+    refresh transformed -- an optimizer step, a `load_state_dict` or any other in-place write in between sends the call back
+    to its own transform.  Entries hold weak references; a dead weight drops out at the next refresh."""
+
+    def __init__(self):
+        self.entries = {}          # id(weight) -> [weakref, data_ptr, forward buffer, backward buffer, version at refresh]
+        self.table = None          # device int64 (n, 5) the kernel reads
+        self.order = []
+        self.dirty = False
+
+    def lookup(self, weight):
+        e = self.entries.get(id(weight))
+        if e is None or e[0]() is not weight or e[1] != weight.data_ptr() or e[4] != weight._version:
+            return None
+        return e
+
+    def register(self, weight):
+        import weakref
+        if not _PREP_TABLE or torch.cuda.is_current_stream_capturing() or not isinstance(weight, torch.nn.Parameter):
+            return                                     # parameters only: a cast / reshaped copy is a new object every step
+        e = self.entries.get(id(weight))
+        if e is not None and e[0]() is weight and e[1] == weight.data_ptr():
+            return
+        L = _lib.lib()
+        Co, Ci = weight.shape[0], weight.shape[1]
+        tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device)
+        tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device)
+        self.entries[id(weight)] = [weakref.ref(weight), weight.data_ptr(), tf, tb, -1]
+        self.dirty = True
+
+    def refresh(self):
+        if not self.entries or not _PREP_TABLE:
+            return
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[1]]
+        if (dead or self.dirty) and torch.cuda.is_current_stream_capturing():
+            return                                     # no table upload inside a capture: the calls transform their own weights
+        for k in dead:
+            del self.entries[k]
+            self.dirty = True
+        if not self.entries:
+            self.table = None
+            return
+        if self.dirty or self.table is None:
+            self.order = list(self.entries.values())
+            dev = self.order[0][2].device
+            rows = [[e[1], e[2].data_ptr(), e[3].data_ptr(), e[0]().shape[1], e[0]().shape[0]] for e in self.order]
+            self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
+            self.dirty = False
+        st = _lib.lib().dcd_conv3x3_transform_weights_table(_lib.stream_of(self.table), self.table.data_ptr(), len(self.order))
+        _lib.check(st, "dcd_conv3x3_transform_weights_table")
+        for e in self.order:
+            e[4] = e[0]()._version
+
+
+_PREPARED = {}                     # device index -> _PreparedWeights
+
+
+def conv3x3_step_weights(weight, like):
+    """(forward, backward-data) Winograd-domain weights for a call inside a train step: the step's table entry when it is
+    current (no launch), else transformed now -- both directions, one launch -- and the layer is registered for the next
+    `refresh_conv_weights`."""
+    if not _conv_split(like):
+        prepared = _PREPARED.setdefault(like.device.index, _PreparedWeights())
+        e = prepared.lookup(weight)
+        if e is not None:
+            return e[2], e[3]
+        prepared.register(weight)
+    return conv3x3_transform_weights(weight, like=like)
+
+
+def refresh_conv_weights(device=None):
+    """Transform the weights of every registered 3x3 convolution on `device` (default: the current one) in one launch, on the
+    current stream.  Call it after the optimizer step / before the forward of a train step; calling it never is allowed (every
+    convolution then transforms its own weights, as before)."""
+    if not torch.cuda.is_available():
+        return
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    p = _PREPARED.get(idx)
+    if p is not None:
+        p.refresh()
 _WRW_ENABLED = os.environ.get("DCD_CONV_WRW", "1") != "0"        # 0: weight gradient on the stock op (A/B timing)
 
 
@@ -843,8 +932,8 @@ class _Conv3x3(torch.autograd.Function):
         ctx.save_for_backward(x, weight)
         ctx.tw_back = None
         if _PREP_BOTH and ctx.needs_input_grad[0]:
-            # the weights of this call and of its backward-data call in one launch (they do not change in between)
-            tw, ctx.tw_back = conv3x3_transform_weights(weight, like=x)
+            # the weights of this call and of its backward-data call (they do not change in between)
+            tw, ctx.tw_back = conv3x3_step_weights(weight, x)
             return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw)
         return _conv3x3_call(x, weight, weight.shape[0], False)
 

@@ -404,6 +404,11 @@ int dcd_conv3x3(void *stream, const float *input, const float *weight, const flo
  * partial images of a split contraction. */
 size_t dcd_conv3x3_weights_bytes(int Cin, int Cout, int backward_data);
 int dcd_conv3x3_transform_weights(void *stream, const float *weight, int Cin, int Cout, float *forward_out, float *backward_out);
+/* transform_weights for MANY layers in one launch (a train step: once, right after the optimizer step, instead of one launch
+ * per layer).  table: DEVICE array of `entries` records of five 64-bit words {weight pointer, forward_out pointer,
+ * backward_out pointer, Cin, Cout}; either output pointer may be 0.  The table is read by the kernel: keep it alive and
+ * unchanged until the launch has run. */
+int dcd_conv3x3_transform_weights_table(void *stream, const long long *table, int entries);
 int dcd_conv3x3_prepared(void *stream, const float *input, const float *transformed, const float *bias, const float *residual,
                          float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
                          size_t workspace_bytes);

@@ -77,6 +77,38 @@ def test_conv3x3_prepared_weights_equal_per_call_transform(cuda):
         assert torch.equal(only_b, tb)
 
 
+def test_prepared_weight_table_one_launch_for_all_layers(cuda):
+    """refresh_conv_weights: every registered layer's Winograd-domain weights from ONE launch, bitwise equal to the per-layer
+    transform; an entry is used only while the weight is untouched since the refresh."""
+    from dcd_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(3)
+    shapes = [(64, 64), (128, 64), (72, 80), (256, 512), (64, 27)]
+    ws = [torch.nn.Parameter(torch.randn(k, c, 3, 3, device=cuda, generator=g) / (c * 9) ** 0.5) for c, k in shapes]
+    x = [torch.randn(1, c, 24, 80, device=cuda, generator=g, requires_grad=True) for c, _ in shapes]
+    prepared = ops._PREPARED.setdefault(cuda.index if cuda.index is not None else torch.cuda.current_device(), ops._PreparedWeights())
+    first = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # registers the five layers (each transforms its own copy)
+    assert all(prepared.lookup(wi) is None for wi in ws)
+    ops.refresh_conv_weights()
+    for (c, k), wi in zip(shapes, ws):
+        e = prepared.lookup(wi)
+        assert e is not None
+        tf, tb = ops.conv3x3_transform_weights(wi)
+        assert torch.equal(e[2], tf) and torch.equal(e[3], tb)
+    second = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]             # served from the table
+    for a, b in zip(first, second):
+        assert torch.equal(a, b)
+    (second[0].sum() + second[3].sum()).backward()                      # backward-data from the table's other half
+    assert torch.isfinite(x[0].grad).all() and torch.isfinite(x[3].grad).all()
+    with torch.no_grad():
+        ws[1].mul_(2.0)                                                 # an in-place write: the entry is stale until the next refresh
+    assert prepared.lookup(ws[1]) is None and prepared.lookup(ws[0]) is not None
+    y = ops.conv3x3(x[1], ws[1])
+    assert torch.allclose(y, 2.0 * first[1], rtol=1e-5, atol=1e-6)
+    ops.refresh_conv_weights()
+    assert prepared.lookup(ws[1]) is not None
+    assert torch.equal(ops.conv3x3(x[1], ws[1]), y)
+
+
 def test_conv_module_dispatch(cuda):
     from dcd_amd.model.layers.conv import Conv2d
     conv = Conv2d(64, 64, 3, padding=1, bias=False).to(cuda)
