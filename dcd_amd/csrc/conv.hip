@@ -229,7 +229,16 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
         sg[k] = (sv_[k] && yy >= 0 && yy < H && xx >= 0 && xx < W) ? ch * HW + yy * W + xx : -1;
         sl[k] = ch * WN_PLANE + row * WN_RS + 4 * q;
     }
-    f32x4 rin[KIN], rw[KW];
+    f32x4 rin[KIN];
+    // weight slab of chunk ck -> buffer `buf`: a straight copy, so it goes global -> LDS directly (16 bytes per lane, LDS address =
+    // wave base + 16 lane; no staging registers, no ds_write); the caller waits for vmcnt(0) before the barrier that publishes it
+    auto issue_w = [&](int ck, float *buf) {
+        const float *src = ul_z + (size_t)ck * WN_U + 4 * tid;
+        float *dst = buf + WN_IN + 4 * 64 * __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            __builtin_amdgcn_global_load_lds(src + 4 * WN_NT * k, (__attribute__((address_space(3))) void *)(dst + 4 * WN_NT * k), 16, 0, 0);
+    };
     auto issue = [&](int ck) {
         const float *src = x_b + (size_t)ck * WN_CH * HW;
         const int cleft = Cc - ck * WN_CH;
@@ -239,16 +248,11 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
             rin[k] = zero4;
             if (sv_[k] && sg[k] >= 0 && (tid + WN_NT * k) / (WN_ROWS * WN_Q) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
         }
-        const float *wsrc = ul_z + (size_t)ck * WN_U;
-#pragma unroll
-        for (int k = 0; k < KW; ++k) rw[k] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * (tid + WN_NT * k));
     };
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k)
             if (sv_[k]) win_store4<WN_RS>(buf + sl[k], rin[k]);
-#pragma unroll
-        for (int k = 0; k < KW; ++k) *reinterpret_cast<f32x4 *>(buf + WN_IN + 4 * (tid + WN_NT * k)) = rw[k];
     };
 
     f32x16 acc[4][NB];
@@ -259,14 +263,19 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #pragma unroll
             for (int r = 0; r < 16; ++r) acc[nu][mb][r] = 0.f;
 
+    issue_w(ck0, lds);
     issue(ck0);
     commit(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int ck = ck0; ck < ck1; ++ck) {
         const float *buf = lds + ((ck - ck0) & 1) * WN_BUF;
 #ifndef WN_ABL_NOSTAGE
-        if (ck + 1 < ck1) issue(ck + 1);
+        if (ck + 1 < ck1) {
+            issue_w(ck + 1, lds + ((ck + 1 - ck0) & 1) * WN_BUF);      // that buffer was released by the barrier that ended chunk ck - 1
+            issue(ck + 1);
+        }
 #endif
         const float *ub = buf + WN_IN + ((xi * 4 * 2 + h) * WN_KS + p) * 4;
         const float *cp1 = buf + base1, *cp2 = buf + base2;
@@ -309,6 +318,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 #ifndef WN_ABL_NOSTAGE
         if (ck + 1 < ck1) commit(lds + ((ck + 1 - ck0) & 1) * WN_BUF);
 #endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next chunk's weights have landed in LDS
         __syncthreads();
     }
 #ifdef WN_ABL_NOEPI

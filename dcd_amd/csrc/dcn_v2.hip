@@ -590,7 +590,17 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
         sg[k] = (sv_[k] && y >= 0 && y < g.H && x >= 0 && x < g.W) ? ch * HW + y * g.W + x : -1;
         sl[k] = ch * TL_PLANE + row * TL_WW + 4 * q;
     }
-    f32x4 rin[KIN], rw[KW];
+    f32x4 rin[KIN];
+    // weight slab of chunk ck -> buffer `buf`: a straight copy, global -> LDS directly (16 bytes per lane, LDS address = wave base
+    // + 16 lane: no staging registers, no ds_write); vmcnt(0) before the barrier that publishes the buffer
+    auto issue_w = [&](int ck, float *buf) {
+        const float *src = wl_z + (size_t)ck * TL_W_FLOATS + 4 * tid;
+        float *dst = buf + TL_IN_FLOATS + 4 * 64 * __builtin_amdgcn_readfirstlane(wave);
+#pragma unroll
+        for (int k = 0; k < KW; ++k)
+            if (64 * __builtin_amdgcn_readfirstlane(wave) + NT * k < TL_NW)
+                __builtin_amdgcn_global_load_lds(src + 4 * NT * k, (__attribute__((address_space(3))) void *)(dst + 4 * NT * k), 16, 0, 0);
+    };
     auto issue = [&](int ck) {
         const float *src = in_b + (size_t)ck * TL_CH * HW;
         const int cleft = g.C - ck * TL_CH;                      // channels left (may be < 8 in the last chunk)
@@ -600,18 +610,11 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
             rin[k] = zero4;
             if (sv_[k] && sg[k] >= 0 && (tid + NT * k) / (TL_WH * 10) < cleft) rin[k] = *reinterpret_cast<const f32x4 *>(src + sg[k]);
         }
-        const float *wsrc = wl_z + (size_t)ck * TL_W_FLOATS;
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (tid + NT * k < TL_NW) rw[k] = *reinterpret_cast<const f32x4 *>(wsrc + 4 * (tid + NT * k));
     };
     auto commit = [&](float *buf) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k)
             if (sv_[k]) *reinterpret_cast<f32x4 *>(buf + sl[k]) = rin[k];
-#pragma unroll
-        for (int k = 0; k < KW; ++k)
-            if (tid + NT * k < TL_NW) *reinterpret_cast<f32x4 *>(buf + TL_IN_FLOATS + 4 * (tid + NT * k)) = rw[k];
     };
 
     issue(0);
@@ -660,13 +663,18 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
         return;
     }
 
+    issue_w(0, lds);                       // after the early returns above: a workgroup must not end with LDS writes in flight
     commit(lds);
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
     __syncthreads();
 
     for (int ck = 0; ck < nchunk; ++ck) {
         const float *buf = lds + (ck & 1) * TL_BUF;
 #ifndef TL_ABL_NOSTAGE
-        if (ck + 1 < nchunk) issue(ck + 1);
+        if (ck + 1 < nchunk) {
+            issue_w(ck + 1, lds + ((ck + 1) & 1) * TL_BUF);      // released by the barrier that ended chunk ck - 1
+            issue(ck + 1);
+        }
 #endif
         const float *wb_ = buf + TL_IN_FLOATS + (p * 2 + h) * 4;
 #pragma unroll
@@ -696,6 +704,7 @@ __global__ __launch_bounds__(TR * 64) void dcn_fwd_tile_f32(const float *__restr
 #ifndef TL_ABL_NOSTAGE
         if (ck + 1 < nchunk) commit(lds + ((ck + 1) & 1) * TL_BUF);
 #endif
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");                 // the next chunk's weights have landed in LDS
 #ifndef TL_ABL_NOBAR
         __syncthreads();
 #endif
