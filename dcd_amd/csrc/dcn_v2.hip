@@ -781,15 +781,36 @@ constexpr float TL_NEAR = 3.f;   // tiled kernels: |offset| below this stays ins
 // One-pass backward (round 4): its kernel takes the far samples itself, one by one (dcn_bwd_sweep.inc: global loads and atomics
 // instead of the LDS window), so what decides is the NUMBER of far samples, not the tiles they sit in: the call's zero-fill
 // kernel marks far_scal[3] with FAR_BY_COUNT, the offset scan adds the far coordinates to it, and the generic kernels take over
-// when more than 1 in 64 coordinates is far (~3 % of the samples; a far sample costs the one-pass kernel ~8 near ones and four
-// global atomics per channel).
+// when more coordinates are far than far_count_limit() allows (1 in 24 ... 1 in 8 by layer width and batch; a far sample costs
+// the one-pass kernel ~8 near ones and four global atomics per channel).
+// The limit is the HOST's choice per call (far_count_limit below): the marker is written as FAR_BY_COUNT | (FAR_COUNT_PIVOT - limit)
+// and the scan adds to it, so "more far coordinates than the limit" reads "count field above the pivot" in every kernel.
 constexpr unsigned FAR_BY_COUNT = 0x80000000u;
+constexpr unsigned FAR_COUNT_PIVOT = 0x40000000u;
 __device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int total_tiles)
 {
     if (!far_scal) return false;
     const unsigned c = far_scal[3];
-    if (c & FAR_BY_COUNT) return (int64_t)(c & ~FAR_BY_COUNT) * 64 > (int64_t)total_tiles * 32 * 18;
+    if (c & FAR_BY_COUNT) return (c & ~FAR_BY_COUNT) > FAR_COUNT_PIVOT;
     return (int64_t)far_scal[1] * 2 > (int64_t)total_tiles;
+}
+
+// Far coordinates (of B * 18 * HoWo) up to which the one-pass backward keeps the call.  Measured (tools/scratch/far_div_sweep.py,
+// profiles/r04_far_div_b8.txt / _b1.txt): the one-pass kernel's time grows linearly with the far samples (64 -> 64 @ 96x320 x 8:
+// 0.91 ms + 41 ms per unit of far fraction), the generic kernels cost 2.6 - 3.4 ms whatever the fraction, so they take over
+// above ~1 in 24 coordinates; the wide-output layers' generic path is relatively dearer (1 in 16), and with few images the
+// generic kernels under-fill the chip (0.65 ms against 0.18 at one image: 1 in 12 / 1 in 8).  Round 4 started with 1 in 64,
+// which handed calls over at a third of the break-even density.  DCD_FAR_DIV / DCD_FAR_DIV_WIDE override (A/B timing).
+inline unsigned far_count_limit(const Geom &g, bool wide)
+{
+    static const int div = getenv("DCD_FAR_DIV") ? atoi(getenv("DCD_FAR_DIV")) : 0;
+    static const int div_wide = getenv("DCD_FAR_DIV_WIDE") ? atoi(getenv("DCD_FAR_DIV_WIDE")) : 0;
+    int d = wide ? div_wide : div;
+    if (d <= 0) d = wide ? (g.B >= 4 ? 16 : 8) : (g.B >= 4 ? 24 : 12);
+    const int64_t total = (int64_t)g.B * 18 * g.HoWo;
+    int64_t lim = total / d;
+    if (lim > (int64_t)FAR_COUNT_PIVOT - 1) lim = FAR_COUNT_PIVOT - 1;
+    return (unsigned)lim;
 }
 
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
@@ -2493,7 +2514,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             const int nb_gen = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
             const int nb_sw = (int)((sp.wp_floats + 255) / 256 < 2048 ? (sp.wp_floats + 255) / 256 : 2048);
             hipLaunchKernelGGL(dcn_sweep_prologue_a, dim3(nb_gen + nb_sw), dim3(256), 0, stream, weight, wf, wb, swp, absmax, g, sp.nck, sp.nob,
-                               split ? 1 : 0, nb_gen);
+                               split ? 1 : 0, nb_gen, far_count_limit(g, sp.nob > 1));
         }
         {
             ZeroRanges z;
@@ -2568,7 +2589,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                 ga.strideC = (long long)sp.dw_split * n; ga.strideCs = n;
                 ga.nsplit = sp.dw_split; ga.kchunk = sp.dw_kchunk; ga.ct = 0; ga.b_off = nullptr;
                 // far samples dominate (far_dominated, count form): the sweep wrote no columns, the generic kernels produce grad_weight
-                ga.skip_count = fs + 3; ga.skip_above = (unsigned)(((int64_t)B * ((g.HoWo + 31) / 32) * 32 * 18) / 64);
+                ga.skip_count = fs + 3; ga.skip_above = FAR_COUNT_PIVOT;
                 if (split) sgemm_bf16x3(stream, true, true, ga, B);
                 else sgemm_f32(stream, true, true, ga, B);
                 e.nvp = 0; e.dw_bx = 0; e.dw_by = 0;
