@@ -30,6 +30,10 @@
 #include <hip/hip_runtime.h>
 #include <stdint.h>
 #include <stdlib.h>
+#include <string.h>
+#include <map>
+#include <mutex>
+#include <utility>
 
 #include "../../include/dcd_hip.h"
 #include "lds_limit.h"
@@ -811,6 +815,78 @@ inline unsigned far_count_limit(const Geom &g, bool wide)
     int64_t lim = total / d;
     if (lim > (int64_t)FAR_COUNT_PIVOT - 1) lim = FAR_COUNT_PIVOT - 1;
     return (unsigned)lim;
+}
+
+// ---- Who takes the far samples of a one-pass backward call: decided per LAYER on the host, from the far count of earlier calls.
+// The device-side hand-over above needs the generic kernels behind every call -- five launches that return at once in the
+// common case (70 launches and 0.34 ms per train step, a quarter of a millisecond of the 13.7 ms one-image step).  The one-pass
+// kernel is correct for ANY share of far samples (only slower than the generic kernels beyond the limit), so a layer whose last
+// sampled call stayed below half its limit runs without hand-over: limit "never", no generic launches, no generic weight layouts.
+// Every 16th call of a layer copies its far count to pinned host memory (4 bytes, asynchronously); the next call that finds the
+// copy finished re-decides.  Until the first sample, and inside a stream capture while one is pending, the hand-over stays on.
+// DCD_DCN_HANDOVER = always | never | auto (default).  State is keyed by (device, weight pointer).
+struct HandoverState {
+    int handover = 1;
+    int calls = 0;
+    bool pending = false;
+    unsigned limit_used = 0;
+    hipEvent_t ev = nullptr;
+    unsigned *host = nullptr;
+};
+static std::mutex g_handover_mu;
+static std::map<std::pair<int, const void *>, HandoverState> g_handover;
+
+static int handover_mode()
+{
+    static const int m = [] {
+        const char *e = getenv("DCD_DCN_HANDOVER");
+        if (e && !strcmp(e, "always")) return 1;
+        if (e && !strcmp(e, "never")) return 0;
+        return 2;
+    }();
+    return m;
+}
+
+static bool stream_is_capturing(hipStream_t stream)
+{
+    hipStreamCaptureStatus st = hipStreamCaptureStatusNone;
+    return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
+}
+
+// -> 1: device-side hand-over armed (generic launches follow the sweep), 0: the sweep keeps the call whatever the offsets are
+static int handover_decide(hipStream_t stream, const void *weight, unsigned real_limit, HandoverState **out)
+{
+    *out = nullptr;
+    const int mode = handover_mode();
+    if (mode != 2) return mode;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    HandoverState &h = g_handover[std::make_pair(dev, weight)];
+    *out = &h;
+    if (h.pending && !stream_is_capturing(stream) && hipEventQuery(h.ev) == hipSuccess) {
+        h.pending = false;
+        const unsigned v = *h.host & ~FAR_BY_COUNT;                      // = (pivot - limit_used) + far coordinates
+        const unsigned base = FAR_COUNT_PIVOT - h.limit_used;
+        const unsigned far = v >= base ? v - base : 0u;
+        h.handover = (uint64_t)far * 2 > real_limit ? 1 : 0;
+    }
+    (void)hipGetLastError();                                             // hipEventQuery's hipErrorNotReady is not an error of the call
+    return h.handover;
+}
+
+// after the call's last kernel that touches the count: sample it now and then (never inside a capture)
+static void handover_sample(hipStream_t stream, HandoverState *h, const unsigned *count_dev, unsigned limit_used)
+{
+    if (!h) return;
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    if (h->pending || (h->calls++ & 15) != 0 || stream_is_capturing(stream)) return;
+    if (!h->host && hipHostMalloc((void **)&h->host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { h->host = nullptr; return; }
+    if (!h->ev && hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) { h->ev = nullptr; return; }
+    if (hipMemcpyAsync(h->host, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess) return;
+    if (hipEventRecord(h->ev, stream) != hipSuccess) return;
+    h->limit_used = limit_used;
+    h->pending = true;
 }
 
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
@@ -2510,11 +2586,16 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         // one block it accumulates grad_offset / grad_mask with atomics onto what the epilogue wrote (zeros then)
         int nsplit = 1;
         while (nsplit * 2 <= nblk) nsplit *= 2;
+        HandoverState *hstate = nullptr;
+        const unsigned real_limit = far_count_limit(g, sp.nob > 1);
+        const int handover = handover_decide(stream, weight, real_limit, &hstate);
+        const unsigned far_limit = handover ? real_limit : FAR_COUNT_PIVOT - 1;      // "never": no kernel sees the call as far-dominated
         {
-            const int nb_gen = (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024);
+            // the generic kernels' weight layouts are only read after a hand-over
+            const int nb_gen = handover ? (int)((nw + 255) / 256 < 1024 ? (nw + 255) / 256 : 1024) : 0;
             const int nb_sw = (int)((sp.wp_floats + 255) / 256 < 2048 ? (sp.wp_floats + 255) / 256 : 2048);
             hipLaunchKernelGGL(dcn_sweep_prologue_a, dim3(nb_gen + nb_sw), dim3(256), 0, stream, weight, wf, wb, swp, absmax, g, sp.nck, sp.nob,
-                               split ? 1 : 0, nb_gen, far_count_limit(g, sp.nob > 1));
+                               split ? 1 : 0, nb_gen, far_limit);
         }
         {
             ZeroRanges z;
@@ -2598,6 +2679,8 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             }
             hipLaunchKernelGGL(dcn_sweep_epilogue, dim3(e.nb_coord + Cout * splits + nb_dw), dim3(256), 0, stream, e);
         }
+        handover_sample(stream, hstate, fs + 3, far_limit);
+        if (!handover) return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
         // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
         inv.packed = 0;
         inv.tileflag = nullptr;

@@ -540,7 +540,8 @@ class _Conv1x1OfCat(torch.autograd.Function):
                 gxs.append(torch.bmm(w2[:, c0:c0 + Ci].t().unsqueeze(0).expand(B, Ci, O), g3).view(B, Ci, H, W))
             else:
                 gxs.append(None)
-            gw[:, c0:c0 + Ci] = torch.bmm(g3, x3.transpose(1, 2)).sum(0)       # transposed VIEW of x: no copy
+            # transposed VIEW of x: no copy; the batch sum lands in the weight gradient's column slice directly
+            torch.sum(torch.bmm(g3, x3.transpose(1, 2)), 0, out=gw[:, c0:c0 + Ci])
             c0 += Ci
         return (gw.reshape(ctx.wshape),) + tuple(gxs)
 

@@ -286,6 +286,29 @@ def test_one_pass_backward_equals_three_pass(cuda, monkeypatch):
             close(g_, r_, 2e-5, "one-pass vs three-pass %s %s" % (name, (B, C, Co, H, W)))
 
 
+def test_one_pass_backward_keeps_far_heavy_calls_once_the_layer_is_known_as_near(cuda, oracle_dcn):
+    """Host-side hand-over policy (dcn_v2.hip, `handover_decide`): after a layer's sampled call stayed far below its limit the
+    five generic launches are dropped and the one-pass kernel takes EVERY sample of the following calls itself -- also of a call
+    whose offsets would have been handed to the generic kernels.  Same weight tensor (the policy's key): two near calls (the
+    first is sampled, the second reads the sample), then a far-heavy one against the oracle."""
+    from dcd_amd import _ext
+    for (B, C, Co, H, W, seed) in ((1, 32, 64, 16, 48, 21), (1, 32, 128, 12, 36, 22)):
+        x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=0.3, seed=seed)
+        dev = [t.to(cuda) for t in (x, w, b, off, m, gy)]
+        a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+        first = _ext.dcn_v2_backward(*dev, *a)
+        torch.cuda.synchronize()
+        again = _ext.dcn_v2_backward(*dev, *a)                       # policy: hand-over off from here on (unless the env pins it)
+        for g_, r_ in zip(first, again):
+            close(g_, r_, 2e-6, "hand-over on vs off, near offsets")
+        g = torch.Generator().manual_seed(seed + 100)
+        off_far = torch.randn(off.shape, generator=g) * 2.5            # ~23 % of the coordinates beyond 3 px
+        ref = oracle_dcn.dcn_v2_backward(x, w, b, off_far, m, gy, *a)
+        got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], off_far.to(cuda), dev[4], dev[5], *a)
+        for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+            close(g_.cpu(), r_, 5e-5, "far-heavy call on the one-pass kernel alone: %s %s" % (name, (B, C, Co, H, W)))
+
+
 WIDE_SWEEP_CASES = [
     # B, C, Co, H, W, off_scale: one-pass backward with Cout > 64 (round 4): dcol over 2 / 4 blocks of 64 outputs, the masked
     # samples through the col buffer, grad_weight as one product
