@@ -154,6 +154,9 @@ def op_level_dcn(torch, ext, batch, sigma, prec, iters=3):
         for _ in range(2):
             ext.dcn_v2_forward(x, wt, b, off, m, *a, precision=prec)
             ext.dcn_v2_backward(x, wt, b, off, m, gy, *a, precision=prec)
+            # the backward's host-side hand-over policy reads the far count its layer's PREVIOUS call reported (dcn_v2.hip): let
+            # the warm-up calls finish, as a train step's calls of one layer are a whole step apart
+            torch.cuda.synchronize()
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         e[0].record()
         for _ in range(iters):

@@ -817,24 +817,22 @@ inline unsigned far_count_limit(const Geom &g, bool wide)
     return (unsigned)lim;
 }
 
-// ---- Who takes the far samples of a one-pass backward call: decided per LAYER on the host, from the far count of earlier calls.
+// ---- Who takes the far samples of a one-pass backward call: decided per LAYER on the host, from the far count of its previous call.
 // The device-side hand-over above needs the generic kernels behind every call -- five launches that return at once in the
-// common case (70 launches and 0.34 ms per train step, a quarter of a millisecond of the 13.7 ms one-image step).  The one-pass
-// kernel is correct for ANY share of far samples (only slower than the generic kernels beyond the limit), so a layer whose last
-// sampled call stayed below half its limit runs without hand-over: limit "never", no generic launches, no generic weight layouts.
-// Every 16th call of a layer copies its far count to pinned host memory (4 bytes, asynchronously); the next call that finds the
-// copy finished re-decides.  Until the first sample, and inside a stream capture while one is pending, the hand-over stays on.
-// DCD_DCN_HANDOVER = always | never | auto (default).  State is keyed by (device, weight pointer).
+// common case (70 launches and 0.25 - 0.3 ms per train step, 2 % of the one-image step).  The one-pass kernel is correct for ANY
+// share of far samples (only slower than the generic kernels beyond the limit), so the decision may lag by a call: the call's
+// epilogue kernel stores its far count into a word of mapped pinned host memory (one plain store, no copy, no extra launch, works
+// inside a replayed graph too), and the layer's next call reads that word on the host.  Below half the limit the call runs
+// with the limit "never": no generic launches, no generic weight layouts.  Unknown (first call) or above: hand-over armed, as
+// before.  A sudden change of the offset statistics costs one slow call per layer.  State is keyed by (device, weight pointer).
+// DCD_DCN_HANDOVER = always | never | auto (default).
 struct HandoverState {
-    int handover = 1;
-    int calls = 0;
-    bool pending = false;
-    unsigned limit_used = 0;
-    hipEvent_t ev = nullptr;
-    unsigned *host = nullptr;
+    unsigned *host = nullptr;     // far coordinates of the layer's last finished call; 0xffffffff = none yet
+    unsigned *dev = nullptr;      // the same word as the device sees it
 };
 static std::mutex g_handover_mu;
 static std::map<std::pair<int, const void *>, HandoverState> g_handover;
+constexpr unsigned HANDOVER_UNKNOWN = 0xffffffffu;
 
 static int handover_mode()
 {
@@ -853,40 +851,33 @@ static bool stream_is_capturing(hipStream_t stream)
     return hipStreamIsCapturing(stream, &st) == hipSuccess && st != hipStreamCaptureStatusNone;
 }
 
-// -> 1: device-side hand-over armed (generic launches follow the sweep), 0: the sweep keeps the call whatever the offsets are
-static int handover_decide(hipStream_t stream, const void *weight, unsigned real_limit, HandoverState **out)
+// -> 1: device-side hand-over armed (generic launches follow the sweep), 0: the sweep keeps the call whatever the offsets are.
+// *report: device address the call's epilogue stores its far count to (null: no report).
+static int handover_decide(hipStream_t stream, const void *weight, unsigned real_limit, unsigned **report)
 {
-    *out = nullptr;
+    *report = nullptr;
     const int mode = handover_mode();
     if (mode != 2) return mode;
     int dev = 0;
     (void)hipGetDevice(&dev);
     std::lock_guard<std::mutex> lock(g_handover_mu);
     HandoverState &h = g_handover[std::make_pair(dev, weight)];
-    *out = &h;
-    if (h.pending && !stream_is_capturing(stream) && hipEventQuery(h.ev) == hipSuccess) {
-        h.pending = false;
-        const unsigned v = *h.host & ~FAR_BY_COUNT;                      // = (pivot - limit_used) + far coordinates
-        const unsigned base = FAR_COUNT_PIVOT - h.limit_used;
-        const unsigned far = v >= base ? v - base : 0u;
-        h.handover = (uint64_t)far * 2 > real_limit ? 1 : 0;
+    if (!h.host) {
+        if (stream_is_capturing(stream)) return 1;                        // no allocation inside a capture
+        unsigned *hp = nullptr, *dp = nullptr;
+        if (hipHostMalloc((void **)&hp, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
+            hipHostGetDevicePointer((void **)&dp, hp, 0) != hipSuccess) {
+            (void)hipGetLastError();
+            if (hp) (void)hipHostFree(hp);
+            return 1;
+        }
+        *hp = HANDOVER_UNKNOWN;
+        h.host = hp;
+        h.dev = dp;
     }
-    (void)hipGetLastError();                                             // hipEventQuery's hipErrorNotReady is not an error of the call
-    return h.handover;
-}
-
-// after the call's last kernel that touches the count: sample it now and then (never inside a capture)
-static void handover_sample(hipStream_t stream, HandoverState *h, const unsigned *count_dev, unsigned limit_used)
-{
-    if (!h) return;
-    std::lock_guard<std::mutex> lock(g_handover_mu);
-    if (h->pending || (h->calls++ & 15) != 0 || stream_is_capturing(stream)) return;
-    if (!h->host && hipHostMalloc((void **)&h->host, sizeof(unsigned), hipHostMallocDefault) != hipSuccess) { h->host = nullptr; return; }
-    if (!h->ev && hipEventCreateWithFlags(&h->ev, hipEventDisableTiming) != hipSuccess) { h->ev = nullptr; return; }
-    if (hipMemcpyAsync(h->host, count_dev, sizeof(unsigned), hipMemcpyDeviceToHost, stream) != hipSuccess) return;
-    if (hipEventRecord(h->ev, stream) != hipSuccess) return;
-    h->limit_used = limit_used;
-    h->pending = true;
+    *report = h.dev;
+    const unsigned far = *(volatile unsigned *)h.host;
+    return (far == HANDOVER_UNKNOWN || (uint64_t)far * 2 > real_limit) ? 1 : 0;
 }
 
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
@@ -2586,9 +2577,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         // one block it accumulates grad_offset / grad_mask with atomics onto what the epilogue wrote (zeros then)
         int nsplit = 1;
         while (nsplit * 2 <= nblk) nsplit *= 2;
-        HandoverState *hstate = nullptr;
+        unsigned *far_report = nullptr;
         const unsigned real_limit = far_count_limit(g, sp.nob > 1);
-        const int handover = handover_decide(stream, weight, real_limit, &hstate);
+        const int handover = handover_decide(stream, weight, real_limit, &far_report);
         const unsigned far_limit = handover ? real_limit : FAR_COUNT_PIVOT - 1;      // "never": no kernel sees the call as far-dominated
         {
             // the generic kernels' weight layouts are only read after a hand-over
@@ -2639,6 +2630,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             SweepEpilogueArgs e;
             e.cpart = cpart; e.gy = grad_output; e.dwpart = dwpart; e.goff = grad_offset; e.gmsk = grad_mask; e.gw = grad_weight;
             e.gbias = grad_bias; e.far_scal = fs; e.g = g; e.nck = sp.nck; e.total_tiles = B * tiles;
+            e.far_report = far_report; e.far_base = FAR_COUNT_PIVOT - far_limit;
             // nob == 1: the sweep's chunk-0 waves sum dY themselves (dcn_bias_grad's blocks then only act when the generic kernels
             // take the call over)
             e.bias_only_if_far = sp.nob == 1 ? fs : (const unsigned *)nullptr;
@@ -2679,7 +2671,6 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             }
             hipLaunchKernelGGL(dcn_sweep_epilogue, dim3(e.nb_coord + Cout * splits + nb_dw), dim3(256), 0, stream, e);
         }
-        handover_sample(stream, hstate, fs + 3, far_limit);
         if (!handover) return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
         // lists + gather grad_input: only when the far samples dominate (each kernel checks the same device scalar)
         inv.packed = 0;

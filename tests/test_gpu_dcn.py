@@ -290,7 +290,8 @@ def test_one_pass_backward_keeps_far_heavy_calls_once_the_layer_is_known_as_near
     """Host-side hand-over policy (dcn_v2.hip, `handover_decide`): after a layer's sampled call stayed far below its limit the
     five generic launches are dropped and the one-pass kernel takes EVERY sample of the following calls itself -- also of a call
     whose offsets would have been handed to the generic kernels.  Same weight tensor (the policy's key): two near calls (the
-    first is sampled, the second reads the sample), then a far-heavy one against the oracle."""
+    second reads the first one's reported count), a far-heavy one against the oracle (still on the one-pass kernel alone), and
+    the same again (now handed over)."""
     from dcd_amd import _ext
     for (B, C, Co, H, W, seed) in ((1, 32, 64, 16, 48, 21), (1, 32, 128, 12, 36, 22)):
         x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=0.3, seed=seed)
@@ -307,6 +308,10 @@ def test_one_pass_backward_keeps_far_heavy_calls_once_the_layer_is_known_as_near
         got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], off_far.to(cuda), dev[4], dev[5], *a)
         for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
             close(g_.cpu(), r_, 5e-5, "far-heavy call on the one-pass kernel alone: %s %s" % (name, (B, C, Co, H, W)))
+        torch.cuda.synchronize()                                       # that call reported its count: the next one is handed over
+        got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], off_far.to(cuda), dev[4], dev[5], *a)
+        for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
+            close(g_.cpu(), r_, 5e-5, "far-heavy call, hand-over armed again: %s %s" % (name, (B, C, Co, H, W)))
 
 
 WIDE_SWEEP_CASES = [

@@ -13,7 +13,8 @@ dev = torch.device('cuda:0'); B = 8
 x = torch.randn(B, C, H, W, device=dev); off = torch.randn(B, 18, H, W, device=dev) * osc
 m = torch.sigmoid(torch.randn(B, 9, H, W, device=dev)); w = torch.randn(Co, C, 3, 3, device=dev) / (C * 9) ** 0.5
 b = torch.zeros(Co, device=dev); gy = torch.randn(B, Co, H, W, device=dev); a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
-for _ in range(3): _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=prec)
+for _ in range(3):
+    _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=prec); torch.cuda.synchronize()
 e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
 torch.cuda.synchronize(); e0.record()
 for _ in range(10): _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=prec)

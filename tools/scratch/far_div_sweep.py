@@ -16,7 +16,8 @@ for C, Co, H, W in %r:
         x = torch.randn(B, C, H, W, device=dev, generator=g); off = torch.randn(B, 18, H, W, device=dev, generator=g) * osc
         m = torch.sigmoid(torch.randn(B, 9, H, W, device=dev, generator=g)); w = torch.randn(Co, C, 3, 3, device=dev, generator=g) / (C * 9) ** 0.5
         b = torch.zeros(Co, device=dev); gy = torch.randn(B, Co, H, W, device=dev, generator=g); a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
-        for _ in range(2): _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)
+        for _ in range(2):
+            _ext.dcn_v2_backward(x, w, b, off, m, gy, *a); torch.cuda.synchronize()
         e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         torch.cuda.synchronize(); e0.record()
         for _ in range(5): _ext.dcn_v2_backward(x, w, b, off, m, gy, *a)

@@ -22,6 +22,7 @@ def main(B=8, prec="f32", iters=5, off_scale=2.0):
         for _ in range(2):
             _ext.dcn_v2_forward(x, w, b, off, m, *a, precision=prec)
             _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision=prec)
+            torch.cuda.synchronize()       # the backward's hand-over policy reads what the layer's previous call reported
         e = [torch.cuda.Event(enable_timing=True) for _ in range(3)]
         torch.cuda.synchronize()
         e[0].record()
