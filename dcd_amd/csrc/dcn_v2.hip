@@ -880,6 +880,23 @@ static int handover_decide(hipStream_t stream, const void *weight, unsigned real
     return (far == HANDOVER_UNKNOWN || (uint64_t)far * 2 > real_limit) ? 1 : 0;
 }
 
+// Forward side of the same policy.  The tiled forward kernel takes far samples itself (per lane, from global memory); the call-wide
+// far count and the rescue launch behind it only pay when far samples are common.  A layer whose last BACKWARD reported fewer far
+// coordinates than 1 in 64 (half the forward's own limit) runs without both: two launches less per call.  No report yet (first
+// step, inference, the dense backward of the Cout 256 layers): as before.
+static bool forward_keeps_far_samples(const void *weight, int64_t ncoord)
+{
+    const int mode = handover_mode();
+    if (mode != 2) return mode == 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    auto it = g_handover.find(std::make_pair(dev, weight));
+    if (it == g_handover.end() || !it->second.host) return false;
+    const unsigned far = *(volatile unsigned *)it->second.host;
+    return far != HANDOVER_UNKNOWN && (int64_t)far * 64 <= ncoord;
+}
+
 constexpr int INV_CAP = 10;     // list capacity per (cell, tap): offsets below 1 px give at most 9, typically 4
 constexpr int INV_RCAP = 8;     // offsets up to this many pixels are inverted; beyond -> atomic fallback
 constexpr int INV_RTILE = 3;    // the tiled grad_input kernel's dY window covers lists built with a radius up to this
@@ -2409,7 +2426,9 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             unsigned char *flags = (unsigned char *)(wf + 2 * nw);
             unsigned *far_count = (unsigned *)flags + (nflag_words - 1);
             const int64_t ncoord = (int64_t)B * 18 * g.HoWo;
-            const unsigned far_limit = (unsigned)(ncoord / 32 < 0xffffffffll ? ncoord / 32 : 0xffffffffll);
+            const bool keeps = forward_keeps_far_samples(weight, ncoord);     // no far count, no rescue launch (policy above)
+            const unsigned far_limit = keeps ? 0xffffffffu : (unsigned)(ncoord / 32 < 0xffffffffll ? ncoord / 32 : 0xffffffffll);
+            const int rescue_taps_call = keeps ? 10 : rescue_taps;            // 10: no region is ever handed over (nine taps)
             const size_t n9 = (size_t)Cin * 9 * g.Cop;
             if (nwl <= nw && n9 <= nw && workspace_bytes >= 2 * nw * sizeof(float) + (size_t)nflag_words * 4) {
                 float *wf9 = wf + nw;                         // [Wl | Wf9 | flags]
@@ -2419,7 +2438,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                 else
                     hipLaunchKernelGGL(dcn_prep_weights_tile, dim3((unsigned)((nwl + 255) / 256 < 2048 ? (nwl + 255) / 256 : 2048)),
                                        dim3(256), 0, stream, weight, wf, g, nchunk, nz, (unsigned *)flags, nflag_words, wf9);
-                {
+                if (!keeps) {
                     int gsz = (int)((ncoord + 4095) / 4096);
                     if (gsz > 512) gsz = 512;
                     hipLaunchKernelGGL(dcn_fwd_far_count, dim3(gsz), dim3(256), 0, stream, offset, ncoord, far_count);
@@ -2427,21 +2446,22 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                 if (split && rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<8>, dim3(regions, B, nz), dim3(512),
                                        TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
-                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps, (const unsigned *)far_count,
+                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call, (const unsigned *)far_count,
                                        far_limit);
                 else if (split)
                     hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<4>, dim3(regions, B, nz), dim3(256),
                                        TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
-                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps, (const unsigned *)far_count,
+                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call, (const unsigned *)far_count,
                                        far_limit);
                 else if (rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps,
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call,
                                        (const unsigned *)far_count, far_limit);
                 else
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<4>, dim3(regions, B, nz), dim3(256), 2 * TileCfg<4>::BUF * sizeof(float), stream,
-                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps,
+                                       input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call,
                                        (const unsigned *)far_count, far_limit);
+                if (keeps) return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
                 // rescue pass: register-gather kernel over the flagged regions only (usually none: its waves exit at once)
                 const int nb9 = g.Cop / 32, mb9 = nb9 >= 4 ? 4 : nb9 >= 2 ? 2 : 1;
                 dim3 gridr((tiles_x * g.Ho + 3) / 4, B, (nb9 + mb9 - 1) / mb9);

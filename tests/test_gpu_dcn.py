@@ -304,6 +304,12 @@ def test_one_pass_backward_keeps_far_heavy_calls_once_the_layer_is_known_as_near
             close(g_, r_, 2e-6, "hand-over on vs off, near offsets")
         g = torch.Generator().manual_seed(seed + 100)
         off_far = torch.randn(off.shape, generator=g) * 2.5            # ~23 % of the coordinates beyond 3 px
+        # forward side of the policy: after a near backward the tiled forward runs without its far count and rescue launch and
+        # takes every far sample in the kernel -- near offsets and (the report still says "near") far-heavy ones
+        torch.cuda.synchronize()
+        for o_ in (off, off_far):
+            close(_ext.dcn_v2_forward(dev[0], dev[1], dev[2], o_.to(cuda), dev[4], *a).cpu(), oracle_dcn.dcn_v2_forward(x, w, b, o_, m, *a),
+                  2e-5, "forward without rescue launch %s" % ((B, C, Co, H, W),))
         ref = oracle_dcn.dcn_v2_backward(x, w, b, off_far, m, gy, *a)
         got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], off_far.to(cuda), dev[4], dev[5], *a)
         for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), got, ref):
