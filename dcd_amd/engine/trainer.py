@@ -498,6 +498,10 @@ class GraphedTrainStep:
                         if torch.is_tensor(v):
                             v.copy_(old[k]) if old is not None and k in old else v.zero_()
             self.optimizer.zero_grad(set_to_none=True)
+        if on_gpu:
+            # The DCN calls choose their launch sequence per layer from what the layer's previous call reported to the host
+            # (csrc/dcn_v2.hip, hand-over policy); the graph freezes that choice, so let the warm-up's reports arrive first.
+            torch.cuda.synchronize()
         # from here on nothing is executed: a failure below leaves every rank with the same collective history
         if self._fail_capture:                               # test hook: this rank's capture "fails" (after the common warm-up)
             raise RuntimeError("capture failure requested (test hook)")
