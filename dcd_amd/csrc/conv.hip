@@ -636,7 +636,7 @@ struct WrwGeom {
     static constexpr int KO = 32 * NOB;
     static constexpr int DY = KO * WW_DPLANE;      // 4 224 / 2 112 floats
     static constexpr int BUF = WW_IN + DY;         // 14 592 floats (58 KB) per buffer with NOB = 2
-    static constexpr int PART = 16 * KO * 64;      // floats per partial result
+    static constexpr int PART = 12 * KO * 64;      // floats per partial result: [xi 4][b 3][k][c] (the column half of G^T . G is applied before the store)
 };
 
 template <int NOB>
@@ -818,20 +818,25 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 #endif
     }
 
-    // acc[nu][ob][r] = M[xi][nu][k = 32 ob + (r&3) + 8 (r>>2) + 4h][c = 32 cb + p]  ->  part[blk][split][xi*4+nu][k][c]
+    // acc[nu][ob][r] = M[xi][nu][k = 32 ob + (r&3) + 8 (r>>2) + 4h][c = 32 cb + p]  ->  part[blk][split][xi*3+b][k][c]
 #ifdef WW_ABL_NOEPI
     if (acc[0][0][0] != 123.456f) return;
 #endif
+    // dL/dg = G^T M G: the sum over nu (columns of M: (1, .5, .5, 0), (0, .5, -.5, 0), (0, .5, .5, 1)) is linear and local to the wave,
+    // so it is applied to the partial before the store -- 12 instead of 16 planes per partial to write here and to read back in
+    // wino_wrw_reduce, which applies the row half over xi (the partials are 64 MB per 64 -> 64 @ 96x320 call)
     float *mine = part + ((size_t)blk * S + split) * WW_PART;
 #pragma unroll
-    for (int nu = 0; nu < 4; ++nu)
+    for (int ob = 0; ob < NOB; ++ob)
 #pragma unroll
-        for (int ob = 0; ob < NOB; ++ob)
-#pragma unroll
-            for (int r = 0; r < 16; ++r) {
-                const int k = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
-                mine[((xi * 4 + nu) * KO + k) * 64 + cb * 32 + p] = acc[nu][ob][r];
-            }
+        for (int r = 0; r < 16; ++r) {
+            const int k = 32 * ob + (r & 3) + 8 * (r >> 2) + 4 * h;
+            const float m0 = acc[0][ob][r], m1 = acc[1][ob][r], m2 = acc[2][ob][r], m3 = acc[3][ob][r];
+            float *dst = mine + ((xi * 3) * KO + k) * 64 + cb * 32 + p;
+            dst[0] = m0 + 0.5f * (m1 + m2);
+            dst[KO * 64] = 0.5f * (m1 - m2);
+            dst[2 * KO * 64] = 0.5f * (m1 + m2) + m3;
+        }
 }
 
 // grid = (nblk * KO * 64 / 16), block = 256 = 16 positions x 16 (k,c) pairs: sums the S partials of its 16 pairs (fixed order:
@@ -839,28 +844,27 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
 __global__ __launch_bounds__(256) void wino_wrw_reduce(const float *__restrict__ part, float *__restrict__ gw, int Cin, int Cout, int S,
                                                        int ncg, int KO)
 {
-    __shared__ float m[16][17];
+    __shared__ float m[12][17];
     const int tid = threadIdx.x;
-    const int pos = tid >> 4, l = tid & 15;
+    const int pos = tid >> 4, l = tid & 15;            // pos = xi * 3 + b (12 of the 16 thread rows have work)
     const int gidx = blockIdx.x * 16 + l;           // (blk, k, c)
     const int per = KO * 64;
     const int blk = gidx / per, kc = gidx - blk * per;
-    const float *src = part + ((size_t)blk * S * 16 + pos) * per + kc;
-    float sum = 0.f;
+    if (pos < 12) {
+        const float *src = part + ((size_t)blk * S * 12 + pos) * per + kc;
+        float sum = 0.f;
 #pragma unroll 8
-    for (int sp = 0; sp < S; ++sp) sum += src[(size_t)sp * 16 * per];
-    m[pos][l] = sum;
+        for (int sp = 0; sp < S; ++sp) sum += src[(size_t)sp * 12 * per];
+        m[pos][l] = sum;
+    }
     __syncthreads();
     if (pos < 9) {
         const int a = pos / 3, b = pos - a * 3;
-        // G^T rows: a = 0: (1, .5, .5, 0)   1: (0, .5, -.5, 0)   2: (0, .5, .5, 1)
+        // G^T rows: a = 0: (1, .5, .5, 0)   1: (0, .5, -.5, 0)   2: (0, .5, .5, 1)   (the column half was applied by the producer)
         const float ga[4] = {a == 0 ? 1.f : 0.f, 0.5f, a == 1 ? -0.5f : 0.5f, a == 2 ? 1.f : 0.f};
-        const float gb[4] = {b == 0 ? 1.f : 0.f, 0.5f, b == 1 ? -0.5f : 0.5f, b == 2 ? 1.f : 0.f};
         float r = 0.f;
 #pragma unroll
-        for (int xi = 0; xi < 4; ++xi)
-#pragma unroll
-            for (int nu = 0; nu < 4; ++nu) r += ga[xi] * gb[nu] * m[xi * 4 + nu][l];
+        for (int xi = 0; xi < 4; ++xi) r += ga[xi] * m[xi * 3 + b][l];
         const int og = blk / ncg, cg = blk - og * ncg;
         const int k = og * KO + (kc >> 6), c = cg * 64 + (kc & 63);
         if (k < Cout && c < Cin) gw[((size_t)k * Cin + c) * 9 + pos] = r;
@@ -1170,7 +1174,7 @@ size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout)
     if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
     int nog, ncg, S, sx, KO;
     wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, sx, KO);
-    return (size_t)nog * ncg * S * 16 * KO * 64 * sizeof(float);
+    return (size_t)nog * ncg * S * 12 * KO * 64 * sizeof(float);
 }
 
 int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
@@ -1183,7 +1187,7 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     int nog, ncg, S, strips_x, KO;
     wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x, KO);
     const int nblk = nog * ncg;
-    if (workspace_bytes < (size_t)nblk * S * 16 * KO * 64 * sizeof(float)) return DCD_ERR_WORKSPACE;
+    if (workspace_bytes < (size_t)nblk * S * 12 * KO * 64 * sizeof(float)) return DCD_ERR_WORKSPACE;
     if (KO == 64) {
         static LdsLimit lds_limit;
         const size_t ldsb = (size_t)2 * WrwGeom<2>::BUF * sizeof(float);
