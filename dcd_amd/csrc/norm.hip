@@ -151,6 +151,10 @@ __global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict
     }
     block_sum2(ds, unused);
     __shared__ int is_last;
+    if (!arrivals) {                                     // two-launch form: channel_sum_combine adds the partials
+        if (threadIdx.x == 0) partial[(long)c * S + s] = ds;
+        return;
+    }
     if (threadIdx.x == 0) {
         partial[(long)c * S + s] = ds;
         __threadfence();
@@ -166,6 +170,15 @@ __global__ __launch_bounds__(BT) void channel_sum_kernel(const float *__restrict
         out[c] = (float)a;
         arrivals[c] = 0u;
     }
+}
+
+__global__ __launch_bounds__(64) void channel_sum_combine(const double *__restrict__ partial, int S, float *__restrict__ out)
+{
+    const int c = blockIdx.x;
+    double a = 0.0;
+    for (int q = threadIdx.x; q < S; q += 64) a += partial[(long)c * S + q];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) out[c] = (float)a;
 }
 
 // ---- forward apply: y = act((x - mean) * invstd * w + b [+ residual]) ------------------------------------------------
@@ -569,7 +582,17 @@ int dcd_channel_sums(void *stream_, const float *x, int B, int C, int64_t HW, fl
     const int S = slices(g);
     // partials: the first C * S doubles; arrival counters: C words at the start of the workspace's second half
     unsigned *arrivals = reinterpret_cast<unsigned *>(reinterpret_cast<double *>(ws) + (size_t)C * SMAX);
-    hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, arrivals, sums);
+    // The one-launch form pays an agent-scope release (an L2 write-back on gfx950) per workgroup: fine for a few hundred
+    // workgroups, dearer than a second launch beyond (27 channels x 152 slices @ 96x320 x 8: 45 us against 12).  Same partials,
+    // same summation order, same result either way.  DCD_CHANNEL_SUM_ONE_LAUNCH=1|0 pins the form (A/B timing).
+    static const int pin = getenv("DCD_CHANNEL_SUM_ONE_LAUNCH") ? atoi(getenv("DCD_CHANNEL_SUM_ONE_LAUNCH")) : -1;
+    const bool one = pin >= 0 ? pin != 0 : (long)S * C <= 256;
+    if (one) {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, arrivals, sums);
+    } else {
+        hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, (unsigned *)nullptr, sums);
+        hipLaunchKernelGGL(channel_sum_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, sums);
+    }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
