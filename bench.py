@@ -304,12 +304,19 @@ def run_gpu(args):
     if use_graph:
         # kernels inside a graph replay cannot be bracketed by events: the DCN time comes from eager steps of the same model
         # and batch, run right after the timed region (same process, same clocks)
+        # (one untimed eager step first: allocator blocks of the eager step's sizes, DCN hand-over reports).  Under data
+        # parallelism the eager step is host-bound (136 SyncBN collectives issued from Python), so the launches of one DCN call are
+        # not queued back to back and the gaps between them fall between the call's two events: the figure is an upper bound there
+        # (16-18 ms where the single-process eager step measures 13.5-14).
+        train_step(model, optimizer, images, targets, clip)
+        torch.cuda.synchronize()
         timer.enabled = True
         for _ in range(args.dcn_steps):
             train_step(model, optimizer, images, targets, clip)
         torch.cuda.synchronize()
         timer.enabled = False
-        dcn_source = "event pairs around every DCN call in %d eager steps run right after the timed (graph-replayed) region" % args.dcn_steps
+        dcn_source = ("event pairs around every DCN call in %d eager steps run right after the timed (graph-replayed) region%s"
+                      % (args.dcn_steps, "; host-bound under data parallelism: includes launch gaps, an upper bound" if data_parallel else ""))
     offsets = None
     if rank == 0 and not (isinstance(model, torch.nn.parallel.DistributedDataParallel) or data_parallel):
         # one eager FORWARD of the same model and batch, outside the timed region (no collectives involved: single-process runs only)

@@ -563,6 +563,9 @@ class GraphedTrainStep:
         entry = self._graphs[self._signature(images, targets)]
         self._copy_in(entry, images, targets)
         entry["graph"].replay()
+        # the replay stepped the optimizer without touching the parameters' version counters: an eager forward that follows must
+        # not take the transformed 3x3 weights of the step before for current (the graph itself re-transforms them every replay)
+        ops.invalidate_conv_weights()
         return entry["out"]
 
     def __call__(self, images, targets):

@@ -883,6 +883,18 @@ class _PreparedWeights:
 _PREPARED = {}                     # device index -> _PreparedWeights
 
 
+def invalidate_conv_weights(device=None):
+    """Forget that the table's entries are current (the next `refresh_conv_weights` re-validates them).  For code that changes
+    parameters without going through autograd's version counters -- a replayed HIP graph that contains the optimizer step."""
+    if not torch.cuda.is_available():
+        return
+    idx = torch.cuda.current_device() if device is None else torch.device(device).index
+    p = _PREPARED.get(idx)
+    if p is not None:
+        for e in p.entries.values():
+            e[4] = -1
+
+
 def conv3x3_step_weights(weight, like):
     """(forward, backward-data) Winograd-domain weights for a call inside a train step: the step's table entry when it is
     current (no launch), else transformed now -- both directions, one launch -- and the layer is registered for the next
