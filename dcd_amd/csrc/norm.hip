@@ -109,7 +109,10 @@ __global__ __launch_bounds__(BT) void bn_partial(const float *__restrict__ x, Pl
 }
 
 // ---- combine S partials per channel (fixed order -> deterministic) ---------------------------------------------------
-__global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ partial, int S, double *__restrict__ out)
+// gw / gb (backward sums only, may be null): this rank's grad_weight = sum(dz * (x - mean)) * invstd and grad_bias = sum(dz) as fp32
+// -- under data parallelism the parameter gradients stay local while the sums are all-reduced for the input gradient.
+__global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ partial, int S, double *__restrict__ out,
+                                                 const float *__restrict__ invstd, float *__restrict__ gw, float *__restrict__ gb)
 {
     const int c = blockIdx.x;
     double a = 0.0, b = 0.0;
@@ -119,7 +122,12 @@ __global__ __launch_bounds__(64) void bn_combine(const double *__restrict__ part
     }
     a = wave_sum(a);
     b = wave_sum(b);
-    if (threadIdx.x == 0) { out[2 * c] = a; out[2 * c + 1] = b; }
+    if (threadIdx.x == 0) {
+        out[2 * c] = a;
+        out[2 * c + 1] = b;
+        if (gw) gw[c] = (float)(b * (double)invstd[c]);
+        if (gb) gb[c] = (float)a;
+    }
 }
 
 // ---- per-channel sums in ONE launch (a bias gradient): the slices of bn_partial, and the block that arrives last at a
@@ -244,9 +252,12 @@ __global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, cons
 }
 
 // ---- backward sums: partial[c][s] = (sum dz, sum dz * (x - mean)), dz = dy * [y > 0] when ReLU is fused ---------------
+// invstd / gw / gb: only with S == 1 (the block's sums are the channel's: see bn_combine)
 __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ dy, const float *__restrict__ y,
                                                      const float *__restrict__ x, const float *__restrict__ save_mean,
-                                                     Plane g, int S, double *__restrict__ partial)
+                                                     Plane g, int S, double *__restrict__ partial,
+                                                     const float *__restrict__ invstd = nullptr, float *__restrict__ gw = nullptr,
+                                                     float *__restrict__ gb = nullptr)
 {
     const int c = blockIdx.y, s = blockIdx.x;
     const int P = g.B * g.cpp;
@@ -285,6 +296,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ d
     if (threadIdx.x == 0) {
         partial[((long)c * S + s) * 2 + 0] = d0;
         partial[((long)c * S + s) * 2 + 1] = d1;
+        if (gw) gw[c] = (float)(d1 * (double)invstd[c]);
+        if (gb) gb[c] = (float)d0;
     }
 }
 
@@ -551,6 +564,14 @@ inline int slices(const Plane &g)
     return (int)(want < 1 ? 1 : want);
 }
 
+// Synchronised statistics (the sums are all-reduced between two launches): one slice per channel while a channel holds at most
+// 32 K elements -- the block's sums ARE the channel's, written straight to the output, no combine launch (one image per GPU:
+// every DGDE layer but the stem; 110 launches of a one-image data-parallel step).
+inline int sync_slices(const Plane &g)
+{
+    return (long)g.B * g.HW <= 32768 ? 1 : slices(g);
+}
+
 inline bool bad_shape(int B, int C, long HW) { return B <= 0 || C <= 0 || HW <= 0 || C > 65535 || (double)B * ((HW + CH - 1) / CH) > 2.0e9; }
 
 }  // namespace
@@ -566,9 +587,14 @@ int dcd_bn_stats(void *stream_, const float *x, int B, int C, int64_t HW, double
     if (!x || !stats || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
     if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
     const Plane g = make_plane(B, C, HW);
-    const int S = slices(g);
-    hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
-    hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, stats);
+    const int S = sync_slices(g);
+    if (S == 1) {
+        hipLaunchKernelGGL(bn_partial, dim3(1, C), dim3(BT), 0, stream, x, g, 1, stats);
+    } else {
+        hipLaunchKernelGGL(bn_partial, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws);
+        hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, stats, (const float *)nullptr, (float *)nullptr,
+                           (float *)nullptr);
+    }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
@@ -627,18 +653,38 @@ int dcd_bn_eval_apply(void *stream_, const float *x, const float *residual, cons
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
+static int bn_backward_stats_run(hipStream_t stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
+                                 const float *save_invstd, int B, int C, int64_t HW, double *sums, float *grad_weight, float *grad_bias,
+                                 void *ws, size_t ws_bytes)
+{
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !sums || bad_shape(B, C, HW) || ((grad_weight || grad_bias) && !save_invstd)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    const Plane g = make_plane(B, C, HW);
+    const int S = sync_slices(g);
+    if (S == 1) {
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(1, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, 1, sums, save_invstd, grad_weight,
+                           grad_bias);
+    } else {
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws, (const float *)nullptr,
+                           (float *)nullptr, (float *)nullptr);
+        hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, sums, save_invstd, grad_weight, grad_bias);
+    }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
 int dcd_bn_backward_stats(void *stream_, const float *grad_y, const float *y, const float *x, const float *save_mean, int B,
                           int C, int64_t HW, double *sums, void *ws, size_t ws_bytes)
 {
-    hipStream_t stream = (hipStream_t)stream_;
-    (void)hipGetLastError();
-    if (!grad_y || !x || !save_mean || !sums || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
-    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
-    const Plane g = make_plane(B, C, HW);
-    const int S = slices(g);
-    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws);
-    hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, sums);
-    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    return bn_backward_stats_run((hipStream_t)stream_, grad_y, y, x, save_mean, nullptr, B, C, HW, sums, nullptr, nullptr, ws, ws_bytes);
+}
+
+int dcd_bn_backward_stats_params(void *stream_, const float *grad_y, const float *y, const float *x, const float *save_mean,
+                                 const float *save_invstd, int B, int C, int64_t HW, double *sums, float *grad_weight,
+                                 float *grad_bias, void *ws, size_t ws_bytes)
+{
+    return bn_backward_stats_run((hipStream_t)stream_, grad_y, y, x, save_mean, save_invstd, B, C, HW, sums, grad_weight, grad_bias, ws,
+                                 ws_bytes);
 }
 
 int dcd_bn_backward_apply(void *stream_, const float *grad_y, const float *y, const float *x, const float *weight,

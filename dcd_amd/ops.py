@@ -689,10 +689,12 @@ class _BatchNormAct(torch.autograd.Function):
             # weight / bias gradients stay local (DDP averages them); the input gradient needs the global sums
             import torch.distributed as dist
             sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
-            _lib.check(L.dcd_bn_backward_stats(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), save_mean.data_ptr(), B, C, HW,
-                                               sums.data_ptr(), ws.data_ptr(), ws.numel()), "dcd_bn_backward_stats")
-            gw = (sums[:, 1] * save_invstd.double()).float()
-            gb = sums[:, 0].float()
+            gw = torch.empty(C, dtype=torch.float32, device=dev)
+            gb = torch.empty(C, dtype=torch.float32, device=dev)
+            # this rank's parameter gradients come out of the same launch(es) as the sums (they were three ATen ops per layer)
+            _lib.check(L.dcd_bn_backward_stats_params(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), save_mean.data_ptr(),
+                                                      save_invstd.data_ptr(), B, C, HW, sums.data_ptr(), gw.data_ptr(), gb.data_ptr(),
+                                                      ws.data_ptr(), ws.numel()), "dcd_bn_backward_stats_params")
             dist.all_reduce(sums, group=ctx.group)
             _lib.check(L.dcd_bn_backward_apply(st, gy.data_ptr(), _lib.ptr(y), x.data_ptr(), _lib.ptr(weight), save_mean.data_ptr(),
                                                save_invstd.data_ptr(), sums.data_ptr(), ctx.count, gx.data_ptr(), gres_ptr, None, None,

@@ -348,6 +348,12 @@ int dcd_bn_eval_apply(void *stream, const float *x, const float *residual, const
                       int64_t HW);
 int dcd_bn_backward_stats(void *stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
                           int B, int C, int64_t HW, double *sums, void *workspace, size_t workspace_bytes);
+/* dcd_bn_backward_stats that also writes THIS rank's parameter gradients from the same sums (grad_weight[c] = sum dz*(x-mean) *
+ * invstd, grad_bias[c] = sum dz; either may be NULL): under data parallelism they stay local (DDP averages parameter gradients)
+ * while `sums` is all-reduced for the input gradient -- torch.nn.SyncBatchNorm's backward, torch/nn/modules/_functions.py. */
+int dcd_bn_backward_stats_params(void *stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
+                                 const float *save_invstd, int B, int C, int64_t HW, double *sums, float *grad_weight,
+                                 float *grad_bias, void *workspace, size_t workspace_bytes);
 int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, const float *x, const float *weight,
                           const float *save_mean, const float *save_invstd, const double *sums, double count,
                           float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,

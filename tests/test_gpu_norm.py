@@ -101,16 +101,22 @@ def test_bn_sync_group_world_size_1_equals_local(cuda, tmp_path):
         created = True
     try:
         g = torch.Generator(device="cpu").manual_seed(11)
-        x = torch.randn(2, 8, 12, 40, generator=g).to(cuda)
-        a, b = BatchNorm2d(8, fuse_relu=True).to(cuda).train(), BatchNorm2d(8, fuse_relu=True).to(cuda).train()
-        b.sync_group = dist.group.WORLD
-        xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
-        ya, yb = a(xa), b(xb)
-        ya.sum().backward()
-        yb.sum().backward()
-        assert torch.equal(ya, yb) and torch.equal(xa.grad, xb.grad)
-        _close(b.weight.grad, a.weight.grad.double(), "grad_weight", 1e-6)
-        assert torch.equal(a.running_var, b.running_var)
+        # two sizes: one slice per channel (sums straight from the statistics kernels, no combine launch) and the two-stage form
+        for shape in ((2, 8, 12, 40), (2, 8, 160, 128)):
+            x = torch.randn(*shape, generator=g).to(cuda)
+            a, b = BatchNorm2d(8, fuse_relu=True).to(cuda).train(), BatchNorm2d(8, fuse_relu=True).to(cuda).train()
+            b.sync_group = dist.group.WORLD
+            xa, xb = x.clone().requires_grad_(), x.clone().requires_grad_()
+            ya, yb = a(xa), b(xb)
+            w = torch.randn(*shape, generator=g).to(cuda)
+            (ya * w).sum().backward()
+            (yb * w).sum().backward()
+            # same sums up to their order (the local path reduces in one kernel, the synchronised one in slices)
+            _close(yb, ya.double(), "forward %s" % (shape,), 1e-6)
+            _close(xb.grad, xa.grad.double(), "grad_input %s" % (shape,), 1e-5)
+            _close(b.weight.grad, a.weight.grad.double(), "grad_weight %s" % (shape,), 1e-5)
+            _close(b.bias.grad, a.bias.grad.double(), "grad_bias %s" % (shape,), 1e-5)
+            _close(b.running_var, a.running_var.double(), "running_var %s" % (shape,), 1e-6)
     finally:
         if created:
             dist.destroy_process_group()
