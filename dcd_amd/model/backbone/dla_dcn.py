@@ -47,9 +47,11 @@ class BasicBlock(nn.Module):
         self.stride = stride
 
     def forward(self, x, residual=None):
-        if residual is None:
-            residual = x
-        out = self.bn1(self.conv1(x))                      # bn + relu
+        if residual is None or residual is x:
+            y, residual = self.conv1.forward_with_skip(x)   # identity skip: its gradient joins conv1's inside the kernel
+        else:
+            y = self.conv1(x)
+        out = self.bn1(y)                                  # bn + relu
         return self.bn2(self.conv2(out), residual)         # bn + residual + relu
 
 

@@ -13,6 +13,7 @@ from torch import nn
 from dcd_amd import ops
 
 _ENABLED = os.environ.get("DCD_CONV_WINOGRAD", "1") != "0"
+_SKIP = os.environ.get("DCD_CONV_SKIP_NODE", "1") != "0"     # 0: conv + identity skip as two consumers of x (A/B timing)
 _STEM = os.environ.get("DCD_CONV_STEM", "1") != "0"          # 0: the two stem convolutions stay on the stock op (A/B timing)
 
 
@@ -37,6 +38,16 @@ class Conv2d(nn.Conv2d):
                      or ops.conv3x3_bias_supported(x, self.weight, self.stride, self.padding, self.dilation))):
             return ops.conv2d_bias(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
         return super().forward(x)
+
+
+    def forward_with_skip(self, x):
+        """(self(x), x): for a block whose skip connection starts at this convolution's input.  On the Winograd path the skip's
+        gradient is added inside the input-gradient kernel (ops.conv3x3_with_skip); otherwise x itself is returned."""
+        if (_ENABLED and _SKIP and self.bias is None and self.kernel_size == (3, 3) and self.stride == (1, 1) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros" and torch.is_grad_enabled()
+                and x.requires_grad and ops.conv3x3_supported(x, self.weight)):
+            return ops.conv3x3_with_skip(x, self.weight)
+        return self.forward(x), x
 
 
 class DepthwiseUpsample(nn.ConvTranspose2d):

@@ -780,8 +780,9 @@ def conv3x3_transform_weights(weight, forward=True, backward=True, like=None):
     return tf, tb
 
 
-def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None, transformed=None):
-    """residual: a tensor of the output's shape that the result is added to IN PLACE (and returned).
+def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None, transformed=None, residual_inplace=True):
+    """residual: a tensor of the output's shape that the result is added to -- IN PLACE (and returned) unless residual_inplace
+    is False (then it is only read: a gradient the caller does not own).
     transformed: this direction's weights from conv3x3_transform_weights (else they are transformed inside the call)."""
     L = _lib.lib()
     B, _, H, W = inp.shape
@@ -789,7 +790,7 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
     if residual is not None:
         if tuple(residual.shape) != (B, out_channels, H, W) or residual.dtype != torch.float32 or not residual.is_contiguous():
             raise RuntimeError("conv3x3: residual must be a contiguous fp32 tensor of the output's shape")
-        out = residual
+        out = residual if residual_inplace else torch.empty_like(residual)
     else:
         out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
     if transformed is None and _conv_split(inp):
@@ -971,6 +972,42 @@ class _Conv3x3(torch.autograd.Function):
 
 def conv3x3(x, weight):
     return _Conv3x3.apply(x, weight)
+
+
+class _Conv3x3Skip(torch.autograd.Function):
+    """(conv3x3(x, w), x): the convolution and an alias of its input for a skip connection that starts at the same tensor
+    (DLA's BasicBlock with an identity residual, dla_dcn.py:83-101: x feeds conv1 and the block's final addition).  As two
+    consumers of x autograd adds their gradients in a pass of its own (read, read, write over the map); here the skip's
+    gradient enters the input-gradient kernel as its `residual` and is added in the output transform."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        ctx.save_for_backward(x, weight)
+        tw, ctx.tw_back = conv3x3_step_weights(weight, x) if _PREP_BOTH and ctx.needs_input_grad[0] else (None, None)
+        return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw), x.view_as(x)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy, gskip):
+        x, weight = ctx.saved_tensors
+        gx = gw = None
+        if gy is None:                                      # only the skip was used
+            return gskip, None
+        gy = _f32c(gy)
+        if ctx.needs_input_grad[0]:
+            res = None if gskip is None else _f32c(gskip)   # read only: the gradient tensor belongs to autograd
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True, residual=res, transformed=ctx.tw_back, residual_inplace=False)
+        if ctx.needs_input_grad[1]:
+            gw = (_conv3x3_wrw_call(x, gy, weight.shape) if _WRW_ENABLED else
+                  torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1])
+        return gx, gw
+
+
+def conv3x3_with_skip(x, weight):
+    """(conv3x3(x, weight), x) with the two gradients of x summed inside the input-gradient kernel."""
+    return _Conv3x3Skip.apply(x, weight)
 
 
 def conv3x3_wrw_only_supported(x, weight):

@@ -109,6 +109,31 @@ def test_prepared_weight_table_one_launch_for_all_layers(cuda):
     assert torch.equal(ops.conv3x3(x[1], ws[1]), y)
 
 
+def test_conv_with_skip_sums_both_gradients_in_the_kernel(cuda):
+    """ops.conv3x3_with_skip: (conv(x), x) as one node; d/dx = input gradient of the convolution + the skip's gradient, added in the
+    kernel's output transform -- against the two-consumer form (autograd's own addition), incl. a split contraction (small map)."""
+    from dcd_amd import ops
+    g = torch.Generator(device=cuda).manual_seed(17)
+    for B, C, H, W in ((2, 64, 24, 80), (1, 256, 8, 32)):
+        x = torch.randn(B, C, H, W, device=cuda, generator=g)
+        w = torch.randn(C, C, 3, 3, device=cuda, generator=g) / (C * 9) ** 0.5
+        gy, gs = torch.randn(B, C, H, W, device=cuda, generator=g), torch.randn(B, C, H, W, device=cuda, generator=g)
+        xa, wa = x.clone().requires_grad_(), w.clone().requires_grad_()
+        y, skip = ops.conv3x3_with_skip(xa, wa)
+        gs_before = gs.clone()
+        torch.autograd.backward([y, skip], [gy, gs])
+        assert torch.equal(gs, gs_before)                     # the skip's gradient is read, not accumulated into
+        xb, wb = x.clone().requires_grad_(), w.clone().requires_grad_()
+        yb = ops.conv3x3(xb, wb)
+        torch.autograd.backward([yb, xb * 1.0], [gy, gs])
+        assert torch.equal(y, yb)
+        _close(xa.grad, xb.grad.double(), "grad_input with skip", 1e-6)
+        assert torch.equal(wa.grad, wb.grad)
+        xc = x.clone().requires_grad_()
+        ops.conv3x3_with_skip(xc, w)[1].backward(gs)           # only the skip used
+        assert torch.equal(xc.grad, gs)
+
+
 def test_conv_module_dispatch(cuda):
     from dcd_amd.model.layers.conv import Conv2d
     conv = Conv2d(64, 64, 3, padding=1, bias=False).to(cuda)
