@@ -24,6 +24,7 @@ def main():
     types = collections.Counter()
     fanin = collections.Counter()
     views = collections.Counter()
+    consumers = collections.defaultdict(list)
     while stack:
         n = stack.pop()
         if n is None or n in seen:
@@ -37,6 +38,7 @@ def main():
         for nxt, idx in n.next_functions:
             if nxt is not None:
                 fanin[(nxt, idx)] += 1
+                consumers[(nxt, idx)].append(name)
                 stack.append(nxt)
     print("nodes:", sum(types.values()))
     for k, v in types.most_common(60):
@@ -48,6 +50,13 @@ def main():
     for (n, idx), c in fanin.items():
         if c > 1:
             multi[(type(n).__name__, c)] += 1
+    pat = collections.Counter()
+    for (n, idx), c in fanin.items():
+        if c > 1:
+            pat[(type(n).__name__, tuple(sorted(consumers[(n, idx)])))] += 1
+    print("producer <- consumers (count):")
+    for (k, cons), v in sorted(pat.items(), key=lambda x: -x[1]):
+        print("  %3d  %s <- %s" % (v, k, ", ".join(cons)))
     print("inputs fed by more than one consumer (each extra consumer = one addition in the backward):")
     for (k, c), v in sorted(multi.items(), key=lambda x: -x[1]):
         print("  %4d  %s x%d" % (v, k, c))
