@@ -69,11 +69,16 @@ def patch_moments_gram(x):
 
 
 # ---- autocorrelation form ---------------------------------------------------------------------------------------------------
-# G[(c,t),(c',t')] = sum_p X[c, p+t-1] X[c', p+t'-1] depends on the taps only through d = t' - t, up to border terms:
-#     G(t,t') = R_d - (terms of the one image row / column that the zero padding cuts off for tap t)
-#     R_d[c,c'] = sum_u X[c,u] X[c',u+d]                 (X = 0 outside the image; d in [-2,2]^2, R_-d = R_d^T)
-# 13 products of size C x C x BHW instead of (9C)^2 x BHW: 6x fewer flops, and no patch matrix at all -- the shifted operand is a
-# pointer offset into the zero-padded image (dcd_sgemm_shifted).  The border terms need the three outermost rows / columns only.
+# Summed over the EXTENDED pixel range p in [-1, H] x [-1, W] (one ring around the image), every in-image u = p + t - 1 occurs
+# exactly once for every tap t, so
+#     G_ext[(c,t),(c',t')] = sum_u X[c,u] X[c',u+d] = R_d[c,c'],   d = t' - t in [-2,2]^2,  R_-d = R_d^T   (X = 0 outside the image)
+# depends on the taps only through d: 13 products of size C x C x BHW instead of (9C)^2 x BHW -- 6x fewer flops, and no patch
+# matrix at all: the shifted operand is a pointer offset into the zero-padded image (dcd_sgemm_shifted).  The true sums run over
+# the image's own pixels, i.e. G = G_ext - sum over the ring's 2 (W + 2) + 2 H pixels of P_p P_p^T (their zero-padded patches only
+# touch the two outermost rows / columns), and S1 = total - sum over the ring of P_p.  The ring's patches are gathered by the
+# correlation node (like the patches at the listed positions) and their Gram matrix is one small batched product.
+# (Rounds 2-3 wrote the same correction as ~60 small tensor operations on the border bands -- row / column / corner terms per
+# tap pair -- and ~100 more in their backward: the longest run of tiny launches of the step.)
 HALF = [(dy, dx) for dy in range(0, 3) for dx in range(-2, 3) if dy > 0 or dx >= 0]           # 13 shifts, (0,0) first
 ALL25 = [(dy, dx) for dy in range(-2, 3) for dx in range(-2, 3)]
 _CONST = {}
@@ -85,11 +90,22 @@ def _const(key, build):
     return _CONST[key]
 
 
+def _ring_bases(H, W, Wp, device):
+    """Padded-plane index of (window corner - (1, 1)) for the ring pixels p = (py, px), py in {-1, H} or px in {-1, W}: the
+    3x3 window of p covers padded rows py + 1 .. py + 3, columns px + 1 .. px + 3 (image (y, x) sits at padded (y + 2, x + 2))."""
+    def build():
+        ring = [(-1, px) for px in range(-1, W + 1)] + [(H, px) for px in range(-1, W + 1)]
+        ring += [(py, -1) for py in range(H)] + [(py, W) for py in range(H)]
+        return torch.tensor([py * Wp + px for py, px in ring], dtype=torch.int64, device=device)
+    return _const(("ring", H, W, Wp, str(device)), build)
+
+
 class _ShiftCorr(torch.autograd.Function):
-    """x (B,C,H,W) -> R (13,C,C) fp64 [HALF order], total (C,) fp64 = sum of x per channel, and copies of the border bands
-    (top / bottom three rows, left / right three columns) through which autograd reaches the border terms.
+    """x (B,C,H,W) -> R (13,C,C) fp64 [HALF order], total (C,) fp64 = sum of x per channel, the zero-padded 3x3 patches of the
+    ring pixels (B, 9C, 2 (W + 2) + 2 H) [row c*9 + tap] and, with `positions` (B, n), the patches at those cells (B, 9C, n).
     Device tensors: two launches of the shifted-view GEMM (forward: A = padded x, B = its 13 shifts, split-K partials summed in
-    fp64; backward: dX = K Xshift over all 25 shifts with the gradient of `total` as the row bias).  Host tensors (the fp64
+    fp64; backward: dX = K Xshift over all 25 shifts with the gradient of `total` as the row bias); the patch gradients are
+    scatter-added into dX by this node's backward (no zero-filled map, no extra full-size addition).  Host tensors (the fp64
     host-logic tests): the same sums written with torch slices."""
 
     @staticmethod
@@ -120,26 +136,29 @@ class _ShiftCorr(torch.autograd.Function):
             R = torch.stack([torch.einsum('bcyx,bkyx->ck', xp[:, :, 2:2 + H, 2:2 + W], xp[:, :, 2 + dy:2 + dy + H, 2 + dx:2 + dx + W])
                              for (dy, dx) in HALF]).double()
         total = x.sum(3).double().sum((0, 2))
-        outs = (R, total, x[:, :, 0:3, :].clone(), x[:, :, H - 3:H, :].clone(), x[:, :, :, 0:3].clone(), x[:, :, :, W - 3:W].clone())
-        ctx.pidx = None
+        taps = _const(("ptaps", Wp, str(x.device)), lambda: torch.tensor(
+            [(dy + 1) * Wp + dx + 1 for dy in range(3) for dx in range(3)], device=x.device))
+        flat = xp.reshape(B, C, Lp)
+
+        def gather(base):                                   # base (Bx, n): window corner - (1, 1) -> (B, 9C, n), row c*9 + tap
+            n = base.shape[1]
+            idx = (base.unsqueeze(1) + taps.view(1, 9, 1)).reshape(base.shape[0], 1, 9 * n)
+            return flat.gather(2, idx.expand(B, C, 9 * n)).reshape(B, 9 * C, n)
+
+        rbase = _ring_bases(H, W, Wp, x.device).view(1, -1)
+        ctx.rbase = (rbase + Wp + 1).expand(B, -1).contiguous()                              # top-left element of each 3x3 window
+        outs = (R, total, gather(rbase))
+        ctx.pbase = None
         if positions is not None:
-            # the 3x3 patches at listed cells (B, n) -> (B, 9C, n) [row c*9 + tap] read from the padded buffer: their gradient is
-            # scatter-added into this node's dx in the backward (no zero-filled map, no extra full-size addition)
             pos = positions.long()
-            n = pos.shape[1]
-            taps = _const(("ptaps", Wp, str(x.device)), lambda: torch.tensor(
-                [(dy + 1) * Wp + dx + 1 for dy in range(3) for dx in range(3)], device=x.device))
-            base = (pos // W) * Wp + pos % W                                                     # (B, n): window's corner - (1, 1)
-            idx = base.unsqueeze(1) + taps.view(1, 9, 1)                                        # (B, 9, n) into the padded plane
-            idx = idx.reshape(B, 1, 9 * n)
-            ctx.pidx = idx
-            ctx.pbase = (base + Wp + 1).contiguous()                                            # top-left element of the 3x3 window
-            outs = outs + (xp.reshape(B, C, Lp).gather(2, idx.expand(B, C, 9 * n)).reshape(B, 9 * C, n),)
+            base = (pos // W) * Wp + pos % W
+            ctx.pbase = (base + Wp + 1).contiguous()
+            outs = outs + (gather(base),)
         return outs
 
     @staticmethod
     @torch.autograd.function.once_differentiable
-    def backward(ctx, dR, dtotal, dT, dBt, dL, dRr, dP=None):
+    def backward(ctx, dR, dtotal, dRing, dP=None):
         buf, = ctx.saved_tensors
         B, C, H, W, Hp, Wp, Lp, guard = ctx.geom
         xp = buf[guard:guard + B * C * Lp].view(B, C, Hp, Wp)
@@ -169,39 +188,30 @@ class _ShiftCorr(torch.autograd.Function):
             for j, (dy, dx_) in enumerate(ALL25):
                 dxi += torch.einsum('ck,bkyx->bcyx', K1[:, j, :], xp[:, :, 2 + dy:2 + dy + H, 2 + dx_:2 + dx_ + W])
             dxp[:, :, 2:2 + H, 2:2 + W] = dxi
-        if ctx.pidx is not None and dP is not None:
-            n9 = ctx.pidx.shape[2]
+        # patch gradients (ring, listed positions): scatter-added onto the padded plane; what lands on the padding is dropped below
+        for grad, pbase in ((dRing, ctx.rbase), (dP, ctx.pbase)):
+            if grad is None or pbase is None:
+                continue
+            n = pbase.shape[1]
             if dxp.is_cuda:
                 from dcd_amd import _lib
-                gp = dP.to(dxp.dtype).contiguous()
-                st = _lib.lib().dcd_patch_scatter_add(_lib.stream_of(dxp), gp.data_ptr(), ctx.pbase.data_ptr(), B, C, Lp, Wp, n9 // 9,
-                                                      dxp.data_ptr())
+                gp = grad.to(dxp.dtype).contiguous()
+                st = _lib.lib().dcd_patch_scatter_add(_lib.stream_of(dxp), gp.data_ptr(), pbase.data_ptr(), B, C, Lp, Wp, n, dxp.data_ptr())
                 _lib.check(st, "dcd_patch_scatter_add")
             else:
-                dxp.view(B, C, Lp).scatter_add_(2, ctx.pidx.expand(B, C, n9), dP.reshape(B, C, n9).to(dxp.dtype))
-        dx = dxp[:, :, 2:2 + H, 2:2 + W].contiguous()
-        dx[:, :, 0:3, :] += dT
-        dx[:, :, H - 3:H, :] += dBt
-        dx[:, :, :, 0:3] += dL
-        dx[:, :, :, W - 3:W] += dRr
-        return dx, None
+                taps = torch.tensor([dy * Wp + dx for dy in range(3) for dx in range(3)], device=dxp.device)
+                idx = (pbase.unsqueeze(1) + taps.view(1, 9, 1)).reshape(B, 1, 9 * n)
+                dxp.view(B, C, Lp).scatter_add_(2, idx.expand(B, C, 9 * n), grad.reshape(B, C, 9 * n).to(dxp.dtype))
+        return dxp[:, :, 2:2 + H, 2:2 + W].contiguous(), None
 
 
-def _border_tables(device):
-    """Constant tables of the assembly: E[t,t'] = index of d = t' - t in ALL25; Mk[t, s] = coefficient of border term s
-    (bottom row, top row, right column, left column, corners BR, BL, TR, TL) that tap t subtracts."""
+def _assembly_tables(device):
+    """E[t,t'] = index of d = t' - t in ALL25; half_of / flip: R_d from the 13 stored matrices (R_-d = R_d^T)."""
     def build():
         E = torch.tensor([[ALL25.index((t2 // 3 - t1 // 3, t2 % 3 - t1 % 3)) for t2 in range(9)] for t1 in range(9)], device=device)
-        Mk = torch.zeros(9, 8, dtype=torch.float64)
-        for t in range(9):
-            ty, tx = t // 3, t % 3
-            # tap t reads u = p + t - 1: over all p it misses the LAST row when ty == 0, the FIRST row when ty == 2 (same for columns)
-            Mk[t, 0] = ty == 0; Mk[t, 1] = ty == 2; Mk[t, 2] = tx == 0; Mk[t, 3] = tx == 2
-            Mk[t, 4] = -(ty == 0 and tx == 0); Mk[t, 5] = -(ty == 0 and tx == 2)
-            Mk[t, 6] = -(ty == 2 and tx == 0); Mk[t, 7] = -(ty == 2 and tx == 2)
         half_of = torch.tensor([HALF.index(d) if d in HALF else HALF.index((-d[0], -d[1])) for d in ALL25], device=device)
         flip = torch.tensor([d not in HALF for d in ALL25], device=device)
-        return E, Mk.to(device), half_of, flip
+        return E, half_of, flip
     return _const(("tables", str(device)), build)
 
 
@@ -209,48 +219,21 @@ def patch_moments(x, positions=None):
     """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above); with `positions`
     (B, n) also the 3x3 patches at those cells (B, 9C, n) from the same node, else None as third value."""
     mode = os.environ.get("DCD_TRUNK_GRAM", "auto")
-    # auto: the autocorrelation form pays from ~100k pixels per rank on (its border terms are ~60 small launches: at one
-    # 96x320 image per rank the step is launch-bound and the single bmm is 1 ms faster; at eight images it is 1.7 ms slower)
-    small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 100000
+    # auto: the autocorrelation form pays from two 96x320 images per rank on (17.2 vs 17.8 ms per step; one image: 13.8 either
+    # way -- with the border terms as ~60 small launches, rounds 2-3, the threshold was 100k pixels)
+    small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 40000
     if mode == "bmm" or (mode == "auto" and small) or x.shape[2] < 5 or x.shape[3] < 5:
         return patch_moments_gram(x) + (None,)
     B, C, H, W = x.shape
     res = _ShiftCorr.apply(x, positions)
-    R13, total, T, Bt, Lb, Rb = res[:6]
-    P = res[6] if positions is not None else None
-    E, Mk, half_of, flip = _border_tables(x.device)
+    R13, total, ring = res[:3]
+    P = res[3] if positions is not None else None
+    E, half_of, flip = _assembly_tables(x.device)
     R25 = R13[half_of]
     R25 = torch.where(flip.view(25, 1, 1), R25.transpose(1, 2), R25)                           # R_-d = R_d^T
-    T, Bt, Lb, Rb = T.double(), Bt.double(), Lb.double(), Rb.double()
-
-    # Border terms, two bands per call: the bottom / right band is mirrored so that its strip line sits at index 0 like the
-    # top / left band's (a mirrored axis turns d into -d along it: the result is mirrored back).
-    rows = torch.stack((T, Bt.flip(2)))                                                         # (2,B,C,3,W), strip row = index 0
-    nbr = F.pad(rows, (2, 2, 2, 0))                                                             # rows -2..2 around the strip row
-    # (one index per tensor and `unbind` for pairs: every separate integer index is a zero-filled tensor, a copy and an
-    # accumulation in the backward)
-    strip_rows = rows[:, :, :, 0, :]                                                            # (2,B,C,W)
-    row_t = torch.einsum('sbcx,sbkijx->sijck', strip_rows, nbr.unfold(4, W, 1))                 # (2,5,5,C,C): [band, dy, dx]
-    cols = torch.stack((Lb, Rb.flip(3)))                                                        # (2,B,C,H,3), strip column = index 0
-    nbc = F.pad(cols, (2, 0, 2, 2))
-    col_t = torch.einsum('sbcy,sbkijy->sijck', cols[:, :, :, :, 0], nbc.unfold(3, H, 1))        # (2,5(dy),5(dx),C,C)
-    # corners: the strip row's first / last pixel against its 5x5 neighbourhood
-    cor_l = torch.einsum('sbc,sbkij->sijck', strip_rows[..., 0], nbr[..., 0:5])                 # column 0:    (top-left, bottom-left)
-    cor_r = torch.einsum('sbc,sbkij->sijck', strip_rows[..., W - 1], nbr[..., W - 1:W + 4])     # column W-1:  (top-right, bottom-right)
-    top_row, bot_row = row_t.unbind(0)
-    left_col, right_col = col_t.unbind(0)
-    cor_l_top, cor_l_bot = cor_l.unbind(0)
-    cor_r_top, cor_r_bot = cor_r.unbind(0)
-    strips = torch.stack((bot_row.flip(0), top_row, right_col.flip(1), left_col, cor_r_bot.flip(0), cor_l_bot.flip(0), cor_r_top,
-                          cor_l_top)).reshape(8, 25, C, C)
-    corr = (Mk @ strips.view(8, -1)).view(9, 25, C, C)
-    Gt = (R25.unsqueeze(0) - corr)[torch.arange(9, device=x.device).view(9, 1), E]            # (9, 9, C, C): [t, t', c, c']
-    G = Gt.permute(2, 0, 3, 1).reshape(9 * C, 9 * C)
-    # S1[c,t] = sum over u in the image minus the row / column tap t never reads (+ the corner counted twice)
-    bot_line, top_line = Bt[:, :, 2, :].sum(0), T[:, :, 0, :].sum(0)                            # (C, W): outermost rows, summed over the batch
-    sums = torch.stack((bot_line.sum(1), top_line.sum(1), Rb[:, :, :, 2].sum((0, 2)), Lb[:, :, :, 0].sum((0, 2)),
-                        bot_line[:, W - 1], bot_line[:, 0], top_line[:, W - 1], top_line[:, 0]))                            # (8, C)
-    S1 = (total.view(1, C) - Mk @ sums).t().reshape(9 * C)
+    G_ext = R25[E].permute(2, 0, 3, 1).reshape(9 * C, 9 * C)                                   # [t, t', c, c'] -> [(c,t), (c',t')]
+    G = G_ext - _Gram.apply(ring)
+    S1 = total.view(C, 1).expand(C, 9).reshape(9 * C) - ring.sum(2).double().sum(0)
     return S1, G, P
 
 

@@ -18,16 +18,23 @@ def test_shift_correlations_match_host_float64(cuda, shape):
         xi = x.to(dev, dt).requires_grad_(True)
         pos = torch.randint(0, H * W, (B, 37), generator=torch.Generator().manual_seed(9))
         pos[:, 0], pos[:, 1], pos[:, 2] = 0, H * W - 1, W - 1                    # corners: the zero padding is read
-        R, total, T, Bt, L, Rr, P = TM._ShiftCorr.apply(xi, pos.to(dev))
+        R, total, ring, P = TM._ShiftCorr.apply(xi, pos.to(dev))
+        assert ring.shape == (B, 9 * C, 2 * (W + 2) + 2 * H)                    # patches of the ring around the image (border correction)
         g = torch.Generator().manual_seed(5)
         wR = torch.randn(R.shape, generator=g, dtype=torch.float64).to(dev)
         wt = torch.randn(total.shape, generator=g, dtype=torch.float64).to(dev)
-        wb = [torch.randn(t.shape, generator=g).to(dev, dt) for t in (T, Bt, L, Rr)]
+        wr = torch.randn(ring.shape, generator=g).to(dev, dt)
         wP = torch.randn(P.shape, generator=g).to(dev, dt)
-        loss = (R * wR).sum() + (total * wt).sum() + sum((t * w_).sum().double() for t, w_ in zip((T, Bt, L, Rr), wb)) + (P * wP).sum().double()
+        loss = (R * wR).sum() + (total * wt).sum() + (ring * wr).sum().double() + (P * wP).sum().double()
         loss.backward()
-        outs.append((R.detach().cpu().double(), total.detach().cpu().double(), xi.grad.detach().cpu().double(), P.detach().cpu().double()))
-    (R0, t0, g0, P0), (R1, t1, g1, P1) = outs
+        outs.append((R.detach().cpu().double(), total.detach().cpu().double(), xi.grad.detach().cpu().double(), P.detach().cpu().double(),
+                     ring.detach().cpu().double()))
+    (R0, t0, g0, P0, r0), (R1, t1, g1, P1, r1) = outs
+    assert (r0 - r1).abs().max().item() <= 1e-6 * max(r1.abs().max().item(), 1.0)
+    # the ring's patches, independently: pixel (-1, -1) sees only x[0, 0] (at tap (2, 2)), pixel (H, W) only x[H-1, W-1] (tap (0, 0))
+    corner = r1.view(B, C, 9, -1)
+    assert torch.allclose(corner[:, :, 8, 0], x[:, :, 0, 0].double(), atol=1e-6) and float(corner[:, :, :8, 0].abs().max()) == 0.0
+    assert torch.allclose(corner[:, :, 0, 2 * (W + 2) - 1], x[:, :, H - 1, W - 1].double(), atol=1e-6)
     assert (P0 - P1).abs().max().item() <= 1e-6 * max(P1.abs().max().item(), 1.0)     # gathered patches (fp32 copy of the input)
     n = B * H * W
     assert (R0 - R1).abs().max().item() <= 2e-6 * n ** 0.5 * max(R1.abs().max().item() / n ** 0.5, 1.0)
