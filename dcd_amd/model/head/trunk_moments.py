@@ -274,7 +274,10 @@ def trunks_at(x, trunks, centers, extra=None, stacked=False):
     K = S1.shape[0]
     Wall = torch.stack([t[0].weight.reshape(t[0].out_channels, K) for t in trunks])            # (T, O, 9C)
     Wd = Wall.double()
-    sums = torch.stack((Wd @ S1, ((Wd @ G) * Wd).sum(-1)), dim=-1)                              # (T, O, 2): sum y, sum y^2
+    # sum y = W S1 and sum y^2 = diag(W G W^T) from ONE product W [G | S1] (S1 as a 577th column: the separate fp64 matrix-vector
+    # product was a 100 us rocBLAS gemv, and another in the backward)
+    WG = Wd.reshape(-1, K) @ torch.cat((G, S1.unsqueeze(1)), dim=1)                            # (T O, K + 1)
+    sums = torch.stack((WG[:, K], (WG[:, :K] * Wd.reshape(-1, K)).sum(-1)), dim=-1).view(len(trunks), -1, 2)   # (T, O, 2): sum y, sum y^2
     n = B * H * W
     group = trunks[0][1].sync_group
     if group is not None:
