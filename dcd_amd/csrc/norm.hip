@@ -572,6 +572,73 @@ inline int sync_slices(const Plane &g)
     return (long)g.B * g.HW <= 32768 ? 1 : slices(g);
 }
 
+// ---- batch-norm parameters of the head's regression trunks from the Gram form (model/head/trunk_moments.py) --------------------
+// Row r = (trunk, output channel), K = 9 Cin.  WG (R, K + 1) = W [G | S1] in fp64 (one library product), Wd (R, K) the weights in
+// fp64:  sum y = WG[r][K],  sum y^2 = sum_k WG[r][k] Wd[r][k].  Rounds 2-4 wrote what follows as ~30 small fp64 tensor
+// operations and let autograd derive ~50 more for the backward; here: row sums, finalisation and their backward as four kernels.
+__global__ __launch_bounds__(64) void trunk_row_sums(const double *__restrict__ WG, const double *__restrict__ Wd, int K,
+                                                     double *__restrict__ sums)
+{
+    const int r = blockIdx.x;
+    double a = 0.0;
+    for (int k = threadIdx.x; k < K; k += 64) a += WG[(long)r * (K + 1) + k] * Wd[(long)r * K + k];
+    a = wave_sum(a);
+    if (threadIdx.x == 0) {
+        sums[2 * r] = WG[(long)r * (K + 1) + K];
+        sums[2 * r + 1] = a;
+    }
+}
+
+// stats (R, 3) fp64 = (mean, biased variance after the clamp at 0, 1 / sqrt(var + eps)); scale = gamma invstd, shift = beta - mean scale
+__global__ __launch_bounds__(256) void trunk_finalize_fwd(const double *__restrict__ sums, const float *__restrict__ gamma,
+                                                          const float *__restrict__ beta, double n, double eps, int R,
+                                                          float *__restrict__ scale, float *__restrict__ shift, double *__restrict__ stats)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double mean = sums[2 * r] / n;
+    const double raw = sums[2 * r + 1] / n - mean * mean;
+    const double var = raw > 0.0 ? raw : 0.0;
+    const double invstd = 1.0 / sqrt(var + eps);
+    const double sc = (double)gamma[r] * invstd;
+    scale[r] = (float)sc;
+    shift[r] = (float)((double)beta[r] - mean * sc);
+    stats[3 * r] = mean;
+    stats[3 * r + 1] = var;
+    stats[3 * r + 2] = invstd;
+}
+
+// (dscale, dshift) -> d sums (R, 2) fp64, dgamma, dbeta.  raw variance <= 0 (clamped): no gradient through the variance.
+__global__ __launch_bounds__(256) void trunk_finalize_bwd(const float *__restrict__ dscale, const float *__restrict__ dshift,
+                                                          const float *__restrict__ gamma, const double *__restrict__ stats, double n, int R,
+                                                          double *__restrict__ dsums, float *__restrict__ dgamma, float *__restrict__ dbeta)
+{
+    const int r = blockIdx.x * blockDim.x + threadIdx.x;
+    if (r >= R) return;
+    const double mean = stats[3 * r], var = stats[3 * r + 1], invstd = stats[3 * r + 2];
+    const double ds = dscale[r], dh = dshift[r], g = gamma[r];
+    dgamma[r] = (float)((ds - dh * mean) * invstd);
+    dbeta[r] = (float)dh;
+    const double dinv = (ds - dh * mean) * g;
+    double dmean = -dh * g * invstd;
+    const double dvar = var > 0.0 ? dinv * -0.5 * invstd * invstd * invstd : 0.0;
+    dmean += dvar * -2.0 * mean;
+    dsums[2 * r] = dmean / n;
+    dsums[2 * r + 1] = dvar / n;
+}
+
+// dWG (R, K + 1): columns k < K = d(sum y^2) Wd[r][k], column K = d(sum y)
+__global__ __launch_bounds__(256) void trunk_dwg(const double *__restrict__ dsums, const double *__restrict__ Wd, int R, int K,
+                                                 double *__restrict__ dWG)
+{
+    const long n = (long)R * (K + 1);
+    for (long i = (long)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (long)gridDim.x * blockDim.x) {
+        const long r = i / (K + 1);
+        const int k = (int)(i - r * (K + 1));
+        dWG[i] = k < K ? dsums[2 * r + 1] * Wd[r * K + k] : dsums[2 * r];
+    }
+}
+
 inline bool bad_shape(int B, int C, long HW) { return B <= 0 || C <= 0 || HW <= 0 || C > 65535 || (double)B * ((HW + CH - 1) / CH) > 2.0e9; }
 
 }  // namespace
@@ -785,6 +852,45 @@ int dcd_bn_at_backward_sums(void *stream_, const float *grad_at, const float *x_
     if (!grad_at || !x_at || !y_at || !save_mean || !save_invstd || !sums || !dzk || total <= 0 || C <= 0) return DCD_ERR_BAD_ARG;
     hipLaunchKernelGGL(bn_at_backward_sums, dim3(C), dim3(BT), 0, stream, grad_at, x_at, y_at, weight, save_mean, save_invstd, relu,
                        total, C, sums, dzk);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_trunk_row_sums(void *stream_, const double *WG, const double *Wd, int R, int K, double *sums)
+{
+    (void)hipGetLastError();
+    if (!WG || !Wd || !sums || R <= 0 || K <= 0) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(trunk_row_sums, dim3(R), dim3(64), 0, (hipStream_t)stream_, WG, Wd, K, sums);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_trunk_finalize_forward(void *stream_, const double *sums, const float *gamma, const float *beta, double count, double eps, int R,
+                               float *scale, float *shift, double *stats)
+{
+    (void)hipGetLastError();
+    if (!sums || !gamma || !beta || !scale || !shift || !stats || R <= 0 || !(count >= 1.0)) return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(trunk_finalize_fwd, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream_, sums, gamma, beta, count, eps, R, scale,
+                       shift, stats);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_trunk_finalize_backward(void *stream_, const float *grad_scale, const float *grad_shift, const float *gamma, const double *stats,
+                                double count, int R, double *grad_sums, float *grad_gamma, float *grad_beta)
+{
+    (void)hipGetLastError();
+    if (!grad_scale || !grad_shift || !gamma || !stats || !grad_sums || !grad_gamma || !grad_beta || R <= 0 || !(count >= 1.0))
+        return DCD_ERR_BAD_ARG;
+    hipLaunchKernelGGL(trunk_finalize_bwd, dim3((R + 255) / 256), dim3(256), 0, (hipStream_t)stream_, grad_scale, grad_shift, gamma, stats,
+                       count, R, grad_sums, grad_gamma, grad_beta);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_trunk_grad_wg(void *stream_, const double *grad_sums, const double *Wd, int R, int K, double *grad_WG)
+{
+    (void)hipGetLastError();
+    if (!grad_sums || !Wd || !grad_WG || R <= 0 || K <= 0) return DCD_ERR_BAD_ARG;
+    const long n = (long)R * (K + 1);
+    hipLaunchKernelGGL(trunk_dwg, dim3((unsigned)((n + 255) / 256 < 2048 ? (n + 255) / 256 : 2048)), dim3(256), 0, (hipStream_t)stream_,
+                       grad_sums, Wd, R, K, grad_WG);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -262,6 +262,74 @@ def _taps(W, device):
     return _TAPS[key]
 
 
+_FUSED_STATS = os.environ.get("DCD_TRUNK_STATS_KERNELS", "1") != "0"       # 0: the finalisation as tensor operations (A/B timing)
+
+
+class _TrunkScaleShift(torch.autograd.Function):
+    """(Wall (T,O,K) fp32, S1 (K) fp64, G (K,K) fp64, gamma (T,O), beta (T,O)) -> scale, shift (T,O) fp32 of the trunks' training
+    BatchNorm, and -- not differentiable -- mean, biased variance (T,O) fp64 for the running estimates.  Device tensors only:
+    one fp64 library product W [G | S1] and two small kernels forward (row sums, finalisation: csrc/norm.hip), two kernels and two
+    products backward, with the all-reduce of the per-channel sums (and of their gradients) in between under SyncBN.  The
+    same mathematics as the tensor-operation form in `trunks_at` (which the host-logic tests run in fp64): ~30 small launches
+    forward and ~50 in autograd's backward became 6 + 7."""
+
+    @staticmethod
+    def forward(ctx, Wall, S1, G, gamma, beta, n_local, eps, group):
+        from dcd_amd import _lib
+        L = _lib.lib()
+        T, O, K = Wall.shape
+        R = T * O
+        dev = Wall.device
+        st = _lib.stream_of(Wall)
+        Wd = Wall.reshape(R, K).double()
+        GS = torch.cat((G, S1.unsqueeze(1)), dim=1)                                             # (K, K + 1)
+        WG = Wd @ GS                                                                            # (R, K + 1)
+        sums = torch.empty((R, 2), dtype=torch.float64, device=dev)
+        _lib.check(L.dcd_trunk_row_sums(st, WG.data_ptr(), Wd.data_ptr(), R, K, sums.data_ptr()), "dcd_trunk_row_sums")
+        n = float(n_local)
+        if group is not None:
+            import torch.distributed as dist
+            dist.all_reduce(sums, group=group)
+            n *= dist.get_world_size(group)
+        gamma, beta = gamma.reshape(R).float().contiguous(), beta.reshape(R).float().contiguous()
+        scale = torch.empty(R, dtype=torch.float32, device=dev)
+        shift = torch.empty(R, dtype=torch.float32, device=dev)
+        stats = torch.empty((R, 3), dtype=torch.float64, device=dev)
+        _lib.check(L.dcd_trunk_finalize_forward(st, sums.data_ptr(), gamma.data_ptr(), beta.data_ptr(), n, float(eps), R, scale.data_ptr(),
+                                                shift.data_ptr(), stats.data_ptr()), "dcd_trunk_finalize_forward")
+        ctx.save_for_backward(Wd, GS, WG, gamma, stats)
+        ctx.geom, ctx.n, ctx.group = (T, O, K), n, group
+        mean, var = stats[:, 0].reshape(T, O), stats[:, 1].reshape(T, O)
+        ctx.mark_non_differentiable(mean, var)
+        return scale.view(T, O), shift.view(T, O), mean, var
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, dscale, dshift, _dmean, _dvar):
+        from dcd_amd import _lib
+        L = _lib.lib()
+        Wd, GS, WG, gamma, stats = ctx.saved_tensors
+        T, O, K = ctx.geom
+        R = T * O
+        dev = Wd.device
+        st = _lib.stream_of(Wd)
+        dscale, dshift = dscale.reshape(R).float().contiguous(), dshift.reshape(R).float().contiguous()
+        dsums = torch.empty((R, 2), dtype=torch.float64, device=dev)
+        dgamma = torch.empty(R, dtype=torch.float32, device=dev)
+        dbeta = torch.empty(R, dtype=torch.float32, device=dev)
+        _lib.check(L.dcd_trunk_finalize_backward(st, dscale.data_ptr(), dshift.data_ptr(), gamma.data_ptr(), stats.data_ptr(), ctx.n, R,
+                                                 dsums.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()), "dcd_trunk_finalize_backward")
+        if ctx.group is not None:                     # the forward summed the ranks' sums: every rank's sums feel every rank's gradient
+            import torch.distributed as dist
+            dist.all_reduce(dsums, group=ctx.group)
+        dWG = torch.empty((R, K + 1), dtype=torch.float64, device=dev)
+        _lib.check(L.dcd_trunk_grad_wg(st, dsums.data_ptr(), Wd.data_ptr(), R, K, dWG.data_ptr()), "dcd_trunk_grad_wg")
+        # sum y^2 = sum_k WG[r][k] Wd[r][k] depends on Wd twice: through the product and directly
+        dWd = torch.addcmul(dWG @ GS.t(), dsums[:, 1:2], WG[:, :K])
+        dGS = Wd.t() @ dWG                                                                      # (K, K + 1)
+        return dWd.float().view(T, O, K), dGS[:, K], dGS[:, :K], dgamma.view(T, O), dbeta.view(T, O), None, None, None
+
+
 def trunks_at(x, trunks, centers, extra=None, stacked=False):
     """BN + ReLU outputs of every trunk at `centers` (B, M) linear pixel indices -> list of (B, M, Cout); `extra` = (trunk index,
     positions (B, Ke)) appends that trunk's outputs at further positions (the border cells of the edge-fusion branch).  Updates the
@@ -273,26 +341,33 @@ def trunks_at(x, trunks, centers, extra=None, stacked=False):
     S1, G, P_all = patch_moments(x, pos_all if os.environ.get("DCD_TRUNK_PATCH_NODE", "1") != "0" else None)   # 0: separate gather (A/B)
     K = S1.shape[0]
     Wall = torch.stack([t[0].weight.reshape(t[0].out_channels, K) for t in trunks])            # (T, O, 9C)
-    Wd = Wall.double()
-    # sum y = W S1 and sum y^2 = diag(W G W^T) from ONE product W [G | S1] (S1 as a 577th column: the separate fp64 matrix-vector
-    # product was a 100 us rocBLAS gemv, and another in the backward)
-    WG = Wd.reshape(-1, K) @ torch.cat((G, S1.unsqueeze(1)), dim=1)                            # (T O, K + 1)
-    sums = torch.stack((WG[:, K], (WG[:, :K] * Wd.reshape(-1, K)).sum(-1)), dim=-1).view(len(trunks), -1, 2)   # (T, O, 2): sum y, sum y^2
     n = B * H * W
     group = trunks[0][1].sync_group
-    if group is not None:
-        import torch.distributed as dist
-        import torch.distributed.nn.functional as distf
-        sums = distf.all_reduce(sums, group=group)
-        n = n * dist.get_world_size(group)
-    sum_y, sum_yy = sums.unbind(-1)
-    mean = sum_y / n
-    var = (sum_yy / n - mean * mean).clamp_min(0)
-    gamma = torch.stack([t[1].weight for t in trunks]).double()
-    beta = torch.stack([t[1].bias for t in trunks]).double()
     eps = trunks[0][1].eps
-    scale = gamma * torch.rsqrt(var + eps)                                                     # (T, O) fp64
-    shift = beta - mean * scale
+    if _FUSED_STATS and x.is_cuda and Wall.dtype == torch.float32:
+        scale, shift, mean, var = _TrunkScaleShift.apply(Wall, S1, G, torch.stack([t[1].weight for t in trunks]),
+                                                         torch.stack([t[1].bias for t in trunks]), n, eps, group)
+        if group is not None:
+            import torch.distributed as dist
+            n = n * dist.get_world_size(group)
+    else:
+        Wd = Wall.double()
+        # sum y = W S1 and sum y^2 = diag(W G W^T) from ONE product W [G | S1] (S1 as a 577th column: the separate fp64
+        # matrix-vector product was a 100 us rocBLAS gemv, and another in the backward)
+        WG = Wd.reshape(-1, K) @ torch.cat((G, S1.unsqueeze(1)), dim=1)                        # (T O, K + 1)
+        sums = torch.stack((WG[:, K], (WG[:, :K] * Wd.reshape(-1, K)).sum(-1)), dim=-1).view(len(trunks), -1, 2)   # (T, O, 2): sum y, sum y^2
+        if group is not None:
+            import torch.distributed as dist
+            import torch.distributed.nn.functional as distf
+            sums = distf.all_reduce(sums, group=group)
+            n = n * dist.get_world_size(group)
+        sum_y, sum_yy = sums.unbind(-1)
+        mean = sum_y / n
+        var = (sum_yy / n - mean * mean).clamp_min(0)
+        gamma = torch.stack([t[1].weight for t in trunks]).double()
+        beta = torch.stack([t[1].bias for t in trunks]).double()
+        scale = gamma * torch.rsqrt(var + eps)                                                 # (T, O) fp64
+        shift = beta - mean * scale
     with torch.no_grad():
         unbiased = var * (n / max(n - 1, 1))
         bns = [t[1] for t in trunks]

@@ -358,6 +358,21 @@ int dcd_bn_backward_apply(void *stream, const float *grad_y, const float *y, con
                           const float *save_mean, const float *save_invstd, const double *sums, double count,
                           float *grad_x, float *grad_residual, float *grad_weight, float *grad_bias, int B, int C,
                           int64_t HW);
+/* Batch-norm parameters of the head's regression trunks from the Gram form (model/head/trunk_moments.py; the reference runs the
+ * eleven dense conv + BatchNorm2d trunks, DGDE/model/head/detector_predictor.py:78-101).  Row r = (trunk, output channel), R rows,
+ * K = 9 Cin.  WG (R, K + 1) = W [G | S1] and Wd (R, K) = W, both fp64.
+ *   row_sums:           sums (R, 2) = (sum y, sum y^2) = (WG[r][K], sum_k WG[r][k] Wd[r][k])   [all-reduced by the caller under SyncBN]
+ *   finalize_forward:   stats (R, 3) = (mean, biased variance clamped at 0, 1 / sqrt(var + eps)); scale = gamma / sqrt(var + eps),
+ *                       shift = beta - mean * scale (fp32)
+ *   finalize_backward:  (grad_scale, grad_shift) -> grad_sums (R, 2) fp64, grad_gamma, grad_beta
+ *   grad_wg:            grad_WG (R, K + 1): columns k < K = grad_sums[r][1] * Wd[r][k], column K = grad_sums[r][0] */
+int dcd_trunk_row_sums(void *stream, const double *WG, const double *Wd, int R, int K, double *sums);
+int dcd_trunk_finalize_forward(void *stream, const double *sums, const float *gamma, const float *beta, double count, double eps, int R,
+                               float *scale, float *shift, double *stats);
+int dcd_trunk_finalize_backward(void *stream, const float *grad_scale, const float *grad_shift, const float *gamma, const double *stats,
+                                double count, int R, double *grad_sums, float *grad_gamma, float *grad_beta);
+int dcd_trunk_grad_wg(void *stream, const double *grad_sums, const double *Wd, int R, int K, double *grad_WG);
+
 /* BN (+ReLU), training mode, evaluated at listed positions only (the regression-head trunks: the loss reads their output at
  * the object centres and, for one head, the border cells).  pos (B,N) int64 linear pixel indices; x_at, y_at (B,N,C).
  * stats NULL: statistics computed here (workspace needed); else the C x 2 combined (all-reduced) sums with the global count.

@@ -77,3 +77,44 @@ def test_batch_variance_error_with_a_dc_component(cuda, monkeypatch, shift, boun
     var = ((Wd @ G) * Wd).sum(-1) / n - mean * mean
     rel = ((var - var_ref).abs() / var_ref).max().item()
     assert rel <= bound, (shift, rel)
+
+
+def test_fused_scale_shift_node_equals_tensor_operation_form(cuda, monkeypatch):
+    """`_TrunkScaleShift` (one fp64 product + the finalisation kernels of csrc/norm.hip, hand-written backward) against the same
+    statistics written as tensor operations with autograd's backward: trunk outputs at the positions, gradients of the input, of
+    every trunk's convolution weight and BatchNorm weight / bias, and the running estimates."""
+    from torch import nn
+    from dcd_amd.model.head import trunk_moments as TM
+    from dcd_amd.model.layers.norm import BatchNorm2d
+    torch.manual_seed(4)
+    B, C, H, W, O, T = 2, 64, 24, 40, 32, 3
+    monkeypatch.setenv("DCD_TRUNK_GRAM", "shift")
+    x0 = torch.relu(torch.randn(B, C, H, W, device=cuda))
+    centers = torch.randint(0, H * W, (B, 7), device=cuda)
+    wts = [torch.randn(B, 7, O, device=cuda) for _ in range(T)]
+    res = []
+    for fused in (True, False):
+        monkeypatch.setattr(TM, "_FUSED_STATS", fused)
+        torch.manual_seed(9)
+        trunks = nn.ModuleList([nn.Sequential(nn.Conv2d(C, O, 3, padding=1, bias=False), BatchNorm2d(O, fuse_relu=True), nn.Identity())
+                                for _ in range(T)]).to(cuda).train()
+        for t in trunks:
+            nn.init.uniform_(t[1].weight, 0.5, 1.5)
+            nn.init.uniform_(t[1].bias, -0.5, 0.5)
+        x = x0.clone().requires_grad_()
+        outs = TM.trunks_at(x, trunks, centers)
+        sum((o * w).sum() for o, w in zip(outs, wts)).backward()
+        res.append(([o.detach().double() for o in outs], x.grad.double(), [p.grad.double() for p in trunks.parameters()],
+                    [t[1].running_mean.double() for t in trunks], [t[1].running_var.double() for t in trunks]))
+    (o0, gx0, gp0, rm0, rv0), (o1, gx1, gp1, rm1, rv1) = res
+
+    def close(a, b, tol, what):
+        err = (a - b).abs().max().item()
+        assert err <= tol * max(b.abs().max().item(), 1e-6), (what, err, b.abs().max().item())
+    for a, b in zip(o0, o1):
+        close(a, b, 1e-5, "outputs")
+    close(gx0, gx1, 1e-4, "grad_input")
+    for a, b in zip(gp0, gp1):
+        close(a, b, 1e-4, "parameter gradient")
+    for a, b in zip(rm0 + rv0, rm1 + rv1):
+        close(a, b, 1e-6, "running estimate")
