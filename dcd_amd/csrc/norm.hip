@@ -30,6 +30,10 @@ __device__ inline double wave_sum(double v)
     return v;
 }
 
+// shift of y = x * scale + shift: ONE spelling for the forward kernels and for the backward kernels that recompute the ReLU mask
+// from x (an explicit fma: the compiler's own contraction could differ from kernel to kernel)
+__device__ inline float bn_shift(float bias, float mean, float scale) { return fmaf(-mean, scale, bias); }
+
 // Block-wide sum of two doubles; result valid in thread 0.
 __device__ inline void block_sum2(double &a, double &b)
 {
@@ -225,7 +229,7 @@ __global__ __launch_bounds__(BT) void bn_apply(const float *__restrict__ x, cons
         invstd = 1.f / sqrtf(running_var[c] + eps);
     }
     const float scale = invstd * (weight ? weight[c] : 1.f);
-    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+    const float shift = bn_shift(bias ? bias[c] : 0.f, mean, scale);
     const long base = ((long)b * g.C + c) * g.HW;
     const long lo = (long)k * CH, hi = min(g.HW, lo + CH);
     if ((g.HW & 3) == 0) {
@@ -257,12 +261,17 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ d
                                                      const float *__restrict__ x, const float *__restrict__ save_mean,
                                                      Plane g, int S, double *__restrict__ partial,
                                                      const float *__restrict__ invstd = nullptr, float *__restrict__ gw = nullptr,
-                                                     float *__restrict__ gb = nullptr)
+                                                     float *__restrict__ gb = nullptr, const float *__restrict__ mask_weight = nullptr,
+                                                     const float *__restrict__ mask_bias = nullptr, int mask_from_x = 0)
 {
+    // mask_from_x (ReLU fused, no residual): y > 0  <=>  fma(x, scale, shift) > 0 with the forward's own scale / shift -- the
+    // output map is not read at all (one of the kernel's three tensor reads)
     const int c = blockIdx.y, s = blockIdx.x;
     const int P = g.B * g.cpp;
     const bool vec = (g.HW & 3) == 0;
     const float mean = save_mean[c];
+    const float msc = mask_from_x ? invstd[c] * (mask_weight ? mask_weight[c] : 1.f) : 0.f;
+    const float msh = mask_from_x ? bn_shift(mask_bias ? mask_bias[c] : 0.f, mean, msc) : 0.f;
     double d0 = 0.0, d1 = 0.0;
     for (int j = s; j < P; j += S) {
         const int b = j / g.cpp, k = j - b * g.cpp;
@@ -273,7 +282,10 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ d
             for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
                 float4 d = *reinterpret_cast<const float4 *>(dy + base + i);
                 const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
-                if (y) {
+                if (mask_from_x) {
+                    d.x = fmaf(v.x, msc, msh) <= 0.f ? 0.f : d.x; d.y = fmaf(v.y, msc, msh) <= 0.f ? 0.f : d.y;
+                    d.z = fmaf(v.z, msc, msh) <= 0.f ? 0.f : d.z; d.w = fmaf(v.w, msc, msh) <= 0.f ? 0.f : d.w;
+                } else if (y) {
                     const float4 o = *reinterpret_cast<const float4 *>(y + base + i);
                     d.x = o.x <= 0.f ? 0.f : d.x; d.y = o.y <= 0.f ? 0.f : d.y;
                     d.z = o.z <= 0.f ? 0.f : d.z; d.w = o.w <= 0.f ? 0.f : d.w;
@@ -284,7 +296,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_partial(const float *__restrict__ d
         } else {
             for (long i = lo + threadIdx.x; i < hi; i += BT) {
                 float d = dy[base + i];
-                if (y) d = y[base + i] <= 0.f ? 0.f : d;
+                if (mask_from_x) d = fmaf(x[base + i], msc, msh) <= 0.f ? 0.f : d;
+                else if (y) d = y[base + i] <= 0.f ? 0.f : d;
                 f0 += d;
                 f1 = fmaf(d, x[base + i] - mean, f1);
             }
@@ -308,11 +321,14 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
                                                    const double *__restrict__ sums, const double *__restrict__ partial, int S,
                                                    double count, float *__restrict__ dx,
                                                    float *__restrict__ dres, float *__restrict__ dweight,
-                                                   float *__restrict__ dbias, Plane g)
+                                                   float *__restrict__ dbias, Plane g, const float *__restrict__ mask_bias = nullptr,
+                                                   int mask_from_x = 0)
 {
     const int c = blockIdx.y;
     const int b = blockIdx.x / g.cpp, k = blockIdx.x - b * g.cpp;
     const float mean = save_mean[c], invstd = save_invstd[c];
+    const float msc = invstd * (weight ? weight[c] : 1.f);
+    const float msh = bn_shift(mask_bias ? mask_bias[c] : 0.f, mean, msc);
     double s0, s1;
     channel_sums(sums, partial, S, c, s0, s1);
     if (blockIdx.x == 0 && threadIdx.x == 0) {
@@ -328,7 +344,10 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
         for (long i = lo + 4 * threadIdx.x; i < hi; i += 4 * BT) {
             float4 d = dy ? *reinterpret_cast<const float4 *>(dy + base + i) : make_float4(0.f, 0.f, 0.f, 0.f);
             const float4 v = *reinterpret_cast<const float4 *>(x + base + i);
-            if (y) {
+            if (mask_from_x) {
+                d.x = fmaf(v.x, msc, msh) <= 0.f ? 0.f : d.x; d.y = fmaf(v.y, msc, msh) <= 0.f ? 0.f : d.y;
+                d.z = fmaf(v.z, msc, msh) <= 0.f ? 0.f : d.z; d.w = fmaf(v.w, msc, msh) <= 0.f ? 0.f : d.w;
+            } else if (y) {
                 const float4 o = *reinterpret_cast<const float4 *>(y + base + i);
                 d.x = o.x <= 0.f ? 0.f : d.x; d.y = o.y <= 0.f ? 0.f : d.y;
                 d.z = o.z <= 0.f ? 0.f : d.z; d.w = o.w <= 0.f ? 0.f : d.w;
@@ -342,7 +361,8 @@ __global__ __launch_bounds__(BT) void bn_bwd_apply(const float *__restrict__ dy,
     } else {
         for (long i = lo + threadIdx.x; i < hi; i += BT) {
             float d = dy ? dy[base + i] : 0.f;
-            if (y) d = y[base + i] <= 0.f ? 0.f : d;
+            if (mask_from_x) d = fmaf(x[base + i], msc, msh) <= 0.f ? 0.f : d;
+            else if (y) d = y[base + i] <= 0.f ? 0.f : d;
             if (dres) dres[base + i] = d;
             dx[base + i] = (d - a - (x[base + i] - mean) * bq) * k1;
         }
@@ -409,7 +429,7 @@ __global__ __launch_bounds__(BT) void bn_small_fwd(const float *__restrict__ x, 
         if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
     }
     const float scale = invstd * (weight ? weight[c] : 1.f);
-    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+    const float shift = bn_shift(bias ? bias[c] : 0.f, mean, scale);
 #pragma unroll
     for (int j = 0; j < SM_V; ++j) {
         if (off[j] < 0) continue;
@@ -430,11 +450,14 @@ __global__ __launch_bounds__(BT) void bn_small_bwd(const float *__restrict__ dy,
                                                    const float *__restrict__ x, const float *__restrict__ weight,
                                                    const float *__restrict__ save_mean, const float *__restrict__ save_invstd,
                                                    float *__restrict__ dx, float *__restrict__ dres, float *__restrict__ dweight,
-                                                   float *__restrict__ dbias, int B, int C, int HW4)
+                                                   float *__restrict__ dbias, int B, int C, int HW4,
+                                                   const float *__restrict__ mask_bias = nullptr, int mask_from_x = 0)
 {
     const int c = blockIdx.x;
     const int total = B * HW4;
     const float mean = save_mean[c], invstd = save_invstd[c];
+    const float msc = invstd * (weight ? weight[c] : 1.f);
+    const float msh = bn_shift(mask_bias ? mask_bias[c] : 0.f, mean, msc);
     float4 d[SM_V], v[SM_V];
     long off[SM_V];
     double d0 = 0.0, d1 = 0.0;
@@ -448,7 +471,10 @@ __global__ __launch_bounds__(BT) void bn_small_bwd(const float *__restrict__ dy,
             off[j] = ((long)b * C + c) * (4L * HW4) + 4L * q;
             d[j] = *reinterpret_cast<const float4 *>(dy + off[j]);
             v[j] = *reinterpret_cast<const float4 *>(x + off[j]);
-            if (y) {
+            if (mask_from_x) {
+                d[j].x = fmaf(v[j].x, msc, msh) <= 0.f ? 0.f : d[j].x; d[j].y = fmaf(v[j].y, msc, msh) <= 0.f ? 0.f : d[j].y;
+                d[j].z = fmaf(v[j].z, msc, msh) <= 0.f ? 0.f : d[j].z; d[j].w = fmaf(v[j].w, msc, msh) <= 0.f ? 0.f : d[j].w;
+            } else if (y) {
                 const float4 o = *reinterpret_cast<const float4 *>(y + off[j]);
                 d[j].x = o.x <= 0.f ? 0.f : d[j].x; d[j].y = o.y <= 0.f ? 0.f : d[j].y;
                 d[j].z = o.z <= 0.f ? 0.f : d[j].z; d[j].w = o.w <= 0.f ? 0.f : d[j].w;
@@ -514,7 +540,7 @@ __global__ __launch_bounds__(BT) void bn_at_forward(const float *__restrict__ x,
         if (num_batches_tracked && c == 0) *num_batches_tracked += 1;
     }
     const float scale = invstd * (weight ? weight[c] : 1.f);
-    const float shift = (bias ? bias[c] : 0.f) - mean * scale;
+    const float shift = bn_shift(bias ? bias[c] : 0.f, mean, scale);
     for (int e = threadIdx.x; e < B * N; e += BT) {
         const int b = e / N;
         const float v = x[((long)b * C + c) * HW + pos[e]];
@@ -813,6 +839,29 @@ int dcd_bn_backward(void *stream_, const float *grad_y, const float *y, const fl
     hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, y, x, weight, save_mean, save_invstd,
                        (const double *)nullptr, (const double *)ws, S, (double)B * (double)HW, grad_x, grad_residual, grad_weight,
                        grad_bias, g);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_bn_backward_relu_from_x(void *stream_, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                const float *save_mean, const float *save_invstd, float *grad_x, float *grad_weight, float *grad_bias,
+                                int B, int C, int64_t HW, void *ws, size_t ws_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !save_invstd || !grad_x || bad_shape(B, C, HW)) return DCD_ERR_BAD_ARG;
+    if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
+    if (small_channels(B, C, HW)) {
+        hipLaunchKernelGGL(bn_small_bwd, dim3(C), dim3(BT), 0, stream, grad_y, (const float *)nullptr, x, weight, save_mean, save_invstd,
+                           grad_x, (float *)nullptr, grad_weight, grad_bias, B, C, (int)(HW / 4), bias, 1);
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
+    const Plane g = make_plane(B, C, HW);
+    const int S = slices(g);
+    hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, (const float *)nullptr, x, save_mean, g, S, (double *)ws,
+                       save_invstd, (float *)nullptr, (float *)nullptr, weight, bias, 1);
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, (const float *)nullptr, x, weight, save_mean,
+                       save_invstd, (const double *)nullptr, (const double *)ws, S, (double)B * (double)HW, grad_x, (float *)nullptr,
+                       grad_weight, grad_bias, g, bias, 1);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

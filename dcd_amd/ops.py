@@ -624,6 +624,9 @@ def _bn_ws(C, dev):
     return torch.empty(_lib.lib().dcd_bn_workspace_bytes(C), dtype=torch.uint8, device=dev)
 
 
+_BN_MASK_FROM_X = os.environ.get("DCD_BN_MASK_FROM_X", "1") != "0"     # 0: the backward reads the forward output for the ReLU mask (A/B timing)
+
+
 class _BatchNormAct(torch.autograd.Function):
     """y = act(batch_norm(x) [+ residual]) on the HIP kernels of csrc/norm.hip (two launches forward, two backward;
     the stock chain is BN + add + ReLU = 3 kernels and 3 extra tensor round trips).  With `group` the per-channel fp64
@@ -659,7 +662,13 @@ class _BatchNormAct(torch.autograd.Function):
                                             count, _lib.ptr(running_mean), _lib.ptr(running_var), _lib.ptr(num_batches_tracked),
                                             float(momentum), float(eps), int(bool(relu)), y.data_ptr(), save_mean.data_ptr(),
                                             save_invstd.data_ptr(), B, C, HW), "dcd_bn_train_apply")
-        ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
+        # ReLU fused, no residual, local statistics: the backward recomputes the mask y > 0 from x (dcd_bn_backward_relu_from_x) and
+        # does not read y at all -- bias is kept instead of the output
+        ctx.mask_from_x = bool(relu) and residual is None and group is None and _BN_MASK_FROM_X
+        if ctx.mask_from_x:
+            ctx.save_for_backward(x, bias, weight, save_mean, save_invstd)
+        else:
+            ctx.save_for_backward(x, y if relu else None, weight, save_mean, save_invstd)
         ctx.count, ctx.group, ctx.has_res = count, group, residual is not None
         return y
 
@@ -674,6 +683,15 @@ class _BatchNormAct(torch.autograd.Function):
         dev, st = x.device, _lib.stream_of(x)
         ws = _bn_ws(C, dev)
         gx = torch.empty_like(x)
+        if ctx.mask_from_x:
+            bias = y                                   # (the second saved tensor is the bias on this path)
+            gw = torch.empty(C, dtype=torch.float32, device=dev)
+            gb = torch.empty(C, dtype=torch.float32, device=dev)
+            _lib.check(L.dcd_bn_backward_relu_from_x(st, gy.data_ptr(), x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), save_mean.data_ptr(),
+                                                     save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, C, HW,
+                                                     ws.data_ptr(), ws.numel()), "dcd_bn_backward_relu_from_x")
+            return (gx, None, gw if weight is not None else None, gb if weight is not None else None,
+                    None, None, None, None, None, None, None)
         want_res = ctx.has_res and ctx.needs_input_grad[1]
         gres = None
         if want_res:

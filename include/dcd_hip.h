@@ -348,6 +348,13 @@ int dcd_bn_eval_apply(void *stream, const float *x, const float *residual, const
                       int64_t HW);
 int dcd_bn_backward_stats(void *stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
                           int B, int C, int64_t HW, double *sums, void *workspace, size_t workspace_bytes);
+/* dcd_bn_backward for a layer with fused ReLU and NO residual that does not read the forward output: the ReLU mask y > 0 is
+ * recomputed as fma(x, scale, shift) > 0 from the saved statistics, weight and bias -- the forward's own expression -- so the
+ * backward reads two tensors (grad_y, x) per pass instead of three.  (The reference's nn.BatchNorm2d + F.relu keep and read the
+ * output, DGDE/model/backbone/dla_dcn.py:76-101.) */
+int dcd_bn_backward_relu_from_x(void *stream, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                const float *save_mean, const float *save_invstd, float *grad_x, float *grad_weight, float *grad_bias,
+                                int B, int C, int64_t HW, void *workspace, size_t workspace_bytes);
 /* dcd_bn_backward_stats that also writes THIS rank's parameter gradients from the same sums (grad_weight[c] = sum dz*(x-mean) *
  * invstd, grad_bias[c] = sum dz; either may be NULL): under data parallelism they stay local (DDP averages parameter gradients)
  * while `sums` is all-reduced for the input gradient -- torch.nn.SyncBatchNorm's backward, torch/nn/modules/_functions.py. */
