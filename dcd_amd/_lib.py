@@ -94,6 +94,8 @@ SIGNATURES = {
     "dcd_trunk_finalize_backward": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_void_p, c_double, c_int, c_void_p, c_void_p, c_void_p]),
     "dcd_trunk_grad_wg": (c_int, [c_void_p, c_void_p, c_void_p, c_int, c_int, c_void_p]),
     "dcd_bn_backward_relu_from_x": (c_int, [c_void_p] * 10 + [c_int, c_int, c_int64, c_void_p, c_size_t]),
+    "dcd_bn_backward_stats_params_relu_from_x": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
+    "dcd_bn_backward_apply_relu_from_x": (c_int, [c_void_p] * 8 + [c_double, c_void_p, c_int, c_int, c_int64]),
     "dcd_bn_backward_stats_params": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int64, c_void_p, c_void_p, c_void_p, c_void_p, c_size_t]),
     "dcd_bn_backward_apply": (c_int, [c_void_p] * 8 + [c_double] + [c_void_p] * 4 + [c_int, c_int, c_int64]),
     "dcd_bn_at_forward": (c_int, [c_void_p] * 6 + [c_double] + [c_void_p] * 3 + [c_float, c_float, c_int] + [c_void_p] * 4

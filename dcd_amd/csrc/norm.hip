@@ -748,19 +748,21 @@ int dcd_bn_eval_apply(void *stream_, const float *x, const float *residual, cons
 
 static int bn_backward_stats_run(hipStream_t stream, const float *grad_y, const float *y, const float *x, const float *save_mean,
                                  const float *save_invstd, int B, int C, int64_t HW, double *sums, float *grad_weight, float *grad_bias,
-                                 void *ws, size_t ws_bytes)
+                                 void *ws, size_t ws_bytes, const float *mask_weight = nullptr, const float *mask_bias = nullptr,
+                                 int mask_from_x = 0)
 {
     (void)hipGetLastError();
-    if (!grad_y || !x || !save_mean || !sums || bad_shape(B, C, HW) || ((grad_weight || grad_bias) && !save_invstd)) return DCD_ERR_BAD_ARG;
+    if (!grad_y || !x || !save_mean || !sums || bad_shape(B, C, HW) || ((grad_weight || grad_bias || mask_from_x) && !save_invstd))
+        return DCD_ERR_BAD_ARG;
     if (!ws || ws_bytes < dcd_bn_workspace_bytes(C)) return DCD_ERR_WORKSPACE;
     const Plane g = make_plane(B, C, HW);
     const int S = sync_slices(g);
     if (S == 1) {
         hipLaunchKernelGGL(bn_bwd_partial, dim3(1, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, 1, sums, save_invstd, grad_weight,
-                           grad_bias);
+                           grad_bias, mask_weight, mask_bias, mask_from_x);
     } else {
-        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws, (const float *)nullptr,
-                           (float *)nullptr, (float *)nullptr);
+        hipLaunchKernelGGL(bn_bwd_partial, dim3(S, C), dim3(BT), 0, stream, grad_y, y, x, save_mean, g, S, (double *)ws, save_invstd,
+                           (float *)nullptr, (float *)nullptr, mask_weight, mask_bias, mask_from_x);
         hipLaunchKernelGGL(bn_combine, dim3(C), dim3(64), 0, stream, (const double *)ws, S, sums, save_invstd, grad_weight, grad_bias);
     }
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
@@ -778,6 +780,27 @@ int dcd_bn_backward_stats_params(void *stream_, const float *grad_y, const float
 {
     return bn_backward_stats_run((hipStream_t)stream_, grad_y, y, x, save_mean, save_invstd, B, C, HW, sums, grad_weight, grad_bias, ws,
                                  ws_bytes);
+}
+
+int dcd_bn_backward_stats_params_relu_from_x(void *stream_, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                             const float *save_mean, const float *save_invstd, int B, int C, int64_t HW, double *sums,
+                                             float *grad_weight, float *grad_bias, void *ws, size_t ws_bytes)
+{
+    return bn_backward_stats_run((hipStream_t)stream_, grad_y, nullptr, x, save_mean, save_invstd, B, C, HW, sums, grad_weight, grad_bias, ws,
+                                 ws_bytes, weight, bias, 1);
+}
+
+int dcd_bn_backward_apply_relu_from_x(void *stream_, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                      const float *save_mean, const float *save_invstd, const double *sums, double count, float *grad_x,
+                                      int B, int C, int64_t HW)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_y || !x || !save_mean || !save_invstd || !sums || !grad_x || bad_shape(B, C, HW) || !(count >= 1.0)) return DCD_ERR_BAD_ARG;
+    const Plane g = make_plane(B, C, HW);
+    hipLaunchKernelGGL(bn_bwd_apply, dim3(B * g.cpp, C), dim3(BT), 0, stream, grad_y, (const float *)nullptr, x, weight, save_mean, save_invstd,
+                       sums, (const double *)nullptr, 0, count, grad_x, (float *)nullptr, (float *)nullptr, (float *)nullptr, g, bias, 1);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 
 int dcd_bn_backward_apply(void *stream_, const float *grad_y, const float *y, const float *x, const float *weight,

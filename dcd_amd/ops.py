@@ -664,7 +664,7 @@ class _BatchNormAct(torch.autograd.Function):
                                             save_invstd.data_ptr(), B, C, HW), "dcd_bn_train_apply")
         # ReLU fused, no residual, local statistics: the backward recomputes the mask y > 0 from x (dcd_bn_backward_relu_from_x) and
         # does not read y at all -- bias is kept instead of the output
-        ctx.mask_from_x = bool(relu) and residual is None and group is None and _BN_MASK_FROM_X
+        ctx.mask_from_x = bool(relu) and residual is None and _BN_MASK_FROM_X
         if ctx.mask_from_x:
             ctx.save_for_backward(x, bias, weight, save_mean, save_invstd)
         else:
@@ -687,6 +687,19 @@ class _BatchNormAct(torch.autograd.Function):
             bias = y                                   # (the second saved tensor is the bias on this path)
             gw = torch.empty(C, dtype=torch.float32, device=dev)
             gb = torch.empty(C, dtype=torch.float32, device=dev)
+            if ctx.group is not None:                  # statistics, all-reduce, apply
+                import torch.distributed as dist
+                sums = torch.empty((C, 2), dtype=torch.float64, device=dev)
+                _lib.check(L.dcd_bn_backward_stats_params_relu_from_x(st, gy.data_ptr(), x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                                                                      save_mean.data_ptr(), save_invstd.data_ptr(), B, C, HW, sums.data_ptr(),
+                                                                      gw.data_ptr(), gb.data_ptr(), ws.data_ptr(), ws.numel()),
+                           "dcd_bn_backward_stats_params_relu_from_x")
+                dist.all_reduce(sums, group=ctx.group)
+                _lib.check(L.dcd_bn_backward_apply_relu_from_x(st, gy.data_ptr(), x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias),
+                                                               save_mean.data_ptr(), save_invstd.data_ptr(), sums.data_ptr(), ctx.count,
+                                                               gx.data_ptr(), B, C, HW), "dcd_bn_backward_apply_relu_from_x")
+                return (gx, None, gw if weight is not None else None, gb if weight is not None else None,
+                        None, None, None, None, None, None, None)
             _lib.check(L.dcd_bn_backward_relu_from_x(st, gy.data_ptr(), x.data_ptr(), _lib.ptr(weight), _lib.ptr(bias), save_mean.data_ptr(),
                                                      save_invstd.data_ptr(), gx.data_ptr(), gw.data_ptr(), gb.data_ptr(), B, C, HW,
                                                      ws.data_ptr(), ws.numel()), "dcd_bn_backward_relu_from_x")

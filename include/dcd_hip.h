@@ -355,6 +355,13 @@ int dcd_bn_backward_stats(void *stream, const float *grad_y, const float *y, con
 int dcd_bn_backward_relu_from_x(void *stream, const float *grad_y, const float *x, const float *weight, const float *bias,
                                 const float *save_mean, const float *save_invstd, float *grad_x, float *grad_weight, float *grad_bias,
                                 int B, int C, int64_t HW, void *workspace, size_t workspace_bytes);
+/* The two halves of the same backward under data parallelism (sums all-reduced in between), mask recomputed from x: */
+int dcd_bn_backward_stats_params_relu_from_x(void *stream, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                             const float *save_mean, const float *save_invstd, int B, int C, int64_t HW, double *sums,
+                                             float *grad_weight, float *grad_bias, void *workspace, size_t workspace_bytes);
+int dcd_bn_backward_apply_relu_from_x(void *stream, const float *grad_y, const float *x, const float *weight, const float *bias,
+                                      const float *save_mean, const float *save_invstd, const double *sums, double count, float *grad_x,
+                                      int B, int C, int64_t HW);
 /* dcd_bn_backward_stats that also writes THIS rank's parameter gradients from the same sums (grad_weight[c] = sum dz*(x-mean) *
  * invstd, grad_bias[c] = sum dz; either may be NULL): under data parallelism they stay local (DDP averages parameter gradients)
  * while `sums` is all-reduced for the input gradient -- torch.nn.SyncBatchNorm's backward, torch/nn/modules/_functions.py. */
