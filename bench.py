@@ -40,7 +40,7 @@ if ROOT not in sys.path:
 DCN_LAYERS = [(512, 256, 12, 40, 1), (256, 256, 24, 80, 1), (256, 128, 24, 80, 2), (128, 128, 48, 160, 2),
               (128, 64, 48, 160, 4), (64, 64, 96, 320, 5), (256, 64, 24, 80, 1)]
 HBM_PEAK_GBS = 8000.0          # /opt/skills/guides/MI355X_MICROARCH.md: 8 TB/s spec
-MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0}
+MFMA_PEAK_TFLOPS = {"f32": 157.3, "bf16x3": 2500.0 / 3.0, "bf16": 2500.0}
 
 
 def dcn_algorithmic(batch):
@@ -329,7 +329,12 @@ def run_gpu(args):
         elapsed = float(t.item())
 
     global_batch = per_rank * world
-    prec = "bf16x3" if args.amp else args.precision          # MODEL.FP16 routes every DCN call to the split kernels
+    # MODEL.FP16: a precision scope around backbone and predictor -- every DCN / 3x3 contraction as ONE product of bf16-rounded
+    # operands (DCD_PREC_BF16), fp32 accumulate and storage
+    prec = "bf16" if args.amp else args.precision
+    # the fused DCN op has 196 FLOP per algorithmic byte: above the fp32 matrix ridge (157.3 TF / 8 TB/s = 19.7), below the bf16
+    # one (2 500 / 8 = 312) -- in mixed precision HBM is the roofline that bounds it
+    hbm_bound = prec == "bf16"
     dcn_count = args.dcn_steps if use_graph else args.steps
     dcn_ms = timer.total_ms() / max(dcn_count, 1)                       # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
@@ -340,25 +345,29 @@ def run_gpu(args):
             "metric": "images/sec DGDE train step (bs=%d, 384x1280)" % global_batch, "value": global_batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
-            "vs_baseline": None, "dtype": "bf16" if args.amp else "f32", "data": "synthetic",
+            "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}[prec], "data": "synthetic",
             "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI 384x1280 + random kpts_ann "
                                    "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
-                                       global_batch, "bf16 autocast (MODEL.FP16)" if args.amp else "fp32", world, args.objects),
+                                       global_batch, "bf16 matrix operands, fp32 accumulate / storage (MODEL.FP16)" if args.amp
+                                       else "fp32", world, args.objects),
                        "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
                        "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": step_launch,
                        "sync_bn": bool(data_parallel)},
             # The fused op has 196 FLOP per algorithmic byte (ridge of the part: 157.3 TF / 8 TB/s = 19.7), so the matrix pipe
             # is the bound that applies; the HBM view north_star also asks for is kept beside it.
-            "roofline": {"bound": "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers, batch %d per GPU" % per_rank,
-                         "achieved": fl / 1e12 / (dcn_ms / 1e3) if dcn_ms > 0 else None,
-                         "peak": MFMA_PEAK_TFLOPS[prec], "unit": "TFLOP/s",
-                         "frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
+            "roofline": {"bound": "hbm" if hbm_bound else "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers, batch %d per GPU" % per_rank,
+                         "achieved": ((by / 1e9 if hbm_bound else fl / 1e12) / (dcn_ms / 1e3)) if dcn_ms > 0 else None,
+                         "peak": HBM_PEAK_GBS if hbm_bound else MFMA_PEAK_TFLOPS[prec], "unit": "GB/s" if hbm_bound else "TFLOP/s",
+                         "frac": (((by / 1e9) / (dcn_ms / 1e3)) / HBM_PEAK_GBS if hbm_bound
+                                  else (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec]) if dcn_ms > 0 else None,
+                         "mfma_frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
                          "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "pmc_commit": pmc_commit,
                          # what the counters say bounds these kernels (the algorithmic bound is "mfma": 196 FLOP/B): on gfx950 the
                          # f32-input MFMA executes on the vector ALUs' FP32 lanes -- one MFMA and one VALU instruction never
                          # overlap (tools/micro/mfma_valu_overlap.hip, profiles/r03_mfma_valu_overlap.txt) -- so the measured bound
                          # is the SUM of matrix and vector issue cycles, not the matrix pipe alone
-                         "bound_measured": "valu+mfma issue (f32 MFMA shares the VALU lanes)", "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
+                         "bound_measured": ("valu / lds issue (bf16 MFMA overlaps; sampling arithmetic is per (sample, channel))" if hbm_bound
+                                            else "valu+mfma issue (f32 MFMA shares the VALU lanes)"), "flops": fl, "algorithmic_bytes": by, "ms_per_step": dcn_ms,
                          "calls_per_step": len(timer.pairs) // max(dcn_count, 1), "source": dcn_source,
                          "offsets": offsets,
                          "layers": timer.per_layer(max(dcn_count, 1), per_rank)},
@@ -372,29 +381,33 @@ def run_gpu(args):
     # accumulate, ~2^-16 relative per product against north_star's 1e-3 bound) as an EXTRA object: `value` above stays the exact
     # fp32 run.  One GPU, eager step only (a captured graph has the fp32 kernels baked in).
     if out is not None and world == 1 and not use_graph and not args.amp and args.precision == "f32" and not args.no_split_line:
-        _ext.set_precision("bf16x3")
-        s_steps = args.steps
-        for _ in range(max(args.warmup, 2)):
-            step()
-        torch.cuda.synchronize()
-        timer2 = DcnTimer(torch, _ext)
-        timer2.enabled = True
-        t0 = time.perf_counter()
-        for _ in range(s_steps):
-            step()
-        torch.cuda.synchronize()
-        s_el = time.perf_counter() - t0
-        timer2.enabled = False
-        _ext.set_precision("f32")
-        s_dcn = timer2.total_ms() / s_steps
-        out["split_bf16x3"] = {"value": global_batch * s_steps / s_el, "unit": "images/s", "ms_per_step": 1e3 * s_el / s_steps,
-                               "steps": s_steps, "dcn_precision": "bf16x3", "dcn_ms_per_step": s_dcn,
-                               "dcn_tflops": fl / 1e12 / (s_dcn / 1e3) if s_dcn > 0 else None,
-                               "dcn_frac_of_fp32_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if s_dcn > 0 else None,
-                               # against its OWN peak: three bf16 products per fp32 one on the 2.5 PF matrix cores
-                               "dcn_frac_of_split_bf16_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["bf16x3"] if s_dcn > 0 else None,
-                               "dcn_hbm_frac": (by / 1e9 / (s_dcn / 1e3)) / HBM_PEAK_GBS if s_dcn > 0 else None,
-                               "note": "same model, data and step as `value`; only the DCN weight contractions change precision"}
+        # ... and in mixed precision (DCD_PREC_BF16, what MODEL.FP16 / --amp selects: ONE product of bf16-rounded operands, fp32
+        # accumulate and storage): BASELINE config 3's arithmetic on this box, next to the fp32 number it is compared with
+        for key, pname in (("split_bf16x3", "bf16x3"), ("mixed_bf16", "bf16")):
+            _ext.set_precision(pname)
+            s_steps = args.steps
+            for _ in range(max(args.warmup, 2)):
+                step()
+            torch.cuda.synchronize()
+            timer2 = DcnTimer(torch, _ext)
+            timer2.enabled = True
+            t0 = time.perf_counter()
+            for _ in range(s_steps):
+                step()
+            torch.cuda.synchronize()
+            s_el = time.perf_counter() - t0
+            timer2.enabled = False
+            _ext.set_precision("f32")
+            s_dcn = timer2.total_ms() / s_steps
+            out[key] = {"value": global_batch * s_steps / s_el, "unit": "images/s", "ms_per_step": 1e3 * s_el / s_steps,
+                        "ratio_to_fp32": (global_batch * s_steps / s_el) / out["value"],
+                        "steps": s_steps, "dcn_precision": pname, "dcn_ms_per_step": s_dcn,
+                        "dcn_tflops": fl / 1e12 / (s_dcn / 1e3) if s_dcn > 0 else None,
+                        "dcn_frac_of_fp32_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if s_dcn > 0 else None,
+                        # against its OWN peak: three (one) bf16 products per fp32 one on the 2.5 PF matrix cores
+                        "dcn_frac_of_own_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS[pname] if s_dcn > 0 else None,
+                        "dcn_hbm_frac": (by / 1e9 / (s_dcn / 1e3)) / HBM_PEAK_GBS if s_dcn > 0 else None,
+                        "note": "same model, data and step as `value`; the DCN and 3x3-convolution weight contractions change precision"}
     # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
     # bucketed all-reduce overlapped with the backward) as an extra key -- what BASELINE.json configs[2] is at N = 4
     test_weak = force_ddp and os.environ.get("DCD_TEST_WEAK") == "1"        # one-GPU rehearsal of this branch (twice the batch)
@@ -873,9 +886,11 @@ def main():
     ap.add_argument("--objects", type=int, default=6)
     ap.add_argument("--no-split-line", action="store_true", help="skip the extra split-bf16 measurement of the default run")
     ap.add_argument("--no-op-line", action="store_true", help="skip the op-level DCN lines (roofline_op_2px / _0p5px)")
-    ap.add_argument("--precision", choices=("f32", "bf16x3"), default="f32",
-                    help="matrix path of the DCN weight contraction (bf16x3: split bf16, fp32 in / fp32 out)")
-    ap.add_argument("--amp", action="store_true", help="MODEL.FP16: bf16 autocast around the backbone + split-bf16 DCN "
+    ap.add_argument("--precision", choices=("f32", "bf16x3", "bf16"), default="f32",
+                    help="matrix path of the DCN / 3x3 weight contractions everywhere (bf16x3: split bf16, ~2^-16 per product; "
+                         "bf16: one product of bf16-rounded operands; fp32 in / fp32 out either way)")
+    ap.add_argument("--amp", action="store_true", help="MODEL.FP16: backbone and predictor inside a bf16 precision scope (DCN and 3x3 "
+                                                        "contractions on the bf16 matrix cores, fp32 accumulate and storage) "
                                                         "(BASELINE config 3: --gpus 4 --batch 32 --amp)")
     ap.add_argument("--dcn-steps", type=int, default=5, help="eager steps used to time the DCN calls when the timed steps are graph replays")
     ap.add_argument("--no-cpu-baseline", action="store_true")

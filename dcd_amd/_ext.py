@@ -10,12 +10,14 @@ import torch
 
 from . import _lib
 
-PRECISION = {"f32": 0, "bf16x3": 1}
+PRECISION = {"f32": 0, "bf16x3": 1, "bf16": 2}
 _default_precision = "f32"
 
 
 def set_precision(name):
-    """Select the MFMA path used for the weight contraction ("f32" exact, "bf16x3" split-bf16)."""
+    """Select the MFMA path used for the weight contractions of the DCNv2 op and of the 3x3 convolutions:
+    "f32" exact, "bf16x3" split-bf16 (~2^-16 per product), "bf16" mixed precision -- operands rounded to bf16, one
+    product on the bf16 matrix cores, fp32 accumulate (MODEL.FP16, DGDE/model/detector.py:34-36)."""
     global _default_precision
     if name not in PRECISION:
         raise ValueError("precision must be one of %s" % sorted(PRECISION))
@@ -24,6 +26,29 @@ def set_precision(name):
 
 def get_precision():
     return _default_precision
+
+
+class precision_scope:
+    """`with precision_scope("bf16"):` -- the contraction precision of every op whose FORWARD runs inside the block (autograd
+    nodes remember it for their backward).  What MODEL.FP16 wraps around the backbone and the predictor where the reference has
+    `torch.cuda.amp.autocast()` (DGDE/model/detector.py:34-36, head/detector_head.py:20-22)."""
+
+    def __init__(self, name):
+        if name is not None and name not in PRECISION:
+            raise ValueError("precision must be one of %s" % sorted(PRECISION))
+        self.name = name
+
+    def __enter__(self):
+        global _default_precision
+        self.saved = _default_precision
+        if self.name is not None:
+            _default_precision = self.name
+        return self
+
+    def __exit__(self, *exc):
+        global _default_precision
+        _default_precision = self.saved
+        return False
 
 
 def _check(input, weight, bias, offset, mask, kernel_h, kernel_w):

@@ -67,7 +67,7 @@ SIGNATURES = {
     "dcd_conv3x3_split_weights_bytes": (c_size_t, [c_int] * 3),
     "dcd_conv3x3_split_transform_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dcd_conv3x3_split_workspace_bytes": (c_size_t, [c_int] * 5),
-    "dcd_conv3x3_split_prepared": (c_int, [c_void_p] * 6 + [c_int] * 6 + [c_void_p, c_size_t]),
+    "dcd_conv3x3_split_prepared": (c_int, [c_void_p] * 6 + [c_int] * 7 + [c_void_p, c_size_t]),
     "dcd_conv_stem_workspace_bytes": (c_size_t, [c_int] * 3),
     "dcd_conv_stem": (c_int, [c_void_p] * 4 + [c_int] * 7 + [c_void_p, c_size_t]),
     "dcd_conv_stem_wrw_workspace_bytes": (c_size_t, [c_int] * 3),
@@ -76,7 +76,7 @@ SIGNATURES = {
     "dcd_context_norm_backward": (c_int, [c_void_p] * 5 + [c_int, c_int]),
     "dcd_sum_tensors": (c_int, [c_void_p, c_void_p, c_int, c_void_p, c_int64]),
     "dcd_conv3x3_wrw_workspace_bytes": (c_size_t, [c_int] * 5),
-    "dcd_conv3x3_wrw": (c_int, [c_void_p] * 4 + [c_int] * 5 + [c_void_p, c_size_t]),
+    "dcd_conv3x3_wrw": (c_int, [c_void_p] * 4 + [c_int] * 6 + [c_void_p, c_size_t]),
     "dcd_upsample_dw_forward": (c_int, [c_void_p] * 4 + [c_int] * 5),
     "dcd_upsample_dw_forward_add": (c_int, [c_void_p] * 5 + [c_int] * 5),
     "dcd_maxpool2x2_forward": (c_int, [c_void_p, c_void_p, c_void_p, c_int64, c_int, c_int]),

@@ -6,6 +6,8 @@
 typedef __bf16 sp_bf16x8 __attribute__((ext_vector_type(8)));
 typedef __bf16 sp_bf16x2 __attribute__((ext_vector_type(2)));
 typedef unsigned sp_u32x4 __attribute__((ext_vector_type(4)));
+typedef unsigned sp_u32x2 __attribute__((ext_vector_type(2)));
+typedef short sp_s16x4 __attribute__((ext_vector_type(4)));
 typedef float sp_f32x2 __attribute__((ext_vector_type(2)));
 typedef float sp_f32x16 __attribute__((ext_vector_type(16)));
 
@@ -35,6 +37,15 @@ __device__ __forceinline__ SpSplit8 sp_split8(const float (&v)[8])
     s.hi = __builtin_bit_cast(sp_bf16x8, h);
     s.lo = __builtin_bit_cast(sp_bf16x8, l);
     return s;
+}
+
+// eight fp32 values -> bf16 (round to nearest even), no low part: the operand of the ONE-product form (DCD_PREC_BF16)
+__device__ __forceinline__ sp_bf16x8 sp_round8(const float (&v)[8])
+{
+    sp_u32x4 h;
+#pragma unroll
+    for (int q = 0; q < 4; ++q) h[q] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f32x2{v[2 * q], v[2 * q + 1]}, sp_bf16x2));
+    return __builtin_bit_cast(sp_bf16x8, h);
 }
 
 // acc += A * B over K = 16 (v_mfma_f32_32x32x16_bf16), small terms first

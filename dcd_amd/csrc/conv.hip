@@ -437,7 +437,10 @@ __global__ void wino_prep_weights_split(const float *__restrict__ w, unsigned *_
     }
 }
 
-template <int NB>
+// NP = 3: split-bf16 (hi*hi + hi*lo + lo*hi).  NP = 1 (DCD_PREC_BF16): ONE bf16 product per operand pair -- both operands rounded
+// to bf16 (round to nearest even), fp32 accumulate: the mixed-precision form (MODEL.FP16); the lo halves of the prepared weights
+// are neither copied to LDS nor read, the transformed inputs are converted (v_cvt_pk_bf16_f32) instead of split.
+template <int NB, int NP>
 __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restrict__ x, const unsigned *__restrict__ us, float *y,
                                                             float *__restrict__ part, const float *__restrict__ bias,
                                                             const float *residual, int Cc, int H, int W, int Kk, int tiles_x,
@@ -506,6 +509,7 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restr
     auto issue_w = [&](int ck, int buf) {
         const unsigned *src = us_z + (size_t)ck * WSLAB + tid * 4;
         unsigned *dst = wbuf + buf * WSLAB + wave * 256;
+        if (NP == 1 && (wave & 1)) return;                   // 256-dword blocks alternate hi | lo: odd waves would copy lo halves
 #pragma unroll
         for (int q = 0; q < WSLAB / (WN_NT * 4); ++q)
             __builtin_amdgcn_global_load_lds(src + q * (WN_NT * 4), (__attribute__((address_space(3))) void *)(dst + q * (WN_NT * 4)), 16, 0, 0);
@@ -547,13 +551,23 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restr
         }
 #pragma unroll
         for (int nu = 0; nu < 4; ++nu) {
-            const SpSplit8 bo = sp_split8(vv[nu]);
+            if constexpr (NP == 1) {
+                const sp_bf16x8 bh = sp_round8(vv[nu]);
 #pragma unroll
-            for (int ob = 0; ob < NB; ++ob) {
-                const unsigned *wa = wl + (((xi * 4 + nu) * NB + ob) * 2) * 256;
-                const sp_bf16x8 ah = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa));
-                const sp_bf16x8 al = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa + 256));
-                acc[nu][ob] = sp_mfma_x3(ah, al, bo, acc[nu][ob]);
+                for (int ob = 0; ob < NB; ++ob) {
+                    const unsigned *wa = wl + (((xi * 4 + nu) * NB + ob) * 2) * 256;
+                    const sp_bf16x8 ah = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa));
+                    acc[nu][ob] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(ah, bh, acc[nu][ob], 0, 0, 0);
+                }
+            } else {
+                const SpSplit8 bo = sp_split8(vv[nu]);
+#pragma unroll
+                for (int ob = 0; ob < NB; ++ob) {
+                    const unsigned *wa = wl + (((xi * 4 + nu) * NB + ob) * 2) * 256;
+                    const sp_bf16x8 ah = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa));
+                    const sp_bf16x8 al = __builtin_bit_cast(sp_bf16x8, *reinterpret_cast<const sp_u32x4 *>(wa + 256));
+                    acc[nu][ob] = sp_mfma_x3(ah, al, bo, acc[nu][ob]);
+                }
             }
         }
         __syncthreads();                                      // every wave is done with the window
@@ -639,7 +653,13 @@ struct WrwGeom {
     static constexpr int PART = 12 * KO * 64;      // floats per partial result: [xi 4][b 3][k][c] (the column half of G^T . G is applied before the store)
 };
 
-template <int NOB>
+// BF (DCD_PREC_BF16, the mixed-precision form): the lane's eight steps of a strip ARE the eight k-slots of its operands of
+// v_mfma_f32_32x32x16_bf16 (A[i = l & 31][k = 8 (l >> 5) + j], B[k][n = l & 31]: lane (p, h) walks the tiles 8 h + j), so the
+// transformed values of the steps are rounded to bf16 pair by pair and every four steps end in 4 NOB matrix instructions
+// (v_mfma_f32_32x32x8_bf16_1k: the K = 16 form would hold the packed operands of all eight steps, 48 registers the kernel does not
+// have beside its 128 accumulators) where the fp32 form issues 16 NOB of 64 cycles -- the kernel is then bound by its transform
+// arithmetic and LDS reads.
+template <int NOB, bool BF>
 __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict__ x, const float *__restrict__ gy,
                                                          float *__restrict__ part, int Cin, int Cout, int B, int H, int W,
                                                          int strips_x, int S, int ncg, int nblk)
@@ -777,6 +797,8 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         f32x2 g00 = *reinterpret_cast<const f32x2 *>(d0), g01 = *reinterpret_cast<const f32x2 *>(d0 + 32);
         f32x2 g10 = *reinterpret_cast<const f32x2 *>(d1), g11 = *reinterpret_cast<const f32x2 *>(d1 + 32);
 #endif
+        float ev[12];                                  // BF: the even step's values, waiting for their odd partners
+        sp_u32x2 pk[12];                               // BF: [v nu 0..3 | wa nu 0..3 | wb nu 0..3] x bf16 pairs of steps (2 i, 2 i + 1)
 #pragma unroll
         for (int s = 0; s < 8; ++s) {
 #ifndef WW_ABL_NOSTAGE
@@ -804,15 +826,40 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
             const float v[4] = {u0 - u2, u1 + u2, u2 - u1, u1 - u3};
             const float wa[4] = {a0, a0 + a1, a0 - a1, -a1};
             const float wb[4] = {b0, b0 + b1, b0 - b1, -b1};
-            __builtin_amdgcn_sched_barrier(0);               // keep the loads above ahead of the MFMAs below
+            if constexpr (BF) {
 #pragma unroll
-            for (int nu = 0; nu < 4; ++nu) {
-                acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
-                if (NOB == 2) acc[nu][NOB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][NOB - 1], 0, 0, 0);
+                for (int nu = 0; nu < 4; ++nu) {
+                    if (s & 1) {
+                        pk[nu][(s >> 1) & 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f32x2{ev[nu], v[nu]}, sp_bf16x2));
+                        pk[4 + nu][(s >> 1) & 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f32x2{ev[4 + nu], wa[nu]}, sp_bf16x2));
+                        if (NOB == 2) pk[8 + nu][(s >> 1) & 1] = __builtin_bit_cast(unsigned, __builtin_convertvector(sp_f32x2{ev[8 + nu], wb[nu]}, sp_bf16x2));
+                    } else {
+                        ev[nu] = v[nu]; ev[4 + nu] = wa[nu]; ev[8 + nu] = wb[nu];
+                    }
+                }
+                // four steps = the four k-slots of a lane in v_mfma_f32_32x32x8_bf16_1k (A[i = l & 31][k = 4 (l >> 5) + j]): which tile sits in
+                // which slot does not matter, the contraction runs over all of them and both operands of a lane come from the same steps
+                if ((s & 3) == 3) {
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) {
+                        const sp_s16x4 bv = __builtin_bit_cast(sp_s16x4, pk[nu]);
+                        acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(sp_s16x4, pk[4 + nu]), bv, acc[nu][0], 0, 0, 0);
+                        if (NOB == 2)
+                            acc[nu][NOB - 1] = __builtin_amdgcn_mfma_f32_32x32x8bf16_1k(__builtin_bit_cast(sp_s16x4, pk[8 + nu]), bv, acc[nu][NOB - 1], 0, 0, 0);
+                    }
+                }
+            } else {
+                __builtin_amdgcn_sched_barrier(0);               // keep the loads above ahead of the MFMAs below
+#pragma unroll
+                for (int nu = 0; nu < 4; ++nu) {
+                    acc[nu][0] = __builtin_amdgcn_mfma_f32_32x32x2f32(wa[nu], v[nu], acc[nu][0], 0, 0, 0);
+                    if (NOB == 2) acc[nu][NOB - 1] = __builtin_amdgcn_mfma_f32_32x32x2f32(wb[nu], v[nu], acc[nu][NOB - 1], 0, 0, 0);
+                }
             }
             u0 = u2;
             u1 = u3;
         }
+
 #ifndef WW_ABL_NOBAR
         __syncthreads();
 #endif
@@ -936,15 +983,15 @@ static int conv_launch(hipStream_t stream, const ConvPlan &pl, const float *inpu
     return DCD_OK;
 }
 
-template <int NB>
+template <int NB, int NP>
 static int conv_launch_split(hipStream_t stream, const ConvPlan &pl, const float *input, const unsigned *us, float *output, float *part,
                              const float *bias, const float *residual, int B, int Cc, int H, int W, int Kk)
 {
     static LdsLimit lds_limit;
     using G = WinoGeom<2, 16, NB>;
     const size_t ldsb = ((size_t)((WS_CH * G::PLANE + 3) & ~3) + (size_t)2 * 16 * NB * 2 * 256) * sizeof(float);
-    if (!lds_limit.raise((int)ldsb, wino_conv3x3_split<NB>)) return DCD_ERR_LAUNCH;
-    hipLaunchKernelGGL((wino_conv3x3_split<NB>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream, input,
+    if (!lds_limit.raise((int)ldsb, wino_conv3x3_split<NB, NP>)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL((wino_conv3x3_split<NB, NP>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(WN_NT), ldsb, stream, input,
                        us, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
     return DCD_OK;
 }
@@ -1129,12 +1176,14 @@ size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 }
 
 int dcd_conv3x3_split_prepared(void *stream_, const float *input, const void *transformed, const float *bias, const float *residual,
-                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, int precision, void *workspace,
                                size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (!input || !transformed || !output || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if (precision != DCD_PREC_BF16X3 && precision != DCD_PREC_BF16) return DCD_ERR_BAD_ARG;
+    const bool one = precision == DCD_PREC_BF16;
     if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31) || (bias && backward_data)) return DCD_ERR_BAD_ARG;
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
     const ConvPlan pl = conv_plan_split(B, Cc, H, W, Kk);
@@ -1142,8 +1191,11 @@ int dcd_conv3x3_split_prepared(void *stream_, const float *input, const void *tr
     const size_t need = (size_t)(pl.ksplit - 1) * img * sizeof(float);
     if (need && (!workspace || workspace_bytes < need)) return DCD_ERR_WORKSPACE;
     float *part = (float *)workspace;
-    const int st = pl.nb == 2 ? conv_launch_split<2>(stream, pl, input, (const unsigned *)transformed, output, part, bias, residual, B, Cc, H, W, Kk)
-                              : conv_launch_split<1>(stream, pl, input, (const unsigned *)transformed, output, part, bias, residual, B, Cc, H, W, Kk);
+    const unsigned *us = (const unsigned *)transformed;
+    const int st = pl.nb == 2 ? (one ? conv_launch_split<2, 1>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk)
+                                     : conv_launch_split<2, 3>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk))
+                              : (one ? conv_launch_split<1, 1>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk)
+                                     : conv_launch_split<1, 3>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk));
     if (st != DCD_OK) return st;
     if (pl.ksplit > 1) {
         const size_t n4 = img / 4;
@@ -1178,11 +1230,13 @@ size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 }
 
 int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
-                    int Cout, void *workspace, size_t workspace_bytes)
+                    int Cout, int precision, void *workspace, size_t workspace_bytes)
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
     if (!input || !grad_output || !grad_weight || !workspace || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3 && precision != DCD_PREC_BF16) return DCD_ERR_BAD_ARG;
+    const bool bf = precision == DCD_PREC_BF16;              // the split-bf16 form has no variant of this kernel: it runs exact fp32
     if ((W & 3) || (H & 1) || (int64_t)(Cin > Cout ? Cin : Cout) * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
     int nog, ncg, S, strips_x, KO;
     wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x, KO);
@@ -1191,15 +1245,23 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     if (KO == 64) {
         static LdsLimit lds_limit;
         const size_t ldsb = (size_t)2 * WrwGeom<2>::BUF * sizeof(float);
-        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<2>)) return DCD_ERR_LAUNCH;
-        hipLaunchKernelGGL(wino_wrw3x3_f32<2>, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout,
-                           B, H, W, strips_x, S, ncg, nblk);
+        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<2, false>, wino_wrw3x3_f32<2, true>)) return DCD_ERR_LAUNCH;
+        if (bf)
+            hipLaunchKernelGGL((wino_wrw3x3_f32<2, true>), dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace,
+                               Cin, Cout, B, H, W, strips_x, S, ncg, nblk);
+        else
+            hipLaunchKernelGGL((wino_wrw3x3_f32<2, false>), dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace,
+                               Cin, Cout, B, H, W, strips_x, S, ncg, nblk);
     } else {
         static LdsLimit lds_limit;
         const size_t ldsb = (size_t)2 * WrwGeom<1>::BUF * sizeof(float);
-        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<1>)) return DCD_ERR_LAUNCH;
-        hipLaunchKernelGGL(wino_wrw3x3_f32<1>, dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin, Cout,
-                           B, H, W, strips_x, S, ncg, nblk);
+        if (!lds_limit.raise((int)ldsb, wino_wrw3x3_f32<1, false>, wino_wrw3x3_f32<1, true>)) return DCD_ERR_LAUNCH;
+        if (bf)
+            hipLaunchKernelGGL((wino_wrw3x3_f32<1, true>), dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace,
+                               Cin, Cout, B, H, W, strips_x, S, ncg, nblk);
+        else
+            hipLaunchKernelGGL((wino_wrw3x3_f32<1, false>), dim3(nblk * S), dim3(WW_NT), ldsb, stream, input, grad_output, (float *)workspace,
+                               Cin, Cout, B, H, W, strips_x, S, ncg, nblk);
     }
     hipLaunchKernelGGL(wino_wrw_reduce, dim3(nblk * KO * 64 / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout,
                        S, ncg, KO);

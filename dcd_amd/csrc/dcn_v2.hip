@@ -2376,14 +2376,16 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
     // DCD_PREC_BF16X3 permits (does not oblige) the split-bf16 contraction: the workgroup-tiled kernels have it, every other
     // geometry runs the exact fp32 kernels, which are inside any tolerance the split form is
-    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3) return DCD_ERR_BAD_ARG;
-    const bool split = precision == DCD_PREC_BF16X3;
+    // DCD_PREC_BF16 (one product of bf16-rounded operands): the same kernels and prepared weights, their low halves unread
+    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3 && precision != DCD_PREC_BF16) return DCD_ERR_BAD_ARG;
+    const bool split = precision != DCD_PREC_F32;
+    const bool one = precision == DCD_PREC_BF16;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes < nw * sizeof(float) * 2) return DCD_ERR_WORKSPACE;
     if (dense_ok(g, false)) {                                  // wide input, small map: column buffer + GEMM
         if (workspace_bytes < base_workspace_bytes(g) + dense_workspace_bytes(g)) return DCD_ERR_WORKSPACE;
         dense_forward(stream, input, weight, bias, offset, mask, output, g, (float *)((char *)workspace + base_workspace_bytes(g)),
-                      split);
+                      precision);
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
     float *wf = (float *)workspace, *wb = wf + nw;
@@ -2409,8 +2411,10 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             if (!lds_limit8.raise((int)(2 * TileCfg<8>::BUF * sizeof(float)), dcn_fwd_tile_f32<8>) ||
                 !lds_limit4.raise((int)(2 * TileCfg<4>::BUF * sizeof(float)), dcn_fwd_tile_f32<4>))
                 return DCD_ERR_LAUNCH;
-            if (split && (!lds_limit8b.raise((int)(TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<8>) ||
-                          !lds_limit4b.raise((int)(TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<4>)))
+            if (split && (!lds_limit8b.raise((int)(TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<8, 3>,
+                                             dcn_fwd_tile_bf16x3<8, 1>) ||
+                          !lds_limit4b.raise((int)(TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float)), dcn_fwd_tile_bf16x3<4, 3>,
+                                             dcn_fwd_tile_bf16x3<4, 1>)))
                 return DCD_ERR_LAUNCH;
             static int rescue_taps = 0;
             if (rescue_taps == 0) {
@@ -2443,16 +2447,16 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                     if (gsz > 512) gsz = 512;
                     hipLaunchKernelGGL(dcn_fwd_far_count, dim3(gsz), dim3(256), 0, stream, offset, ncoord, far_count);
                 }
-                if (split && rows8)
-                    hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<8>, dim3(regions, B, nz), dim3(512),
-                                       TileCfgB<8>::NBUF * TileCfgB<8>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
-                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call, (const unsigned *)far_count,
-                                       far_limit);
-                else if (split)
-                    hipLaunchKernelGGL(dcn_fwd_tile_bf16x3<4>, dim3(regions, B, nz), dim3(256),
-                                       TileCfgB<4>::NBUF * TileCfgB<4>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias,
-                                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call, (const unsigned *)far_count,
-                                       far_limit);
+#define DCD_FWD_TILE_B(TRV, NPV)                                                                                                      \
+    hipLaunchKernelGGL((dcn_fwd_tile_bf16x3<TRV, NPV>), dim3(regions, B, nz), dim3(TRV * 64),                                         \
+                       TileCfgB<TRV>::NBUF * TileCfgB<TRV>::BUF * sizeof(float), stream, input, offset, mask, (const float *)wf, bias, \
+                       output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call, (const unsigned *)far_count, far_limit)
+                if (split && rows8) {
+                    if (one) DCD_FWD_TILE_B(8, 1); else DCD_FWD_TILE_B(8, 3);
+                } else if (split) {
+                    if (one) DCD_FWD_TILE_B(4, 1); else DCD_FWD_TILE_B(4, 3);
+                }
+#undef DCD_FWD_TILE_B
                 else if (rows8)
                     hipLaunchKernelGGL(dcn_fwd_tile_f32<8>, dim3(regions, B, nz), dim3(512), 2 * TileCfg<8>::BUF * sizeof(float), stream,
                                        input, offset, mask, wf, bias, output, g, tiles_x, nchunk, flags, (const float *)wf9, rescue_taps_call,
@@ -2519,8 +2523,9 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         !grad_weight || !grad_bias || !workspace)
         return DCD_ERR_BAD_ARG;
     if (!make_geom(g, B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg)) return DCD_ERR_BAD_ARG;
-    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3) return DCD_ERR_BAD_ARG;
-    const bool split = precision == DCD_PREC_BF16X3;
+    if (precision != DCD_PREC_F32 && precision != DCD_PREC_BF16X3 && precision != DCD_PREC_BF16) return DCD_ERR_BAD_ARG;
+    const bool split = precision != DCD_PREC_F32;              // the generic kernels: DCD_PREC_BF16 runs their split form
+    const bool one = precision == DCD_PREC_BF16;
     const size_t nw = (size_t)g.Kp * g.Cop;
     if (workspace_bytes + 256 < dcd_dcn_v2_workspace_bytes(B, Cin, H, W, Cout, kh, kw, sh, sw, ph, pw, dh, dw, dg))
         return DCD_ERR_WORKSPACE;
@@ -2575,7 +2580,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (splits > 32) splits = 32;
         hipLaunchKernelGGL(dcn_bias_grad, dim3(Cout, splits), dim3(256), 0, stream, grad_output, grad_bias, B, Cout, g.HoWo);
         dense_backward(stream, input, wb, offset, mask, grad_output, grad_input, grad_offset, grad_mask, grad_weight, g, inv,
-                       (float *)((char *)workspace + base_workspace_bytes(g)), split);
+                       (float *)((char *)workspace + base_workspace_bytes(g)), precision);
         return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
     }
     const int tiles = (g.HoWo + 31) / 32;
@@ -2633,12 +2638,15 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             const int ldsb = SW_WAVES * SW_LDS_FLOATS * (int)sizeof(float);
             if (!sw_lds_limit.raise(ldsb, dcn_bwd_sweep<DCD_PREC_F32, 1, true>, dcn_bwd_sweep<DCD_PREC_BF16X3, 1, true>,
                                     dcn_bwd_sweep<DCD_PREC_F32, 2, false>, dcn_bwd_sweep<DCD_PREC_BF16X3, 2, false>,
-                                    dcn_bwd_sweep<DCD_PREC_F32, 4, false>, dcn_bwd_sweep<DCD_PREC_BF16X3, 4, false>))
+                                    dcn_bwd_sweep<DCD_PREC_F32, 4, false>, dcn_bwd_sweep<DCD_PREC_BF16X3, 4, false>,
+                                    dcn_bwd_sweep<DCD_PREC_BF16, 1, true>, dcn_bwd_sweep<DCD_PREC_BF16, 2, false>,
+                                    dcn_bwd_sweep<DCD_PREC_BF16, 4, false>))
                 return DCD_ERR_LAUNCH;
             const dim3 sgrid(sp.nslot / SW_WAVES), sblock(64 * SW_WAVES);
 #define DCD_LAUNCH_SWEEP(NOBV, DWKV)                                                                                     \
     do {                                                                                                                \
-        if (split) hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_BF16X3, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a);    \
+        if (one) hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_BF16, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a);        \
+        else if (split) hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_BF16X3, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a); \
         else hipLaunchKernelGGL((dcn_bwd_sweep<DCD_PREC_F32, NOBV, DWKV>), sgrid, sblock, ldsb, stream, a);             \
     } while (0)
             if (sp.nob == 1) DCD_LAUNCH_SWEEP(1, true);
@@ -2683,7 +2691,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
                 ga.nsplit = sp.dw_split; ga.kchunk = sp.dw_kchunk; ga.ct = 0; ga.b_off = nullptr;
                 // far samples dominate (far_dominated, count form): the sweep wrote no columns, the generic kernels produce grad_weight
                 ga.skip_count = fs + 3; ga.skip_above = FAR_COUNT_PIVOT;
-                if (split) sgemm_bf16x3(stream, true, true, ga, B);
+                if (split) sgemm_bf16x3(stream, true, true, ga, B, one);
                 else sgemm_f32(stream, true, true, ga, B);
                 e.nvp = 0; e.dw_bx = 0; e.dw_by = 0;
                 e.gemm_n = n; e.gemm_S = B * sp.dw_split;

@@ -25,7 +25,8 @@ class _DCNv2(Function):
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, precision=None):
         kernel = tuple(weight.shape[2:4])
         ctx.geometry = (*kernel, *_pair(stride), *_pair(padding), *_pair(dilation), int(deformable_groups))
-        ctx.precision = {} if precision is None else {"precision": precision}      # None: the backend's default (exact fp32)
+        # None: the backend's current default (its precision scope) -- remembered for the backward, which runs outside the scope
+        ctx.precision = {"precision": _backend.get_precision() if precision is None else precision}
         ctx.save_for_backward(input, offset, mask, weight, bias)
         return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geometry, **ctx.precision)
 
@@ -95,12 +96,14 @@ class _DCNWithOffsets(Function):
     def forward(ctx, input, w_off, b_off, weight, bias, geometry):
         from dcd_amd import ops
         input, w_off, weight = input.contiguous(), w_off.contiguous(), weight.contiguous()
+        ctx.cprec = ops._conv_prec(input)                      # the backward runs outside the forward's precision scope
+        ctx.precision = _backend.get_precision()
         tw, ctx.tw_back = (ops.conv3x3_step_weights(w_off, input) if ops._PREP_BOTH and ctx.needs_input_grad[0] else (None, None))
-        out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous(), transformed=tw)
+        out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous(), transformed=tw, prec=ctx.cprec)
         offset, mask = _offset_mask_split(out)
         ctx.geometry = geometry
         ctx.save_for_backward(input, offset, mask, weight, bias, w_off)
-        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *geometry)
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *geometry, precision=ctx.precision)
 
     @staticmethod
     @once_differentiable
@@ -108,27 +111,28 @@ class _DCNWithOffsets(Function):
         from dcd_amd import ops
         input, offset, mask, weight, bias, w_off = ctx.saved_tensors
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
-            input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry)
+            input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry, precision=ctx.precision)
         gout = _offset_mask_merge(grad_offset, grad_mask, mask)
         if ctx.needs_input_grad[0]:
-            grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous(), transformed=ctx.tw_back)
-        gw_off = ops._conv3x3_wrw_call(input, gout, w_off.shape) if ctx.needs_input_grad[1] else None
+            grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous(), transformed=ctx.tw_back,
+                                           prec=ctx.cprec)
+        gw_off = ops._conv3x3_wrw_call(input, gout, w_off.shape, ctx.cprec) if ctx.needs_input_grad[1] else None
         gb_off = ops.channel_sums(gout) if ctx.needs_input_grad[2] else None
         return grad_input, gw_off, gb_off, grad_weight, grad_bias, None
 
 
 def dcn_v2_conv(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups):
-    """`_DCNv2.apply` with the reference's arguments.  Inside an autocast region (MODEL.FP16, DGDE/model/detector.py:34-36)
-    the op itself stays an fp32 op like the reference's (its extension reads `.data<float>()`, cuda/dcn_v2_cuda.cu:58):
-    half-precision activations are cast back to fp32 at its boundary, and the weight contraction may then take the split-bf16
-    matrix path (DCD_PREC_BF16X3: fp32 in, fp32 out, ~2^-16 per product), which is what a reduced-precision run is for."""
+    """`_DCNv2.apply` with the reference's arguments.  Inside a torch.autocast region (someone else's: MODEL.FP16 itself is a
+    precision scope on the device, model/detector.py) the op stays an fp32 op at its boundary like the reference's (its extension
+    reads `.data<float>()`, cuda/dcn_v2_cuda.cu:58): half-precision activations are cast back to fp32, and the weight contraction
+    takes the mixed-precision matrix path (DCD_PREC_BF16: fp32 in, fp32 out, operands rounded to bf16, fp32 accumulate)."""
     dev = input.device.type
     if torch.is_autocast_enabled(dev):
         with torch.autocast(device_type=dev, enabled=False):
             args = (input.float(), offset.float(), mask.float(), weight.float(), bias.float(), stride, padding, dilation,
                     deformable_groups)
             # the split-bf16 contraction exists on the device only; the host-logic tests run the fp32 oracle behind the cast
-            return _DCNv2.apply(*args, "bf16x3") if input.is_cuda else _DCNv2.apply(*args)
+            return _DCNv2.apply(*args, "bf16") if input.is_cuda else _DCNv2.apply(*args)
     return _DCNv2.apply(input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups)
 
 

@@ -25,10 +25,18 @@ class KeypointDetector(nn.Module):
         if training and targets is None:
             raise ValueError("In training mode, targets should be passed")
         pixels = to_image_list(images).tensors
-        # MODEL.FP16 (detector.py:34-36): autocast around the backbone.  bfloat16 on MI355X (no loss scaling needed; BASELINE
-        # config 3); the DCN op stays an fp32 op at its boundary and takes the split-bf16 matrix path (DCNv2/dcn_v2.py).
-        amp = (torch.autocast(device_type=pixels.device.type, dtype=torch.bfloat16) if (training and self.fp16)
-               else contextlib.nullcontext())
+        # MODEL.FP16 (detector.py:34-36: autocast around the backbone).  On the device the mixed-precision region is a PRECISION
+        # SCOPE of our own kernels, not torch.autocast: every 3x3 convolution and every DCNv2 contraction inside it rounds its
+        # operands to bf16 and runs ONE product on the bf16 matrix cores with fp32 accumulation (DCD_PREC_BF16); activations,
+        # normalisation statistics, sampling arithmetic and every sum stay fp32 -- no tensor changes type between our kernels, so none
+        # of them falls back to a stock op (bfloat16 needs no loss scaling: BASELINE config 3).  Host tensors (the CPU tests) have
+        # no kernels of ours: there the flag is torch's autocast, as in the reference.
+        from dcd_amd import _ext
+        if training and self.fp16:
+            amp = (_ext.precision_scope("bf16") if pixels.is_cuda
+                   else torch.autocast(device_type=pixels.device.type, dtype=torch.bfloat16))
+        else:
+            amp = contextlib.nullcontext()
         with amp:
             features = self.backbone(pixels)
         return self.heads(features, targets) if training else self.heads(features, targets, test=self.test)

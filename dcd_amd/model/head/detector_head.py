@@ -11,7 +11,14 @@ from . import detector_infer, detector_loss, detector_predictor
 
 
 def _maybe_autocast(enabled, tensor):
-    return torch.autocast(device_type=tensor.device.type) if enabled else contextlib.nullcontext()
+    """MODEL.FP16 around the predictor (detector_head.py:20-22).  Device tensors: the precision scope of our own kernels
+    (operands of the 3x3 convolutions rounded to bf16, fp32 accumulate and storage; see model/detector.py); host tensors: autocast."""
+    if not enabled:
+        return contextlib.nullcontext()
+    if tensor.is_cuda:
+        from dcd_amd import _ext
+        return _ext.precision_scope("bf16")
+    return torch.autocast(device_type=tensor.device.type)
 
 
 class Detect_Head(nn.Module):

@@ -772,38 +772,59 @@ def conv3x3_supported(x, weight):
 
 
 _CONV_SPLIT_MIN_MAP = int(os.environ.get("DCD_CONV_SPLIT_MIN_MAP", "7680"))
+_CONV_BF16_MIN_MAP = int(os.environ.get("DCD_CONV_BF16_MIN_MAP", "0"))
+PREC_F32, PREC_BF16X3, PREC_BF16 = 0, 1, 2
+
+
+def _conv_prec(like=None):
+    """Precision of a 3x3 convolution's Winograd-domain products (a DCD_PREC_* value), from `_ext.get_precision()`:
+      "bf16x3"  split-bf16 (what `bench.py --precision bf16x3` sets) -- the split kernel has the 8 x 32 px regions only and pays
+                from 48 x 160 maps on (64->64 @ 96x320 123 -> 83 us, 128->128 @ 48x160 101 -> 69; 256->256 @ 24x80 95 -> 120:
+                those stay on the fp32 kernel with its exact-cover 12 x 20 regions);
+      "bf16"    one product of bf16-rounded operands (MODEL.FP16) on the same kernel, on every map of at least
+                DCD_CONV_BF16_MIN_MAP pixels;
+    DCD_CONV_SPLIT=0 keeps the convolutions exact fp32 in either mode (A/B timing).  like: the call's input."""
+    from . import _ext
+    p = _ext.get_precision()
+    if p == "f32" or os.environ.get("DCD_CONV_SPLIT", "1") == "0":
+        return PREC_F32
+    hw = None if like is None else like.shape[2] * like.shape[3]
+    if p == "bf16x3":
+        return PREC_BF16X3 if hw is None or hw >= _CONV_SPLIT_MIN_MAP else PREC_F32
+    return PREC_BF16 if hw is None or hw >= _CONV_BF16_MIN_MAP else PREC_F32
 
 
 def _conv_split(like=None):
-    """Split-bf16 products for the 3x3 convolutions: `_ext.set_precision("bf16x3")` (what `bench.py --precision bf16x3` sets) unless
-    DCD_CONV_SPLIT=0 keeps them exact fp32 (A/B timing).  like: the call's input -- the split kernel has the 8 x 32 px regions
-    only and pays from 48 x 160 maps on (64->64 @ 96x320 123 -> 83 us, 128->128 @ 48x160 101 -> 69; 256->256 @ 24x80 95 -> 120:
-    those stay on the fp32 kernel with its exact-cover 12 x 20 regions)."""
-    from . import _ext
-    if _ext.get_precision() != "bf16x3" or os.environ.get("DCD_CONV_SPLIT", "1") == "0":
-        return False
-    return like is None or like.shape[2] * like.shape[3] >= _CONV_SPLIT_MIN_MAP
+    return _conv_prec(like) != PREC_F32
+
+
+def _wrw_prec(prec):
+    """The weight-gradient kernel has the exact and the one-product form (no split one)."""
+    return PREC_BF16 if prec == PREC_BF16 else PREC_F32
 
 
 class SplitWeights:
     """Winograd-domain weights in split-bf16 layout (dcd_conv3x3_split_transform_weights); a marker type so that the call knows
-    which kernel they belong to."""
+    which kernel they belong to, and with which precision (DCD_PREC_BF16X3 / DCD_PREC_BF16: the same layout) it runs."""
 
-    def __init__(self, tensor):
+    def __init__(self, tensor, prec):
         self.tensor = tensor
+        self.prec = prec
 
 
-def conv3x3_transform_weights(weight, forward=True, backward=True, like=None):
+def conv3x3_transform_weights(weight, forward=True, backward=True, like=None, prec=None):
     """Winograd-domain weights of a (Cout, Cin, 3, 3) filter for the forward and / or the backward-data call, ONE launch
-    (split-bf16 form: one launch per direction).  like: the tensor the convolution will run on (decides the form, see _conv_split)."""
+    (split-bf16 form: one launch per direction).  like: the tensor the convolution will run on (decides the form, see _conv_prec);
+    prec: a DCD_PREC_* value that overrides it."""
     L = _lib.lib()
     Co, Ci = weight.shape[0], weight.shape[1]
-    if _conv_split(like):
+    prec = _conv_prec(like) if prec is None else prec
+    if prec != PREC_F32:
         tf = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device) if forward else None
         tb = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device) if backward else None
         _lib.check(L.dcd_conv3x3_split_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
                    "dcd_conv3x3_split_transform_weights")
-        return (SplitWeights(tf) if forward else None), (SplitWeights(tb) if backward else None)
+        return (SplitWeights(tf, prec) if forward else None), (SplitWeights(tb, prec) if backward else None)
     tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device) if forward else None
     tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device) if backward else None
     _lib.check(L.dcd_conv3x3_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
@@ -811,10 +832,13 @@ def conv3x3_transform_weights(weight, forward=True, backward=True, like=None):
     return tf, tb
 
 
-def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None, transformed=None, residual_inplace=True):
+def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=None, transformed=None, residual_inplace=True,
+                  prec=None):
     """residual: a tensor of the output's shape that the result is added to -- IN PLACE (and returned) unless residual_inplace
     is False (then it is only read: a gradient the caller does not own).
-    transformed: this direction's weights from conv3x3_transform_weights (else they are transformed inside the call)."""
+    transformed: this direction's weights from conv3x3_transform_weights (else they are transformed inside the call).
+    prec: DCD_PREC_* of a call that transforms its own weights (default: `_conv_prec(inp)`, i.e. the current precision scope --
+    a backward call passes what its forward ran with)."""
     L = _lib.lib()
     B, _, H, W = inp.shape
     Co, Ci = weight.shape[0], weight.shape[1]
@@ -824,14 +848,16 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
         out = residual if residual_inplace else torch.empty_like(residual)
     else:
         out = torch.empty((B, out_channels, H, W), dtype=torch.float32, device=inp.device)
-    if transformed is None and _conv_split(inp):
-        transformed = conv3x3_transform_weights(weight, not backward_data, backward_data, like=inp)[1 if backward_data else 0]
+    if transformed is None:
+        prec = _conv_prec(inp) if prec is None else prec
+        if prec != PREC_F32:
+            transformed = conv3x3_transform_weights(weight, not backward_data, backward_data, prec=prec)[1 if backward_data else 0]
     if isinstance(transformed, SplitWeights):
         n = L.dcd_conv3x3_split_workspace_bytes(B, Ci, H, W, Co)
         ws = torch.empty(max(n, 16), dtype=torch.uint8, device=inp.device)
         st = L.dcd_conv3x3_split_prepared(_lib.stream_of(inp), inp.data_ptr(), transformed.tensor.data_ptr(), _lib.ptr(bias),
                                           _lib.ptr(residual), out.data_ptr(), B, Ci, H, W, Co, 1 if backward_data else 0,
-                                          ws.data_ptr(), n)
+                                          transformed.prec, ws.data_ptr(), n)
         _lib.check(st, "dcd_conv3x3_split_prepared")
         return out
     n = L.dcd_conv3x3_workspace_bytes(B, Ci, H, W, Co)
@@ -933,13 +959,14 @@ def conv3x3_step_weights(weight, like):
     """(forward, backward-data) Winograd-domain weights for a call inside a train step: the step's table entry when it is
     current (no launch), else transformed now -- both directions, one launch -- and the layer is registered for the next
     `refresh_conv_weights`."""
-    if not _conv_split(like):
+    prec = _conv_prec(like)
+    if prec == PREC_F32:
         prepared = _PREPARED.setdefault(like.device.index, _PreparedWeights())
         e = prepared.lookup(weight)
         if e is not None:
             return e[2], e[3]
         prepared.register(weight)
-    return conv3x3_transform_weights(weight, like=like)
+    return conv3x3_transform_weights(weight, prec=prec)
 
 
 def refresh_conv_weights(device=None):
@@ -955,14 +982,16 @@ def refresh_conv_weights(device=None):
 _WRW_ENABLED = os.environ.get("DCD_CONV_WRW", "1") != "0"        # 0: weight gradient on the stock op (A/B timing)
 
 
-def _conv3x3_wrw_call(x, gy, wshape):
+def _conv3x3_wrw_call(x, gy, wshape, prec=PREC_F32):
+    """prec: the DCD_PREC_* the layer's forward ran with (the one-product form exists, the split one runs exact)."""
     L = _lib.lib()
     B, Ci, H, W = x.shape
     Co = wshape[0]
     gw = torch.empty(tuple(wshape), dtype=torch.float32, device=x.device)
     n = L.dcd_conv3x3_wrw_workspace_bytes(B, Ci, H, W, Co)
     ws = torch.empty(n, dtype=torch.uint8, device=x.device)
-    st = L.dcd_conv3x3_wrw(_lib.stream_of(x), x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Ci, H, W, Co, ws.data_ptr(), n)
+    st = L.dcd_conv3x3_wrw(_lib.stream_of(x), x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, Ci, H, W, Co, _wrw_prec(prec),
+                           ws.data_ptr(), n)
     _lib.check(st, "dcd_conv3x3_wrw")
     return gw
 
@@ -978,11 +1007,12 @@ class _Conv3x3(torch.autograd.Function):
         x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
         ctx.tw_back = None
+        ctx.prec = _conv_prec(x)                       # the backward runs outside the forward's precision scope
         if _PREP_BOTH and ctx.needs_input_grad[0]:
             # the weights of this call and of its backward-data call (they do not change in between)
             tw, ctx.tw_back = conv3x3_step_weights(weight, x)
             return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw)
-        return _conv3x3_call(x, weight, weight.shape[0], False)
+        return _conv3x3_call(x, weight, weight.shape[0], False, prec=ctx.prec)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -991,10 +1021,10 @@ class _Conv3x3(torch.autograd.Function):
         gy = _f32c(gy)
         gx = gw = None
         if ctx.needs_input_grad[0]:
-            gx = _conv3x3_call(gy, weight, weight.shape[1], True, transformed=ctx.tw_back)
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True, transformed=ctx.tw_back, prec=ctx.prec)
         if ctx.needs_input_grad[1]:
             if _WRW_ENABLED:
-                gw = _conv3x3_wrw_call(x, gy, weight.shape)
+                gw = _conv3x3_wrw_call(x, gy, weight.shape, ctx.prec)
             else:
                 gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                          [False, True, False])[1]
@@ -1016,8 +1046,9 @@ class _Conv3x3Skip(torch.autograd.Function):
         _lib.require_cuda(x, weight)
         x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
+        ctx.prec = _conv_prec(x)
         tw, ctx.tw_back = conv3x3_step_weights(weight, x) if _PREP_BOTH and ctx.needs_input_grad[0] else (None, None)
-        return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw), x.view_as(x)
+        return _conv3x3_call(x, weight, weight.shape[0], False, transformed=tw, prec=ctx.prec), x.view_as(x)
 
     @staticmethod
     @torch.autograd.function.once_differentiable
@@ -1029,9 +1060,10 @@ class _Conv3x3Skip(torch.autograd.Function):
         gy = _f32c(gy)
         if ctx.needs_input_grad[0]:
             res = None if gskip is None else _f32c(gskip)   # read only: the gradient tensor belongs to autograd
-            gx = _conv3x3_call(gy, weight, weight.shape[1], True, residual=res, transformed=ctx.tw_back, residual_inplace=False)
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True, residual=res, transformed=ctx.tw_back, residual_inplace=False,
+                               prec=ctx.prec)
         if ctx.needs_input_grad[1]:
-            gw = (_conv3x3_wrw_call(x, gy, weight.shape) if _WRW_ENABLED else
+            gw = (_conv3x3_wrw_call(x, gy, weight.shape, ctx.prec) if _WRW_ENABLED else
                   torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False])[1])
         return gx, gw
 
@@ -1055,6 +1087,7 @@ class _Conv3x3StockFwd(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, weight):
         ctx.save_for_backward(x, weight)
+        ctx.prec = _conv_prec(x)
         return torch.nn.functional.conv2d(x, weight, None, 1, 1)
 
     @staticmethod
@@ -1067,7 +1100,7 @@ class _Conv3x3StockFwd(torch.autograd.Function):
             gx = torch.ops.aten.convolution_backward(gy, x, weight, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1,
                                                      [True, False, False])[0]
         if ctx.needs_input_grad[1]:
-            gw = _conv3x3_wrw_call(_f32c(x), gy, weight.shape)
+            gw = _conv3x3_wrw_call(_f32c(x), gy, weight.shape, ctx.prec)
         return gx, gw
 
 
@@ -1244,8 +1277,9 @@ class _ConvBias(torch.autograd.Function):
         if ctx.ours:
             x, weight = _f32c(x), _f32c(weight)
         ctx.save_for_backward(x, weight)
+        ctx.prec = _conv_prec(x) if ctx.ours else PREC_F32
         if ctx.ours and _OFFSET_CONV_FWD:
-            return _conv3x3_call(x, weight, weight.shape[0], False, _f32c(bias))
+            return _conv3x3_call(x, weight, weight.shape[0], False, _f32c(bias), prec=ctx.prec)
         return torch.nn.functional.conv2d(x, weight, bias, stride, padding, dilation)
 
     @staticmethod
@@ -1258,9 +1292,9 @@ class _ConvBias(torch.autograd.Function):
         ours_w = ours and _WRW_ENABLED
         gx = gw = None
         if ours and ctx.needs_input_grad[0]:
-            gx = _conv3x3_call(gy, weight, weight.shape[1], True)
+            gx = _conv3x3_call(gy, weight, weight.shape[1], True, prec=ctx.prec)
         if ours_w and ctx.needs_input_grad[1]:
-            gw = _conv3x3_wrw_call(x, gy, weight.shape)
+            gw = _conv3x3_wrw_call(x, gy, weight.shape, ctx.prec)
         need_x, need_w = ctx.needs_input_grad[0] and gx is None, ctx.needs_input_grad[1] and gw is None
         if need_x or need_w:
             sx, sw, _ = torch.ops.aten.convolution_backward(gy, x, weight, None, stride, padding, dilation, False, [0, 0], 1,

@@ -44,11 +44,17 @@ const char *dcd_version(void);
  *            1 = DCD_PREC_BF16X3 split-bf16 (hi*hi + hi*lo + lo*hi on the bf16 MFMAs, fp32 accumulate;
  *                                ~2^-16 relative per product).  Permits, does not oblige: geometries
  *                                without a split kernel run the exact fp32 kernels.
+ *            2 = DCD_PREC_BF16   mixed precision (MODEL.FP16, DGDE/model/detector.py:34-36): both operands of the weight
+ *                                contraction rounded to bf16 (nearest even), ONE product on the bf16 MFMAs, fp32
+ *                                accumulate; sampling / coordinate arithmetic, storage and every sum stay fp32.
+ *                                ~2^-9 relative per operand.  Permits, does not oblige (kernels without the one-product
+ *                                form run the split-bf16 or the exact fp32 one).
  * workspace: device scratch of at least dcd_dcn_v2_workspace_bytes(...) bytes, 256-byte aligned,
  *            owned by the caller; contents are dead after the call's kernels complete.
  * ---------------------------------------------------------------------------------------------- */
 #define DCD_PREC_F32 0
 #define DCD_PREC_BF16X3 1
+#define DCD_PREC_BF16 2
 
 size_t dcd_dcn_v2_workspace_bytes(int B, int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw,
                                   int ph, int pw, int dh, int dw, int dg);
@@ -452,21 +458,25 @@ int dcd_conv3x3_prepared(void *stream, const float *input, const float *transfor
  * accumulate: ~2^-16 relative per product, the form DCD_PREC_BF16X3 names for the deformable convolution): transforms stay fp32,
  * operands stay fp32 in HBM.  Weights are prepared in their own layout (dcd_conv3x3_split_weights_bytes /
  * dcd_conv3x3_split_transform_weights: both directions, either pointer may be NULL); workspace holds the partial images of a
- * split contraction only.  Same shape rules as dcd_conv3x3. */
+ * split contraction only.  Same shape rules as dcd_conv3x3.
+ * precision: DCD_PREC_BF16X3, or DCD_PREC_BF16 = one product of bf16-rounded operands (the same prepared weights: their low halves
+ * are not read). */
 size_t dcd_conv3x3_split_weights_bytes(int Cin, int Cout, int backward_data);
 int dcd_conv3x3_split_transform_weights(void *stream, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out);
 size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int dcd_conv3x3_split_prepared(void *stream, const float *input, const void *transformed, const float *bias, const float *residual,
-                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, int precision, void *workspace,
                                size_t workspace_bytes);
 
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).
- * Same shape requirements; workspace: dcd_conv3x3_wrw_workspace_bytes(B, Cin, H, W, Cout) bytes, dead after the call. */
+ * Same shape requirements; workspace: dcd_conv3x3_wrw_workspace_bytes(B, Cin, H, W, Cout) bytes, dead after the call.
+ * precision: DCD_PREC_F32 exact; DCD_PREC_BF16 the sixteen Winograd-domain products on v_mfma_f32_32x32x16_bf16 with both transformed
+ * operands rounded to bf16 (fp32 accumulate over the tiles); DCD_PREC_BF16X3 runs the exact kernel. */
 size_t dcd_conv3x3_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int dcd_conv3x3_wrw(void *stream, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
-                    int Cout, void *workspace, size_t workspace_bytes);
+                    int Cout, int precision, void *workspace, size_t workspace_bytes);
 
 /* ------------------------------------------------------------------------------------------------
  * The low-channel, full-resolution convolutions of DLA-34's stem (csrc/stem.hip, v_mfma_f32_16x16x4_f32):

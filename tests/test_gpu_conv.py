@@ -449,3 +449,49 @@ def test_conv3x3_split_bf16_form(cuda, monkeypatch, B, C, K, H, W):
     assert torch.equal(y, y_unprepared)
     assert not torch.equal(y, y32)
     assert (y - y32).abs().max().item() <= 5e-5 * y32.abs().max().item()
+
+
+@pytest.mark.parametrize("B,C,K,H,W", CASES + [(2, 64, 27, 24, 64), (1, 128, 27, 12, 40), (8, 64, 64, 96, 320)])
+def test_conv3x3_mixed_bf16_form(cuda, monkeypatch, B, C, K, H, W):
+    """`_ext.precision_scope("bf16")` (MODEL.FP16): forward and input gradient on wino_conv3x3_split<., 1> and the weight gradient on
+    wino_wrw3x3_f32<., true> -- the Winograd-domain products as ONE product of bf16-rounded operands on the bf16 matrix cores, fp32
+    accumulate -- against conv2d in fp64.  Operand rounding is 2^-9 each, on TRANSFORMED values (sums of up to four inputs / nine
+    weights): held to 1.5e-2 of the output scale, required to be above 1e-4 (it is not the fp32 kernel), with bias and residual; the
+    autograd node remembers the scope for its backward (which runs outside it)."""
+    from dcd_amd import _ext, ops
+    g = torch.Generator().manual_seed(C * 7 + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    bias = torch.randn(K, generator=g)
+    res = torch.randn(B, K, H, W, generator=g)
+    gy = torch.randn(B, K, H, W, generator=g)
+    ref = F.conv2d(x.double(), w.double(), bias.double(), padding=1) + res.double()
+    ref_gx = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), padding=1)
+    xd, wd, bd, gd = x.to(cuda), w.to(cuda), bias.to(cuda), gy.to(cuda)
+    y32 = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone())
+    with _ext.precision_scope("bf16"):
+        tf, tb = ops.conv3x3_transform_weights(wd)
+        assert isinstance(tf, ops.SplitWeights) and tf.prec == ops.PREC_BF16
+        y = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone(), transformed=tf)
+        gx = ops._conv3x3_call(gd, wd, C, True, transformed=tb)
+        y_unprepared = ops._conv3x3_call(xd, wd, K, False, bd, residual=res.to(cuda).clone())
+    gw = ops._conv3x3_wrw_call(xd, gd, w.shape, ops.PREC_BF16)
+    gw32 = ops._conv3x3_wrw_call(xd, gd, w.shape)
+    _close(y.cpu(), ref, "bf16 forward", 1.5e-2)
+    _close(gx.cpu(), ref_gx, "bf16 grad_input", 1.5e-2)
+    _close(gw.cpu(), ref_gw, "bf16 grad_weight", 1.5e-2)
+    _close(gw32.cpu(), ref_gw, "fp32 grad_weight", 2e-5)
+    assert torch.equal(y, y_unprepared)
+    for a_, b_ in ((y, y32), (gw, gw32)):
+        assert (a_ - b_).abs().max().item() > 1e-4 * b_.abs().max().item()
+    if K >= 64 and C >= 64:
+        # through the autograd node: scope at forward time only
+        xg, wg = xd.clone().requires_grad_(True), wd.clone().requires_grad_(True)
+        with _ext.precision_scope("bf16"):
+            out = ops.conv3x3(xg, wg)
+        assert _ext.get_precision() == "f32"
+        out.backward(gd)
+        _close(xg.grad.cpu(), ref_gx, "bf16 autograd grad_input", 1.5e-2)
+        _close(wg.grad.cpu(), ref_gw, "bf16 autograd grad_weight", 1.5e-2)
+        assert (wg.grad - gw32).abs().max().item() > 1e-4 * gw32.abs().max().item()     # the backward kept the forward's precision

@@ -155,6 +155,75 @@ def test_full_size_bf16x3(cuda, oracle_dcn, geom):
         close(g_, r_, BF16X3_TOL, "bf16x3 full-size image 0 " + name)
 
 
+# ---- DCD_PREC_BF16: mixed precision (MODEL.FP16): both operands of the weight contraction rounded to bf16 (2^-9 each), ONE
+# product on the bf16 matrix cores, fp32 accumulate; sampling / coordinate arithmetic and sums stay fp32.  Against the SAME fp32
+# oracle the error is the operand rounding: ~2^-8 per product, random in sign, i.e. ~1e-3 of the output scale after a sum over
+# 9 Cin terms -- held to 1e-2 of the output scale (max norm) and required to be ABOVE 1e-6 on the kernels that have the form
+# (it is not the fp32 kernel under another name).
+BF16_TOL = 1e-2
+
+
+@pytest.mark.parametrize("case", CASES)
+def test_forward_and_backward_match_oracle_bf16(cuda, oracle_dcn, case):
+    from dcd_amd import _ext
+    B, C, Co, H, W, dg, osc = case
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, dg, off_scale=osc, seed=1)
+    a = (3, 3, 1, 1, 1, 1, 1, 1, dg)
+    dev = [t.to(cuda) for t in (x, w, b, off, m)]
+    ref = oracle_dcn.dcn_v2_forward(x, w, b, off, m, *a)
+    got = _ext.dcn_v2_forward(*dev, *a, precision="bf16")
+    close(got, ref, BF16_TOL, "bf16 forward %s" % (case,))
+    refg = oracle_dcn.dcn_v2_backward(x, w, b, off, m, gy, *a)
+    gotg = _ext.dcn_v2_backward(*dev, gy.to(cuda), *a, precision="bf16")
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), gotg, refg):
+        close(g_, r_, BF16_TOL, "bf16 %s %s" % (name, case))
+
+
+@pytest.mark.parametrize("shape", [(64, 64, 24, 64), (128, 128, 16, 32), (256, 256, 24, 80), (256, 72, 12, 20)])
+def test_bf16_path_is_the_one_product_kernel(cuda, shape):
+    """Tiled forward, one-pass backward (Cout <= 64 and the wide variant) and the dense path's products under DCD_PREC_BF16: every
+    result that passes through a weight contraction differs from the exact-fp32 one by bf16 operand rounding -- more than the split
+    form's 3e-5, less than 1e-2 of its scale; the bias gradient (a plain sum) is bitwise the same."""
+    from dcd_amd import _ext
+    C, Co, H, W = shape
+    x, w, b, off, m, gy = (t.to(cuda) for t in make_case(2, C, Co, H, W, off_scale=0.5, seed=13))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    y32 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="f32")
+    y16 = _ext.dcn_v2_forward(x, w, b, off, m, *a, precision="bf16")
+    rel = (y32 - y16).abs().max().item() / y32.abs().max().item()
+    assert 1e-4 < rel < BF16_TOL, ("forward", rel)
+    g32 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="f32")
+    g16 = _ext.dcn_v2_backward(x, w, b, off, m, gy, *a, precision="bf16")
+    for name, p32, p16 in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight"), g32, g16):
+        rel = (p32 - p16).abs().max().item() / p32.abs().max().item()
+        assert 1e-4 < rel < BF16_TOL, (name, shape, rel)
+    assert torch.allclose(g32[4], g16[4], rtol=1e-6, atol=0)
+
+
+@pytest.mark.parametrize("geom", [(64, 64, 96, 320), (256, 128, 24, 80)])
+def test_full_size_bf16(cuda, oracle_dcn, geom):
+    """BASELINE batch (8) in mixed precision: image 0 against the fp32 oracle, forward and all five gradients; the other images
+    through additivity of the batch (grad_weight / grad_bias of the batch = sum over single-image calls, to summation order)."""
+    from dcd_amd import _ext
+    C, Co, H, W = geom
+    x, w, b, off, m, gy = make_case(8, C, Co, H, W, seed=7, off_scale=0.5)
+    xd, wd, bd, od, md, gd = (t.to(cuda) for t in (x, w, b, off, m, gy))
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    y = _ext.dcn_v2_forward(xd, wd, bd, od, md, *a, precision="bf16")
+    close(y[:1], oracle_dcn.dcn_v2_forward(x[:1], w, b, off[:1], m[:1], *a), BF16_TOL, "bf16 image 0 forward")
+    g1 = _ext.dcn_v2_backward(xd[:1].contiguous(), wd, bd, od[:1].contiguous(), md[:1].contiguous(), gd[:1].contiguous(), *a,
+                              precision="bf16")
+    refg = oracle_dcn.dcn_v2_backward(x[:1], w, b, off[:1], m[:1], gy[:1], *a)
+    for name, g_, r_ in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias"), g1, refg):
+        close(g_, r_, BF16_TOL, "bf16 full-size image 0 " + name)
+    gall = _ext.dcn_v2_backward(xd, wd, bd, od, md, gd, *a, precision="bf16")
+    close(gall[0][:1], g1[0], 1e-4, "bf16 batch vs single image: grad_input")
+    close(gall[1][:1], g1[1], 1e-4, "bf16 batch vs single image: grad_offset")
+    gw = sum(_ext.dcn_v2_backward(xd[i:i + 1].contiguous(), wd, bd, od[i:i + 1].contiguous(), md[i:i + 1].contiguous(),
+                                  gd[i:i + 1].contiguous(), *a, precision="bf16")[3] for i in range(8))
+    close(gall[3], gw, 1e-4, "bf16 batch grad_weight = sum of the images'")
+
+
 @pytest.mark.parametrize("geom", [(3, 3, 2, 2, 1, 1, 1, 1), (3, 3, 1, 1, 2, 2, 2, 2), (1, 1, 1, 1, 0, 0, 1, 1),
                                   (3, 1, 1, 2, 1, 0, 1, 1)])
 def test_general_geometry(cuda, oracle_dcn, geom):

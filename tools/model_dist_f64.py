@@ -14,6 +14,10 @@ import test_host_golden as H
 from dcd_amd.model.detector import KeypointDetector
 
 dev = torch.device(sys.argv[1] if len(sys.argv) > 1 else "cuda:0")
+if os.environ.get("DCD_PRECISION"):                       # bf16x3 / bf16: the numbers behind the mixed-precision tests' bars
+    from dcd_amd import _ext
+    _ext.set_precision(os.environ["DCD_PRECISION"])
+    print("precision:", _ext.get_precision())
 torch.backends.cudnn.benchmark = False
 g32, g64 = H.load("model_96x320"), H.load("model_96x320_f64")
 model = KeypointDetector(H.small_cfg(str(dev))).to(dev)

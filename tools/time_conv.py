@@ -25,6 +25,10 @@ def t(fn, iters=10):
 
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 8
+if os.environ.get("DCD_PRECISION"):                       # bf16x3 / bf16: the same table with the products in that precision
+    from dcd_amd import _ext
+    _ext.set_precision(os.environ["DCD_PRECISION"])
+PREC = {"f32": 0, "bf16x3": 1, "bf16": 2}[os.environ.get("DCD_PRECISION", "f32")]
 for C, K, H, W in SHAPES:
     x = torch.randn(B, C, H, W, device=dev)
     w = torch.randn(K, C, 3, 3, device=dev) / (C * 9) ** 0.5
@@ -34,7 +38,7 @@ for C, K, H, W in SHAPES:
     b = t(lambda: F.conv2d(x, w, padding=1))
     c = t(lambda: ops._conv3x3_call(gy, w, C, True))
     d = t(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [True, False, False]))
-    e = t(lambda: ops._conv3x3_wrw_call(x, gy, w.shape))
+    e = t(lambda: ops._conv3x3_wrw_call(x, gy, w.shape, PREC))
     f = t(lambda: torch.ops.aten.convolution_backward(gy, x, w, None, [1, 1], [1, 1], [1, 1], False, [0, 0], 1, [False, True, False]))
     print("%4d->%3d @%3dx%3d  wrw hip %.3f ms (%.0f TF eff) | miopen %.3f (%.0f)" % (C, K, H, W, e, fl / e / 1e9, f, fl / f / 1e9))
     print("%4d->%3d @%3dx%3d  fwd hip %.3f ms (%.0f TF eff) | miopen %.3f (%.0f)   bwd-data hip %.3f (%.0f) | miopen %.3f (%.0f)" % (
