@@ -45,6 +45,9 @@ SIGNATURES = {
     "dcd_dcn_v2_workspace_bytes": (c_size_t, [c_int] * 14),
     "dcd_dcn_v2_forward": (c_int, [c_void_p] * 7 + [c_int] * 15 + [c_void_p, c_size_t]),
     "dcd_dcn_v2_backward": (c_int, [c_void_p] * 12 + [c_int] * 15 + [c_void_p, c_size_t]),
+    "dcd_dcn_v2_forget": (c_int, [c_void_p]),
+    "dcd_dcn_v2_policy_state": (c_int, [c_void_p, c_void_p]),
+    "dcd_dcn_v2_policy_free": (c_int, []),
     "dcd_edge_depth_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int]
                                + [c_void_p] * 3),
     "dcd_edge_depth_backward": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int]

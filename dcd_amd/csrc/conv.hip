@@ -23,6 +23,7 @@
 #include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
+#include "tuning_env.h"
 #include "lds_limit.h"
 #include "bf16_split.h"
 
@@ -956,7 +957,7 @@ static ConvPlan conv_plan(int B, int Cc, int H, int W, int Kk)
         const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
         // split the contraction while the launch leaves CUs idle and a split keeps at least 4 chunks (its output transform
         // and the partial image it writes are not free; 4 vs 8: one image per GPU, 256 -> 256 @ 24x80 39 -> 32 us)
-        static const int min_chunks = getenv("DCD_CONV_MINCHUNK") ? atoi(getenv("DCD_CONV_MINCHUNK")) : 4;
+        static const int min_chunks = dcd_env("DCD_CONV_MINCHUNK") ? atoi(dcd_env("DCD_CONV_MINCHUNK")) : 4;
         int ks = 1;
         while (ks < 8 && wgs * (ks * 2) <= cus && p.nchunk / (ks * 2) >= min_chunks) ks *= 2;
         p.ksplit = ks;
@@ -1046,7 +1047,7 @@ static int conv3x3_run(hipStream_t stream, const float *input, const float *weig
     // contraction channels Cc and produced channels Kk of this call
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
     ConvPlan pl = conv_plan(B, Cc, H, W, Kk);
-    if (const char *e = getenv("DCD_CONV_GEOM")) {                     // A/B timing: "0" / "1" pins the region shape
+    if (const char *e = dcd_env("DCD_CONV_GEOM")) {                     // A/B timing: "0" / "1" pins the region shape
         const int g = atoi(e);
         if (g == 0 || g == 1) {
             ConvPlan q = pl;

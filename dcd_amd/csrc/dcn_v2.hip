@@ -32,10 +32,12 @@
 #include <stdlib.h>
 #include <string.h>
 #include <map>
+#include <vector>
 #include <mutex>
 #include <utility>
 
 #include "../../include/dcd_hip.h"
+#include "tuning_env.h"
 #include "lds_limit.h"
 
 typedef float f32x16 __attribute__((ext_vector_type(16)));
@@ -807,8 +809,8 @@ __device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int tota
 // which handed calls over at a third of the break-even density.  DCD_FAR_DIV / DCD_FAR_DIV_WIDE override (A/B timing).
 inline unsigned far_count_limit(const Geom &g, bool wide)
 {
-    static const int div = getenv("DCD_FAR_DIV") ? atoi(getenv("DCD_FAR_DIV")) : 0;
-    static const int div_wide = getenv("DCD_FAR_DIV_WIDE") ? atoi(getenv("DCD_FAR_DIV_WIDE")) : 0;
+    static const int div = dcd_env("DCD_FAR_DIV") ? atoi(dcd_env("DCD_FAR_DIV")) : 0;
+    static const int div_wide = dcd_env("DCD_FAR_DIV_WIDE") ? atoi(dcd_env("DCD_FAR_DIV_WIDE")) : 0;
     int d = wide ? div_wide : div;
     if (d <= 0) d = wide ? (g.B >= 4 ? 16 : 8) : (g.B >= 4 ? 24 : 12);
     const int64_t total = (int64_t)g.B * 18 * g.HoWo;
@@ -824,7 +826,13 @@ inline unsigned far_count_limit(const Geom &g, bool wide)
 // epilogue kernel stores its far count into a word of mapped pinned host memory (one plain store, no copy, no extra launch, works
 // inside a replayed graph too), and the layer's next call reads that word on the host.  Below half the limit the call runs
 // with the limit "never": no generic launches, no generic weight layouts.  Unknown (first call) or above: hand-over armed, as
-// before.  A sudden change of the offset statistics costs one slow call per layer.  State is keyed by (device, weight pointer).
+// before.  A sudden change of the offset statistics costs one slow call per layer.  State is keyed by (device, weight pointer):
+// the owner of a weight tensor says when that key dies -- dcd_dcn_v2_forget(weight) (dcd_amd's DCNv2 module calls it when it is
+// destroyed or its parameters move) drops the entry, so another tensor the allocator later puts at the same address starts as
+// "unknown" instead of inheriting the old layer's history.  A dropped entry's report word is reset and RECYCLED for the next new
+// layer, never unmapped: a HIP graph captured earlier may still hold its device address (its replays then write a far count into a
+// word some other layer reads -- that can cost that layer one slow or one armed call, never a wrong result); dcd_dcn_v2_policy_free
+// really frees everything, for a process that replays no such graph any more.
 // DCD_DCN_HANDOVER = always | never | auto (default).
 struct HandoverState {
     unsigned *host = nullptr;     // far coordinates of the layer's last finished call; 0xffffffff = none yet
@@ -832,12 +840,13 @@ struct HandoverState {
 };
 static std::mutex g_handover_mu;
 static std::map<std::pair<int, const void *>, HandoverState> g_handover;
+static std::map<int, std::vector<HandoverState>> g_handover_free;     // per device: report words of forgotten layers
 constexpr unsigned HANDOVER_UNKNOWN = 0xffffffffu;
 
 static int handover_mode()
 {
     static const int m = [] {
-        const char *e = getenv("DCD_DCN_HANDOVER");
+        const char *e = dcd_env("DCD_DCN_HANDOVER");
         if (e && !strcmp(e, "always")) return 1;
         if (e && !strcmp(e, "never")) return 0;
         return 2;
@@ -863,6 +872,13 @@ static int handover_decide(hipStream_t stream, const void *weight, unsigned real
     std::lock_guard<std::mutex> lock(g_handover_mu);
     HandoverState &h = g_handover[std::make_pair(dev, weight)];
     if (!h.host) {
+        std::vector<HandoverState> &fl = g_handover_free[dev];
+        if (!fl.empty()) {                                                // a forgotten layer's word (already reset to "unknown")
+            h = fl.back();
+            fl.pop_back();
+            *report = h.dev;
+            return 1;
+        }
         if (stream_is_capturing(stream)) return 1;                        // no allocation inside a capture
         unsigned *hp = nullptr, *dp = nullptr;
         if (hipHostMalloc((void **)&hp, sizeof(unsigned), hipHostMallocMapped) != hipSuccess ||
@@ -2397,7 +2413,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
 #ifndef DCN_NO_FWD_TILE
     // workgroup-tiled LDS kernel: the DLA-34 shape (3x3, stride 1, pad 1, dil 1, dg 1); maps of at least 16 rows
     if (kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 && (W & 3) == 0 &&
-        H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr) {
+        H >= 8 && W >= 32 && dcd_env("DCD_NO_TILE") == nullptr) {
         const int nz = (Cout + TL_OB - 1) / TL_OB;
         const int nchunk = split ? (Cin + TB_CH - 1) / TB_CH : (Cin + TL_CH - 1) / TL_CH;
         const size_t nwl = (size_t)nz * nchunk * (split ? TB_W_FLOATS : TL_W_FLOATS);
@@ -2405,7 +2421,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
             static LdsLimit lds_limit8, lds_limit4, lds_limit8b, lds_limit4b;
             static int tile_rows = 0;
             if (tile_rows == 0) {
-                const char *e = getenv("DCD_TILE_ROWS");
+                const char *e = dcd_env("DCD_TILE_ROWS");
                 tile_rows = (e && atoi(e) == 4) ? 4 : 8;
             }
             if (!lds_limit8.raise((int)(2 * TileCfg<8>::BUF * sizeof(float)), dcn_fwd_tile_f32<8>) ||
@@ -2418,7 +2434,7 @@ int dcd_dcn_v2_forward(void *stream_, const float *input, const float *weight, c
                 return DCD_ERR_LAUNCH;
             static int rescue_taps = 0;
             if (rescue_taps == 0) {
-                const char *e = getenv("DCD_FWD_RESCUE_TAPS");       // A/B: far taps in the worst wave that hand a region to the rescue kernel
+                const char *e = dcd_env("DCD_FWD_RESCUE_TAPS");       // A/B: far taps in the worst wave that hand a region to the rescue kernel
                 rescue_taps = (e && atoi(e) >= 1 && atoi(e) <= 10) ? atoi(e) : 5;
             }
             const int tiles_x = (g.Wo + 31) / 32;
@@ -2553,7 +2569,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     // one-pass backward wherever it applies (3x3 / stride 1 / pad 1, Cout <= 256; round 3: Cout <= 64 only), the dense path's
     // layers included: 256->64 @ 24x80 0.36 vs 0.50 ms.  DCD_BWD_SWEEP=2 keeps the dense path for the layers it takes,
     // DCD_SWEEP_WIDE=0 keeps round 3's limit of 64 outputs (A/B)
-    const char *sw_e = getenv("DCD_SWEEP_WIDE");              // read per call: the tests switch it inside one process
+    const char *sw_e = dcd_env("DCD_SWEEP_WIDE");              // read per call: the tests switch it inside one process
     const bool sweep_wide = !(sw_e && atoi(sw_e) == 0);
     // Cout 256 (the two deepest DGDE layers, Cin 512 / 256 on 12x40 / 24x80 maps) stays on the dense path when it applies: the
     // one-pass kernel gains little there (0.68 vs 0.73 ms, 0.46 vs 0.44) and those layers' offsets (fan-in 9 Cin) are large enough in
@@ -2754,12 +2770,12 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     while ((int64_t)tiles * B * nsplit < 1536 && nsplit * 2 <= nblk) nsplit *= 2;
 
     const bool tile_shape = kh == 3 && kw == 3 && sh == 1 && sw == 1 && ph == 1 && pw == 1 && dh == 1 && dw == 1 && dg == 1 &&
-                            (W & 3) == 0 && H >= 8 && W >= 32 && getenv("DCD_NO_TILE") == nullptr;
+                            (W & 3) == 0 && H >= 8 && W >= 32 && dcd_env("DCD_NO_TILE") == nullptr;
     // Cout <= 64: always.  Cout 128 (64 dY registers per lane): possible since the tap weights travel through LDS (no spills,
     // 191 VGPRs) but LDS then allows one workgroup per CU; A/B switch DCD_BD_TILE128=1.
     static int bd128 = -1;
     if (bd128 < 0) {
-        const char *e = getenv("DCD_BD_TILE128");
+        const char *e = dcd_env("DCD_BD_TILE128");
         bd128 = (e && atoi(e) == 1) ? 1 : 0;
     }
     const bool bd_tile_ok = tile_shape && (g.Cop == 64 || (g.Cop == 128 && bd128));
@@ -2792,19 +2808,19 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         // slice and lose to the register-gather kernel (measured: 128->128 1.56 vs 1.48 ms, 256->256 2.25 vs 1.64 ms per backward)
         static int bi_nblk = 0;                                  // A/B: DCD_BI_TILE_NBLK=4 lets the tiled kernel take 128-channel inputs
         if (bi_nblk == 0) {
-            const char *e = getenv("DCD_BI_TILE_NBLK");
+            const char *e = dcd_env("DCD_BI_TILE_NBLK");
             bi_nblk = e ? atoi(e) : 2;
             if (bi_nblk < 1) bi_nblk = 2;
         }
         const bool bi_tile_ok = tile_shape && nblk <= bi_nblk && (nblk <= 2 || g.Cop <= 64) && H < 65536 && W < 65536 &&
-                                getenv("DCD_NO_BI_TILE") == nullptr;
+                                dcd_env("DCD_NO_BI_TILE") == nullptr;
 #else
         const bool bi_tile_ok = false;
 #endif
         inv.packed = bi_tile_ok ? 1 : 0;
         static int bi_hybrid = -1;                               // A/B: DCD_BI_HYBRID=0 -> one kernel per call, chosen by the call-wide radius
         if (bi_hybrid < 0) {
-            const char *e = getenv("DCD_BI_HYBRID");
+            const char *e = dcd_env("DCD_BI_HYBRID");
             bi_hybrid = (e && atoi(e) == 0) ? 0 : 1;
         }
         inv.tileflag = (bi_tile_ok && bi_hybrid) ? tileflag : nullptr;
@@ -2826,7 +2842,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         const int total_blocks = dg * nblk;
         int mbi = total_blocks >= 8 ? 8 : total_blocks >= 4 ? 4 : total_blocks >= 2 ? 2 : 1;
         while (mbi > 1 && (int64_t)in_tiles * B * ((total_blocks + mbi - 1) / mbi) < 1024) mbi >>= 1;
-        if (const char *e = getenv("DCD_BI_MB")) {              // A/B timing of the channel blocks per workgroup
+        if (const char *e = dcd_env("DCD_BI_MB")) {              // A/B timing of the channel blocks per workgroup
             const int v = atoi(e);
             if ((v == 1 || v == 2 || v == 4 || v == 8) && v <= total_blocks) mbi = v;
         }
@@ -2888,12 +2904,12 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
             return DCD_ERR_LAUNCH;
         static int dw_gen = 0;                                 // A/B: DCD_DW_GEN=1 keeps the first-generation f32 kernel
         if (dw_gen == 0) {
-            const char *e = getenv("DCD_DW_GEN");
+            const char *e = dcd_env("DCD_DW_GEN");
             dw_gen = (e && atoi(e) == 1) ? 1 : 2;
         }
         static int dw_colmajor = -1;                           // A/B: DCD_DW_ORDER=0 walks the tiles row by row
         if (dw_colmajor < 0) {
-            const char *e = getenv("DCD_DW_ORDER");
+            const char *e = dcd_env("DCD_DW_ORDER");
             dw_colmajor = (e && atoi(e) == 0) ? 0 : 1;
         }
         const int tiles_x = (g.Wo + 31) / 32, tiles_y = (g.Ho + DW_TR - 1) / DW_TR;
@@ -2949,6 +2965,55 @@ int dcd_debug_sweep_profile(unsigned long long *host_out)
     return hipMemcpyFromSymbol(host_out, HIP_SYMBOL(sw_prof_buf), sizeof(unsigned long long) * 2048) == hipSuccess ? 0 : 1;
 }
 #endif
+
+int dcd_dcn_v2_forget(const float *weight)
+{
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return DCD_ERR_LAUNCH;
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    int n = 0;
+    for (auto it = g_handover.begin(); it != g_handover.end();) {
+        if (it->first.first == dev && (!weight || it->first.second == (const void *)weight)) {
+            if (it->second.host) {
+                *(volatile unsigned *)it->second.host = HANDOVER_UNKNOWN;
+                g_handover_free[dev].push_back(it->second);
+            }
+            it = g_handover.erase(it);
+            ++n;
+        } else {
+            ++it;
+        }
+    }
+    (void)n;
+    return DCD_OK;
+}
+
+int dcd_dcn_v2_policy_state(const float *weight, unsigned *far_count)
+{
+    int dev = 0;
+    if (!weight || hipGetDevice(&dev) != hipSuccess) return -1;
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    auto it = g_handover.find(std::make_pair(dev, (const void *)weight));
+    if (it == g_handover.end() || !it->second.host) return 0;
+    const unsigned far = *(volatile unsigned *)it->second.host;
+    if (far == HANDOVER_UNKNOWN) return 1;
+    if (far_count) *far_count = far;
+    return 2;
+}
+
+int dcd_dcn_v2_policy_free(void)
+{
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    for (auto &kv : g_handover)
+        if (kv.second.host) (void)hipHostFree(kv.second.host);
+    g_handover.clear();
+    for (auto &kv : g_handover_free)
+        for (HandoverState &h : kv.second)
+            if (h.host) (void)hipHostFree(h.host);
+    g_handover_free.clear();
+    (void)hipGetLastError();
+    return DCD_OK;
+}
 
 int dcd_dcn_offset_mask_split(void *stream_, const float *out, float *offset, float *mask, int B, int taps, int64_t HW)
 {

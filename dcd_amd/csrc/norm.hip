@@ -16,6 +16,7 @@
 #include <stdlib.h>
 
 #include "../../include/dcd_hip.h"
+#include "tuning_env.h"
 
 namespace {
 
@@ -505,7 +506,7 @@ __global__ __launch_bounds__(BT) void bn_small_bwd(const float *__restrict__ dy,
 
 inline bool small_channels(int B, int C, int64_t HW)
 {
-    static const bool off = getenv("DCD_BN_SMALL") && atoi(getenv("DCD_BN_SMALL")) == 0;      // A/B timing
+    static const bool off = dcd_env("DCD_BN_SMALL") && atoi(dcd_env("DCD_BN_SMALL")) == 0;      // A/B timing
     return !off && (HW & 3) == 0 && (int64_t)B * HW <= SM_MAX && C >= 64;
 }
 
@@ -704,7 +705,7 @@ int dcd_channel_sums(void *stream_, const float *x, int B, int C, int64_t HW, fl
     // The one-launch form pays an agent-scope release (an L2 write-back on gfx950) per workgroup: fine for a few hundred
     // workgroups, dearer than a second launch beyond (27 channels x 152 slices @ 96x320 x 8: 45 us against 12).  Same partials,
     // same summation order, same result either way.  DCD_CHANNEL_SUM_ONE_LAUNCH=1|0 pins the form (A/B timing).
-    static const int pin = getenv("DCD_CHANNEL_SUM_ONE_LAUNCH") ? atoi(getenv("DCD_CHANNEL_SUM_ONE_LAUNCH")) : -1;
+    static const int pin = dcd_env("DCD_CHANNEL_SUM_ONE_LAUNCH") ? atoi(dcd_env("DCD_CHANNEL_SUM_ONE_LAUNCH")) : -1;
     const bool one = pin >= 0 ? pin != 0 : (long)S * C <= 256;
     if (one) {
         hipLaunchKernelGGL(channel_sum_kernel, dim3(S, C), dim3(BT), 0, stream, x, g, S, (double *)ws, arrivals, sums);

@@ -14,6 +14,7 @@
 #include <stdint.h>
 
 #include "../../include/dcd_hip.h"
+#include "tuning_env.h"
 #include "zero_fill.h"
 
 namespace {
@@ -294,7 +295,7 @@ static int upsample_forward(hipStream_t stream, const float *x, const float *wei
     if ((f != 2 && f != 4 && f != 8) || ((W * f) & 3)) return DCD_ERR_BAD_ARG;
     const int no = H * f * W * f;
     dim3 grid((no / 4 + 255) / 256, B * C), block(256);
-    static const bool old_fwd = getenv("DCD_UP_FWD_OLD") != nullptr;                          // A/B timing
+    static const bool old_fwd = dcd_env("DCD_UP_FWD_OLD") != nullptr;                          // A/B timing
     if (f == 2 && !old_fwd)
         hipLaunchKernelGGL(up_dw_fwd2_block, dim3((H * (W / 2) + 255) / 256, B * C), block, 0, stream, x, weight, y, C, H, W, skip);
     else if (f == 2) hipLaunchKernelGGL(up_dw_fwd<2>, grid, block, 0, stream, x, weight, y, C, H, W, skip);
@@ -332,7 +333,7 @@ int dcd_upsample_dw_backward(void *stream_, const float *x, const float *weight,
     if (chunks < 1) chunks = 1;
     const int rows = (H + chunks - 1) / chunks;
     dim3 rgrid((H + rows - 1) / rows, B * C);
-    static const bool old_kernel = getenv("DCD_UP_BWD_OLD") != nullptr;                       // A/B timing
+    static const bool old_kernel = dcd_env("DCD_UP_BWD_OLD") != nullptr;                       // A/B timing
     if (f == 2 && !old_kernel) hipLaunchKernelGGL(up_dw_bwd_rows<2>, rgrid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W, rows);
     else if (f == 4 && !old_kernel) hipLaunchKernelGGL(up_dw_bwd_rows<4>, rgrid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W, rows);
     else if (f == 2) hipLaunchKernelGGL(up_dw_bwd<2>, grid, block, 0, stream, x, weight, grad_y, grad_x, grad_weight, C, H, W);

@@ -17,6 +17,11 @@ from dcd_amd import _ext as _backend
 from dcd_amd.model.layers.conv import Conv2d
 
 
+def _precision_scope():
+    from dcd_amd import _ext
+    return _ext.get_precision()
+
+
 class _DCNv2(Function):
     """Python-side autograd node of the op: argument order (input, offset, mask, weight, bias, ...) as in the reference's
     `_DCNv2` (dcn_v2.py:16-54); the extension takes (input, weight, bias, offset, mask, kh, kw, sh, sw, ph, pw, dh, dw, dg)."""
@@ -25,8 +30,10 @@ class _DCNv2(Function):
     def forward(ctx, input, offset, mask, weight, bias, stride, padding, dilation, deformable_groups, precision=None):
         kernel = tuple(weight.shape[2:4])
         ctx.geometry = (*kernel, *_pair(stride), *_pair(padding), *_pair(dilation), int(deformable_groups))
-        # None: the backend's current default (its precision scope) -- remembered for the backward, which runs outside the scope
-        ctx.precision = {"precision": _backend.get_precision() if precision is None else precision}
+        # None: the current precision scope -- remembered for the backward, which runs outside the scope.  Exact fp32 passes no
+        # keyword at all: `_backend` then only needs the reference's own signature (the host tests bind the oracle here)
+        p = _precision_scope() if precision is None else precision
+        ctx.precision = {} if p == "f32" else {"precision": p}
         ctx.save_for_backward(input, offset, mask, weight, bias)
         return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *ctx.geometry, **ctx.precision)
 
@@ -97,13 +104,14 @@ class _DCNWithOffsets(Function):
         from dcd_amd import ops
         input, w_off, weight = input.contiguous(), w_off.contiguous(), weight.contiguous()
         ctx.cprec = ops._conv_prec(input)                      # the backward runs outside the forward's precision scope
-        ctx.precision = _backend.get_precision()
+        p = _precision_scope()
+        ctx.precision = {} if p == "f32" else {"precision": p}
         tw, ctx.tw_back = (ops.conv3x3_step_weights(w_off, input) if ops._PREP_BOTH and ctx.needs_input_grad[0] else (None, None))
         out = ops._conv3x3_call(input, w_off, w_off.shape[0], False, b_off.contiguous(), transformed=tw, prec=ctx.cprec)
         offset, mask = _offset_mask_split(out)
         ctx.geometry = geometry
         ctx.save_for_backward(input, offset, mask, weight, bias, w_off)
-        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *geometry, precision=ctx.precision)
+        return _backend.dcn_v2_forward(input, weight, bias, offset, mask, *geometry, **ctx.precision)
 
     @staticmethod
     @once_differentiable
@@ -111,7 +119,7 @@ class _DCNWithOffsets(Function):
         from dcd_amd import ops
         input, offset, mask, weight, bias, w_off = ctx.saved_tensors
         grad_input, grad_offset, grad_mask, grad_weight, grad_bias = _backend.dcn_v2_backward(
-            input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry, precision=ctx.precision)
+            input, weight, bias, offset, mask, grad_output.contiguous(), *ctx.geometry, **ctx.precision)
         gout = _offset_mask_merge(grad_offset, grad_mask, mask)
         if ctx.needs_input_grad[0]:
             grad_input = ops._conv3x3_call(gout, w_off, w_off.shape[1], True, residual=grad_input.contiguous(), transformed=ctx.tw_back,
@@ -156,6 +164,27 @@ class DCNv2(nn.Module):
         bound = 1.0 / math.sqrt(fan_in)
         self.weight.data.uniform_(-bound, bound)
         self.bias.data.zero_()
+
+    # The library keeps a per-layer launch policy keyed by the weight's device address (include/dcd_hip.h, dcd_dcn_v2_forget): the
+    # module owns that address, so it says when the key dies -- when its parameters move (.to / .cuda / .float: `_apply`) and when
+    # it is destroyed.  Another tensor the caching allocator later places at the same address then starts as "unknown".
+    def _forget_policy(self):
+        w = self._parameters.get("weight") if hasattr(self, "_parameters") else None
+        if w is None or not w.is_cuda:
+            return
+        try:
+            from dcd_amd import _lib
+            with torch.cuda.device(w.device):
+                _lib.lib().dcd_dcn_v2_forget(w.data_ptr())
+        except Exception:                         # interpreter shutdown, library not built: nothing to forget
+            pass
+
+    def _apply(self, fn, *args, **kwargs):
+        self._forget_policy()
+        return super()._apply(fn, *args, **kwargs)
+
+    def __del__(self):
+        self._forget_policy()
 
     def forward(self, input, offset, mask):
         taps = self.deformable_groups * self.kernel_size[0] * self.kernel_size[1]

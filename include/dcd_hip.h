@@ -29,6 +29,39 @@ extern "C" {
 const char *dcd_version(void);
 
 /* ------------------------------------------------------------------------------------------------
+ * Environment.  The library's RESULTS never depend on the process environment (beyond summation order); which of two equivalent
+ * launch sequences a call takes can: the variables below are A/B-timing and test switches read through dcd_env()
+ * (csrc/tuning_env.h) -- some once per process (static), some per call (marked *).  Building with -DDCD_NO_TUNING_ENV compiles
+ * every read out (each switch then keeps the default given here).  tests/test_abi.py checks this list against the sources.
+ *   DCD_DCN_HANDOVER     auto (default) | always | never: who takes the far samples of a one-pass DCN backward -- per layer from
+ *                        its previous call's far count (auto), the device-side hand-over to the generic kernels armed on every
+ *                        call (always), or never armed.  See dcd_dcn_v2_forget below.
+ *   DCD_FAR_DIV, DCD_FAR_DIV_WIDE   integer d > 0: hand a one-pass backward call to the generic kernels above 1 far coordinate in
+ *                        d (Cout <= 64 / wider).  Default 24 / 16 at >= 4 images, 12 / 8 below.
+ *   DCD_BWD_SWEEP *      0: three-pass DCN backward everywhere; 2: layers the dense path takes stay on it; default 1: one-pass
+ *                        backward wherever it applies.
+ *   DCD_SWEEP_WIDE *     0: one-pass backward for Cout <= 64 only (round 3's limit).  Default: Cout <= 128, and 256 where the
+ *                        dense path does not apply.
+ *   DCD_SWEEP_SLOTS *    waves of a one-pass backward launch (0: one work unit per wave).  Default: one round of resident waves.
+ *   DCD_DCN_DENSE *      0: never the column-buffer path; 1: every geometry it can take; default: Cin >= 256 only.
+ *   DCD_NO_TILE *        set: the workgroup-tiled LDS kernels (forward, generic backward) stand down for the register-gather ones.
+ *   DCD_TILE_ROWS        4: forward regions of 4 rows always.  Default 8 rows when that fills the chip.
+ *   DCD_FWD_RESCUE_TAPS  1..10: far taps in a region's worst wave that hand the region to the rescue kernel.  Default 5.
+ *   DCD_BD_TILE128       1: the tiled generic data-gradient kernel also for Cout 128.  Default off.
+ *   DCD_BI_TILE_NBLK     input-channel blocks (of 32) up to which the tiled generic grad_input kernel is used.  Default 2.
+ *   DCD_NO_BI_TILE *     set: never the tiled generic grad_input kernel.
+ *   DCD_BI_HYBRID        0: one generic grad_input kernel per call, chosen by the call-wide offset radius.  Default: per tile.
+ *   DCD_BI_MB *          1 | 2 | 4 | 8: channel blocks per workgroup of the register-gather grad_input kernel.  Default: by size.
+ *   DCD_DW_GEN           1: first-generation generic grad_weight kernel.  Default 2.
+ *   DCD_DW_ORDER         0: the generic grad_weight kernel walks its tiles row by row.  Default: down column strips.
+ *   DCD_CONV_GEOM *      0 | 1: pin the Winograd region shape (8 x 32 / 12 x 20 px), no split contraction.  Default: by cost model.
+ *   DCD_CONV_MINCHUNK    smallest number of 8-channel chunks a split of the Winograd contraction keeps.  Default 4.
+ *   DCD_BN_SMALL         0: no single-workgroup-per-channel BatchNorm kernels for small maps.  Default on.
+ *   DCD_CHANNEL_SUM_ONE_LAUNCH   1 | 0: pin the per-channel sums to the one-launch / two-launch form.  Default: by grid size.
+ *   DCD_UP_FWD_OLD, DCD_UP_BWD_OLD   set: the round-1 depthwise up-sampling kernels.
+ * ---------------------------------------------------------------------------------------------- */
+
+/* ------------------------------------------------------------------------------------------------
  * DCNv2 (modulated deformable convolution).
  * Replaces `_ext.dcn_v2_forward` / `_ext.dcn_v2_backward`
  *   DGDE/model/backbone/DCNv2/DCN/src/dcn_v2.h:9-46, :48-92            (dispatch)
@@ -74,6 +107,23 @@ int dcd_dcn_v2_backward(void *stream, const float *input, const float *weight, c
                         float *grad_offset, float *grad_mask, float *grad_weight, float *grad_bias, int B,
                         int Cin, int H, int W, int Cout, int kh, int kw, int sh, int sw, int ph, int pw, int dh,
                         int dw, int dg, int precision, void *workspace, size_t workspace_bytes);
+
+/* Per-layer launch policy of the DCNv2 op (csrc/dcn_v2.hip, "Who takes the far samples").  The library remembers, per
+ * (device, weight pointer), the far-sample count of the layer's last backward call (a word of mapped pinned host memory the
+ * call's last kernel stores to) and chooses the next call's launch sequence from it -- never its result.
+ *   dcd_dcn_v2_forget(weight)   the owner of `weight` (current device) tells the library that this address no longer names that
+ *                               layer (tensor freed, moved, re-used): the entry is dropped, the next call on that address starts as
+ *                               "unknown" (hand-over armed).  weight = NULL: every entry of the current device.  The dropped
+ *                               entry's report word is reset and recycled, not unmapped (a HIP graph captured earlier may still
+ *                               store to it).
+ *   dcd_dcn_v2_policy_state(weight, &far)   0: no entry; 1: entry, no report yet; 2: *far = the last reported far count; -1: error.
+ *   dcd_dcn_v2_policy_free()    frees all policy state of the process (all devices).  Only when no captured graph containing
+ *                               DCN backward calls will be replayed again.
+ * A CAPTURED call freezes its decision: a graph captured while a layer's offsets were small replays the "never hand over" sequence
+ * (correct for any offsets, slower beyond the far-count limit) until it is captured again. */
+int dcd_dcn_v2_forget(const float *weight);
+int dcd_dcn_v2_policy_state(const float *weight, unsigned *far_count);
+int dcd_dcn_v2_policy_free(void);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge-constraint depth solver.

@@ -37,3 +37,22 @@ def test_workspace_query_is_pure_host_code():
     n = L.dcd_dcn_v2_workspace_bytes(8, 64, 96, 320, 64, 3, 3, 1, 1, 1, 1, 1, 1, 1)
     assert n >= 2 * 64 * 576 * 4
     assert L.dcd_dcn_v2_workspace_bytes(8, 64, 96, 320, 64, 3, 3, 0, 1, 1, 1, 1, 1, 1) == 0   # stride 0 is invalid
+
+
+def test_header_lists_every_environment_variable_the_library_reads():
+    """include/dcd_hip.h "Environment" == the names passed to dcd_env() in csrc/ (the only way the library reads its environment:
+    no raw getenv), so a maintainer linking the library can see -- or compile out, -DDCD_NO_TUNING_ENV -- every switch."""
+    import glob
+    src = ""
+    for p in glob.glob(os.path.join(ROOT, "dcd_amd", "csrc", "*")):
+        if p.endswith((".hip", ".inc", ".h")):
+            text = open(p).read()
+            if not p.endswith("tuning_env.h"):
+                assert not re.search(r"(?<![A-Za-z_])getenv\s*\(", text), "%s reads the environment directly" % p
+            src += text
+    used = set(re.findall(r'dcd_env\("([A-Z0-9_]+)"\)', src))
+    header = open(os.path.join(ROOT, "include", "dcd_hip.h")).read()
+    start = header.index(" * Environment.")
+    env_section = header[start:header.index("*/", start)]
+    listed = set(re.findall(r"\b(DCD_[A-Z0-9_]+)\b", env_section)) - {"DCD_NO_TUNING_ENV"}
+    assert used and used == listed, (sorted(used - listed), sorted(listed - used))

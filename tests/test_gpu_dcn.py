@@ -645,3 +645,45 @@ def test_dcn_module_as_one_node_equals_three_nodes(cuda, monkeypatch, B, C, Co, 
     for a, b, what in zip(res[0], res[1], ("output", "grad_input", "grad_weight", "grad_bias", "grad_offset_weight", "grad_offset_bias")):
         scale = max(b.abs().max().item(), 1e-6)
         assert (a - b).abs().max().item() <= 2e-6 * scale, what
+
+
+def test_launch_policy_is_forgotten_with_its_weight(cuda):
+    """VERDICT r4 item 8 / ADVICE r4: the per-layer hand-over policy is keyed by the weight's device address.  A layer that has run
+    backward calls has a report; once its module is destroyed (or moved) the key is dropped, so a NEW layer whose weight the caching
+    allocator places at the SAME address starts as "unknown" (no entry) instead of inheriting the old layer's far history."""
+    import ctypes
+    import gc
+    from dcd_amd import _lib
+    from dcd_amd.model.backbone.DCNv2.dcn_v2 import DCN
+    L = _lib.lib()
+
+    def state(ptr):
+        far = ctypes.c_uint(0)
+        st = L.dcd_dcn_v2_policy_state(ptr, ctypes.byref(far))
+        return st, far.value
+
+    torch.cuda.synchronize()
+    layer = DCN(64, 64, (3, 3), 1, 1).to(cuda)
+    ptr = layer.weight.data_ptr()
+    assert state(ptr)[0] == 0
+    x = torch.randn(2, 64, 24, 64, device=cuda, requires_grad=True)
+    for _ in range(2):
+        layer(x).sum().backward()
+    torch.cuda.synchronize()
+    st, far = state(ptr)
+    assert st == 2 and far == 0, (st, far)              # zero-initialised offset conv: no far samples, reported
+    del layer
+    gc.collect()
+    assert state(ptr)[0] == 0, "the destroyed layer's policy entry survived"
+    # same size, same allocator pool: the new weight lands on the freed block
+    other = DCN(64, 64, (3, 3), 1, 1).to(cuda)
+    if other.weight.data_ptr() == ptr:
+        assert state(ptr)[0] == 0
+        other(x).sum().backward()
+        torch.cuda.synchronize()
+        assert state(ptr)[0] == 2
+    # a module whose parameters move forgets the old address
+    moved = other.weight.data_ptr()
+    other.double().float()
+    assert state(moved)[0] == 0
+    assert L.dcd_dcn_v2_forget(None) == 0

@@ -345,7 +345,7 @@ def test_model_fp16_flag_trains_in_bf16_autocast(cuda):
             loss_dict, _ = train_step(model, opt, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
         finally:
             _ext.dcn_v2_forward, _ext.dcn_v2_backward, ops._conv3x3_wrw_call, ops._conv3x3_call = fwd, bwd, wrw, call
-        want = "bf16" if fp16 else "f32"
+        want = "bf16" if fp16 else None                   # exact fp32: no keyword at all (the reference's own signature)
         assert len(seen) == 16 and all(p == want for p in seen), seen
         assert len(seen_bwd) == 16 and all(p == want for p in seen_bwd), seen_bwd
         assert _ext.get_precision() == "f32"
