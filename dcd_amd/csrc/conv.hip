@@ -716,7 +716,70 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
         dy_q[k] = rem & 7;
     }
     f32x4 rin[KIN], rdy[KDY];
-    auto issue = [&](int t) {
+    // BF: another staging map and buffer loads.  The fp32 form's map (above) costs it nothing -- its addresses and masks live in
+    // registers the 64-cycle MFMAs leave time to spill around -- but in the one-product form the same code spilled the per-load
+    // 64-bit addresses, and every reload's s_waitcnt vmcnt(0) also waited for the PREVIOUS prefetch load: seven serialised round
+    // trips per strip (the kernel ran slower than the fp32 one).  Here thread = (channel tid >> 3, j = tid & 7) takes the items
+    // i = j + 8 k (k < 5) of its channel's 4 x 10 dwordx4 (row = i / 10, q = i % 10 by one compare against a constant; LDS offset
+    // ch * plane + 4 i), dY thread = (o = tid >> 4 (+ 32 k), row, q); one descriptor per tensor (base + byte count in SGPRs), ONE
+    // invariant 32-bit lane offset per load, the strip's part a scalar, out-of-range = the load is dropped and returns zeros.
+    // (the thread's indices are re-derived from its id inside each call, behind an opaque copy: hoisted out of the strip loop they
+    // are five more live registers in a kernel that has none to spare -- two spilled, and their reloads brought the waits back)
+    constexpr int BF_OOB = 0x7ffffff0;
+    __amdgpu_buffer_rsrc_t bf_rx, bf_rg;
+    if constexpr (BF) {
+        bf_rx = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(x), 0, (int)((size_t)B * Cin * HW * 4), 0x00020000);
+        bf_rg = __builtin_amdgcn_make_buffer_rsrc(const_cast<float *>(gy), 0, (int)((size_t)B * Cout * HW * 4), 0x00020000);
+    }
+    auto issue_bf = [&](int t) {
+        const int b = t / (tiles_y * strips_x);
+        const int rem = t - b * (tiles_y * strips_x);
+        const int ty = rem / strips_x, sx = rem - ty * strips_x;
+        const int r0 = 2 * ty, c0 = 32 * sx;
+        const int sx_ = ((b * Cin + cg * 64) * HW + (r0 - 1) * W + c0 - 4) * 4;          // scalar parts (may be negative)
+        const int sg_ = ((b * Cout + og * KO) * HW + r0 * W + c0) * 4;
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        const int bf_ch = tt >> 3, bf_j = tt & 7;
+        const int bf_do = tt >> 4, bf_drow = (tt >> 3) & 1, bf_dq = tt & 7;
+        const bool chv = cg * 64 + bf_ch < Cin;
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            constexpr int RB[5] = {0, 0, 1, 2, 3}, QB[5] = {0, 8, 6, 4, 2};               // divmod(8 k, 10)
+            const bool wrap = bf_j + QB[k] >= 10;
+            const int row = RB[k] + (wrap ? 1 : 0), q = bf_j + QB[k] - (wrap ? 10 : 0);
+            const int yy = r0 - 1 + row, xx = c0 - 4 + 4 * q;
+            const bool ok = chv && yy >= 0 && yy < H && xx >= 0 && xx < W;
+            const int voff = ok ? sx_ + (bf_ch * HW + row * W + 4 * q) * 4 : BF_OOB;
+            rin[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bf_rx, voff, 0, 0));
+        }
+#pragma unroll
+        for (int k = 0; k < KDY; ++k) {
+            const int o = bf_do + 32 * k;
+            const bool ok = og * KO + o < Cout && c0 + 4 * bf_dq < W;
+            const int voff = ok ? sg_ + (o * HW + bf_drow * W + 4 * bf_dq) * 4 : BF_OOB;
+            rdy[k] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(bf_rg, voff, 0, 0));
+        }
+    };
+    auto commit_bf = [&](float *buf) {
+        int tt = tid;
+        asm volatile("" : "+v"(tt));
+        const int bf_ch = tt >> 3, bf_j = tt & 7;
+        const int bf_do = tt >> 4, bf_drow = (tt >> 3) & 1, bf_dq = tt & 7;
+#pragma unroll
+        for (int k = 0; k < KIN; ++k) {
+            float *d = buf + bf_ch * WW_IPLANE + 4 * bf_j + 32 * k;
+            *reinterpret_cast<f32x2 *>(d) = f32x2{rin[k].x, rin[k].y};
+            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rin[k].z, rin[k].w};
+        }
+#pragma unroll
+        for (int k = 0; k < KDY; ++k) {
+            float *d = buf + WW_IN + (bf_do + 32 * k) * WW_DPLANE + bf_drow * 32 + 4 * bf_dq;
+            *reinterpret_cast<f32x2 *>(d) = f32x2{rdy[k].x, rdy[k].y};
+            *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rdy[k].z, rdy[k].w};
+        }
+    };
+    auto issue_f32 = [&](int t) {
         const int b = t / (tiles_y * strips_x);
         const int rem = t - b * (tiles_y * strips_x);
         const int ty = rem / strips_x, sx = rem - ty * strips_x;
@@ -739,7 +802,7 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
                 rdy[k] = *reinterpret_cast<const f32x4 *>(g_b + (size_t)dy_o[k] * HW + yy * W + xx);
         }
     };
-    auto commit = [&](float *buf) {
+    auto commit_f32 = [&](float *buf) {
 #pragma unroll
         for (int k = 0; k < KIN; ++k) {
             float *d = buf + in_ch[k] * WW_IPLANE + in_row[k] * WW_IROW + 4 * in_q[k];
@@ -753,6 +816,9 @@ __global__ __launch_bounds__(WW_NT) void wino_wrw3x3_f32(const float *__restrict
             *reinterpret_cast<f32x2 *>(d + 2) = f32x2{rdy[k].z, rdy[k].w};
         }
     };
+
+    auto issue = [&](int t) { if constexpr (BF) issue_bf(t); else issue_f32(t); };
+    auto commit = [&](float *buf) { if constexpr (BF) commit_bf(buf); else commit_f32(buf); };
 
     f32x16 acc[4][NOB];
 #pragma unroll

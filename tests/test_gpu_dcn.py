@@ -197,7 +197,8 @@ def test_bf16_path_is_the_one_product_kernel(cuda, shape):
     for name, p32, p16 in zip(("grad_input", "grad_offset", "grad_mask", "grad_weight"), g32, g16):
         rel = (p32 - p16).abs().max().item() / p32.abs().max().item()
         assert 1e-4 < rel < BF16_TOL, (name, shape, rel)
-    assert torch.allclose(g32[4], g16[4], rtol=1e-6, atol=0)
+    # the bias gradient is a plain fp32 sum of dY in both (partial sums meet in atomics: equal to summation order)
+    assert (g32[4] - g16[4]).abs().max().item() <= 1e-5 * g32[4].abs().max().item()
 
 
 @pytest.mark.parametrize("geom", [(64, 64, 96, 320), (256, 128, 24, 80)])

@@ -85,7 +85,7 @@ def check_loss_computation(device, tol, through_row_kernel=False):
     assert rel(reg.grad.abs().sum((0, 2, 3)).cpu().numpy(), g["grad_reg_abs_per_channel"]) <= tol
 
 
-def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2, decode_min_match=0.8):
+def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2, decode_min_match=0.8, sparse_tol=1e-4):
     """Whole KeypointDetector vs a fixture of the reference's run: `truth` = "model_96x320" (the reference in fp32 on the CPU)
     or "model_96x320_f64" (the reference in float64: the exact result up to ~1e-12).  tol: activations; loss_tol: the 13
     losses (default tol); gtol: per-parameter gradient norms, relative to the norm (floored at 1e-4 of the largest)."""
@@ -108,8 +108,9 @@ def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_t
     cx = torch.stack([t.get_field("target_centers") for t in targets]).long()
     bidx = torch.arange(cx.shape[0], device=cx.device).view(-1, 1).expand(-1, cx.shape[1])
     dense_at = pred["reg"][bidx, :, cx[:, :, 1], cx[:, :, 0]]                       # B x M x 415
-    assert (sparse["reg_pois"] - dense_at).abs().max().item() <= 1e-4 * max(dense_at.abs().max().item(), 1.0)
-    assert (sparse["cls"] - pred["cls"]).abs().max().item() <= 1e-5
+    # (sparse_tol: in mixed precision the dense trunks run their 3x3 products in bf16, the trunks at listed positions in fp32)
+    assert (sparse["reg_pois"] - dense_at).abs().max().item() <= sparse_tol * max(dense_at.abs().max().item(), 1.0)
+    assert (sparse["cls"] - pred["cls"]).abs().max().item() <= max(1e-5, sparse_tol * 0.1)
     def rel(a, key):
         a = a.detach().cpu().numpy()
         return np.abs(a - g[key]).max() / (np.abs(g[key]).max() + 1e-12)
