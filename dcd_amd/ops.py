@@ -888,18 +888,30 @@ class _PreparedWeights:
     A layer enters the table the first time `_Conv3x3.forward` sees its weight (that call still transforms its own copy).
     An entry is only used while it is provably current: same storage, and `weight._version` equal to the version the last
     refresh transformed -- an optimizer step, a `load_state_dict` or any other in-place write in between sends the call back
-    to its own transform.  Entries hold weak references; a dead weight drops out at the next refresh."""
+    to its own transform (a write that BYPASSES the version counter -- `p.data.*`, a raw-pointer kernel, a replayed graph that
+    is not GraphedTrainStep -- must be followed by `invalidate_conv_weights()`).  Entries hold weak references; a dead weight
+    drops out at the next refresh.
+
+    HIP graphs: a captured `refresh()` bakes the address of `self.table` into the graph, a captured convolution the
+    addresses of its entry's buffers.  From the first lookup / refresh under capture on, nothing a capture may have seen is ever
+    released: replaced tables and the buffers of removed entries move to `self._immortal` (a table rebuild happens when another
+    model registers its convolutions or a parameter's storage moves -- a handful of times per process, a few MB each), so a live
+    graph replays against memory that is still ours -- stale for a layer that no longer exists, never recycled."""
 
     def __init__(self):
         self.entries = {}          # id(weight) -> [weakref, data_ptr, forward buffer, backward buffer, version at refresh]
         self.table = None          # device int64 (n, 5) the kernel reads
         self.order = []
         self.dirty = False
+        self.captured = False      # a capture has read the table or an entry's buffers
+        self._immortal = []
 
     def lookup(self, weight):
         e = self.entries.get(id(weight))
         if e is None or e[0]() is not weight or e[1] != weight.data_ptr() or e[4] != weight._version:
             return None
+        if not self.captured and torch.cuda.is_current_stream_capturing():
+            self.captured = True
         return e
 
     def register(self, weight):
@@ -922,16 +934,24 @@ class _PreparedWeights:
         dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[1]]
         if (dead or self.dirty) and torch.cuda.is_current_stream_capturing():
             return                                     # no table upload inside a capture: the calls transform their own weights
+        if torch.cuda.is_current_stream_capturing():
+            self.captured = True                       # this refresh (table address + every entry's buffers) is part of a graph
         for k in dead:
+            if self.captured:
+                self._immortal.append((self.entries[k][2], self.entries[k][3]))
             del self.entries[k]
             self.dirty = True
         if not self.entries:
+            if self.captured and self.table is not None:
+                self._immortal.append(self.table)
             self.table = None
             return
         if self.dirty or self.table is None:
             self.order = list(self.entries.values())
             dev = self.order[0][2].device
             rows = [[e[1], e[2].data_ptr(), e[3].data_ptr(), e[0]().shape[1], e[0]().shape[0]] for e in self.order]
+            if self.captured and self.table is not None:
+                self._immortal.append(self.table)      # a live graph may still launch the transform on the old table
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.dirty = False
         st = _lib.lib().dcd_conv3x3_transform_weights_table(_lib.stream_of(self.table), self.table.data_ptr(), len(self.order))
@@ -1249,8 +1269,10 @@ def channel_sums(gy):
     ws = _CHANNEL_SUM_WS.get(key)
     if ws is None:
         ws = _CHANNEL_SUM_WS[key] = torch.zeros(L.dcd_bn_workspace_bytes(C), dtype=torch.uint8, device=gy.device)
-    _lib.check(L.dcd_channel_sums(st, gy.data_ptr(), B, C, HW, sums.data_ptr(), ws.data_ptr(), ws.numel()),
-               "dcd_channel_sums")
+    status = L.dcd_channel_sums(st, gy.data_ptr(), B, C, HW, sums.data_ptr(), ws.data_ptr(), ws.numel())
+    if status != 0:
+        _CHANNEL_SUM_WS.pop(key, None)                 # a failed launch may have left arrival counters behind: start afresh
+    _lib.check(status, "dcd_channel_sums")
     return sums
 
 

@@ -1,0 +1,96 @@
+"""Host logic of engine.trainer.GraphedTrainStep that needs no GPU: when it captures, re-captures and refuses (VERDICT r4:
+the captured step freezes the DCNv2 launch policy -> a re-capture hook; data-parallel ranks must not capture a second input
+signature while their peers replay the first), and of ops._PreparedWeights under capture (nothing a graph has seen is
+released)."""
+import pytest
+import torch
+from torch import nn
+
+
+class _FakeGraph:
+    def __init__(self, log):
+        self.log = log
+
+    def replay(self):
+        self.log.append("replay")
+
+
+def _step(distributed=False, recapture_every=None):
+    from dcd_amd.engine.trainer import GraphedTrainStep
+    model = nn.Linear(2, 2)
+    g = GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=0.1), recapture_every=recapture_every)
+    log = []
+    g._signature = staticmethod(lambda images, targets: (tuple(images.shape),))
+    g._capture = lambda images, targets: (log.append("capture"), {"static": None, "graph": _FakeGraph(log), "out": ({}, {})})[1]
+    g._copy_in = lambda entry, images, targets: None
+    if distributed:                      # the vote without a process group: every rank captured
+        g.distributed = True
+        g.agree = lambda ok: ok
+    return g, log
+
+
+def test_recapture_every_n_replays_and_on_demand():
+    g, log = _step(recapture_every=3)
+    x = torch.zeros(1, 3, 4, 4)
+    for _ in range(7):
+        g(x, [])
+    # capture, 3 replays, capture again (the launch decisions of THAT moment), 3 replays, capture, 1 replay
+    assert log == ["capture"] + ["replay"] * 3 + ["capture"] + ["replay"] * 3 + ["capture", "replay"]
+    g.recapture()
+    g(x, [])
+    assert log[-2:] == ["capture", "replay"]
+    g2, log2 = _step()
+    for _ in range(5):
+        g2(x, [])
+    assert log2 == ["capture"] + ["replay"] * 5           # default: one capture per signature
+
+
+def test_data_parallel_step_refuses_a_second_signature():
+    g, log = _step(distributed=True)
+    a, b = torch.zeros(2, 3, 4, 4), torch.zeros(1, 3, 4, 4)
+    g(a, [])
+    g(a, [])
+    with pytest.raises(RuntimeError, match="signature changed"):
+        g(b, [])                                           # peers may be replaying `a` right now: no capture, no collectives
+    assert log == ["capture", "replay", "replay"]
+    g.recapture()                                          # every rank agreed to change the shape
+    g(b, [])
+    assert log[-2:] == ["capture", "replay"]
+    # without data parallelism a second signature is simply captured beside the first
+    g1, log1 = _step()
+    g1(a, [])
+    g1(b, [])
+    g1(a, [])
+    assert log1 == ["capture", "replay", "capture", "replay", "replay"]
+
+
+def test_prepared_weights_keep_what_a_capture_has_seen(monkeypatch):
+    """_PreparedWeights: once a lookup / refresh ran under capture, replaced tables and removed entries' buffers stay referenced."""
+    from dcd_amd import ops
+    p = ops._PreparedWeights()
+    w1, w2 = nn.Parameter(torch.zeros(4, 4, 3, 3)), nn.Parameter(torch.zeros(4, 4, 3, 3))
+    bufs = {id(w): (torch.zeros(3), torch.zeros(3)) for w in (w1, w2)}
+    import weakref
+    for w in (w1, w2):
+        p.entries[id(w)] = [weakref.ref(w), w.data_ptr(), bufs[id(w)][0], bufs[id(w)][1], w._version]
+    p.table = torch.zeros(2, 5, dtype=torch.int64)
+    old_table = p.table
+    capturing = {"on": True}
+    monkeypatch.setattr(torch.cuda, "is_current_stream_capturing", lambda: capturing["on"])
+    assert p.lookup(w1) is not None and p.captured       # a captured convolution read this entry's buffers
+    capturing["on"] = False
+
+    class _L:
+        @staticmethod
+        def dcd_conv3x3_transform_weights_table(*a):
+            return 0
+    monkeypatch.setattr(ops._lib, "lib", lambda: _L)
+    monkeypatch.setattr(ops._lib, "stream_of", lambda t: None)
+    del w, w2                                             # a layer dies: its entry leaves the table at the next refresh
+    import gc
+    gc.collect()
+    p.refresh()
+    assert len(p.entries) == 1 and p.table is not old_table
+    kept = [x for item in p._immortal for x in (item if isinstance(item, tuple) else (item,))]
+    assert any(x is old_table for x in kept), "the table a live graph may still launch on was released"
+    assert sum(1 for x in kept if x.shape == (3,)) == 2, "the removed entry's buffers were released"
