@@ -27,6 +27,10 @@ class Conv2d(nn.Conv2d):
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros" and torch.is_grad_enabled()
                 and self.weight.requires_grad and ops.conv3x3_wrw_only_supported(x, self.weight)):
             return ops.conv3x3_stock_forward(x, self.weight)
+        if (_ENABLED and self.bias is None and self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
+                and ops.conv3x3_stride2_supported(x, self.weight)):
+            return ops.conv3x3_stride2(x, self.weight)
         if (_ENABLED and _STEM and self.bias is None and self.padding_mode == "zeros" and not isinstance(self.padding, str)
                 and ops.conv_stem_supported(x, self.weight, self.stride, self.padding, self.dilation, self.groups)
                 and (self.weight.shape[1] == 16 or not x.requires_grad)):

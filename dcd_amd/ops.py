@@ -1093,6 +1093,58 @@ def conv3x3_with_skip(x, weight):
     return _Conv3x3Skip.apply(x, weight)
 
 
+# ----------------------------------------------------------------------------------------------
+# 3x3 / stride 2 / pad 1 convolution (the first convolution of every DLA level, DGDE/model/backbone/dla_dcn.py:76-78,313-326)
+# on the stride-1 Winograd kernels, through space-to-depth
+# ----------------------------------------------------------------------------------------------
+_S2D_INDEX = {}
+_S2D_MODE = os.environ.get("DCD_CONV_S2D", "auto")      # 1: always, 0: never (stock solver), auto: in the bf16 precision modes
+
+
+def _s2d_index(K, C, device):
+    """Flat gather index of the (K, 4C, 3, 3) space-to-depth filter into [weight.flatten(), 0]: channel c * 4 + 2 rp + cp of the
+    pixel-unshuffled input holds pixel (2 i + rp, 2 j + cp) of channel c, and tap a of the stride-2 filter reads row 2 i + a - 1:
+    the odd row of s2d row i - 1 (a = 0), the even row of s2d row i (a = 1), the odd row of s2d row i (a = 2); likewise columns."""
+    key = (K, C, str(device))
+    idx = _S2D_INDEX.get(key)
+    if idx is None:
+        tap = {0: {1: 1}, 1: {0: 0, 1: 2}}                # parity -> {s2d tap A: original tap a}
+        idx = torch.full((K, C, 2, 2, 3, 3), K * C * 9, dtype=torch.int64)
+        base = torch.arange(K * C, dtype=torch.int64).view(K, C) * 9
+        for rp in (0, 1):
+            for A, a in tap[rp].items():
+                for cp in (0, 1):
+                    for Bc, b in tap[cp].items():
+                        idx[:, :, rp, cp, A, Bc] = base + a * 3 + b
+        idx = _S2D_INDEX[key] = idx.reshape(-1).to(device)
+    return idx
+
+
+def conv3x3_stride2_supported(x, weight):
+    """Stride-2 layers the space-to-depth form takes: even H, W % 8 == 0 (the half-resolution map must satisfy the stride-1 kernel's
+    W % 4 == 0, H even -> H % 4 == 0), at least 64 channels after the regrouping (4 Cin) and a half-resolution map of 12 x 40."""
+    if _S2D_MODE == "0" or not (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if _S2D_MODE != "1" and _conv_prec() == PREC_F32:
+        return False
+    H, W = x.shape[2], x.shape[3]
+    return H % 4 == 0 and W % 8 == 0 and 4 * weight.shape[1] >= 64 and (H // 2) * (W // 2) >= _CONV_MIN_MAP
+
+
+def conv3x3_stride2(x, weight):
+    """conv2d(x, weight, stride 2, padding 1) = conv3x3(pixel_unshuffle(x, 2), W4) with the (Cout, 4 Cin, 3, 3) filter W4 that holds
+    the nine taps at their space-to-depth positions and zeros elsewhere (27 of 36): forward, input gradient and weight gradient all
+    on csrc/conv.hip (the stock path: MIOpen implicit GEMM in NHWC with a transpose of every operand, 3.5 ms per bs-8 step for the
+    five layers).  The regrouped filter does 4x the multiplies of the direct form -- in the bf16 precision modes they run on matrix
+    cores with 16x the fp32 rate and the kernels are bound by their transform arithmetic, i.e. by the 4 Cin channels at a quarter
+    of the pixels = the cost of a stride-1 layer at full resolution.  Filter regrouping and its gradient are one gather / one
+    scatter-add of 36 Cout Cin values (autograd)."""
+    K, C = weight.shape[0], weight.shape[1]
+    idx = _s2d_index(K, C, weight.device)
+    w4 = torch.cat([weight.reshape(-1), weight.new_zeros(1)])[idx].view(K, 4 * C, 3, 3)
+    return conv3x3(torch.nn.functional.pixel_unshuffle(x, 2), w4)
+
+
 def conv3x3_wrw_only_supported(x, weight):
     """Maps below the forward kernel's limit (only when DCD_CONV_MIN_MAP raises it) where the weight-gradient kernel still
     wins (256->256 @ 24x80: 0.14 vs 0.18 ms incl. the stock path's transposes, tools/time_conv.py)."""

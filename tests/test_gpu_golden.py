@@ -352,7 +352,7 @@ def test_model_fp16_flag_trains_in_bf16_autocast(cuda):
         assert len(seen_bwd) == 16 and all(p == want for p in seen_bwd), seen_bwd
         assert _ext.get_precision() == "f32"
         kinds = {k for k, _ in seen_conv}
-        assert kinds == {"fwd", "dgrad", "wrw"} and len(seen_conv) >= 3 * 30, (kinds, len(seen_conv))
+        assert kinds == {"fwd", "dgrad", "wrw"} and len(seen_conv) >= 3 * 15, (kinds, len(seen_conv))     # (96 x 320: two DLA levels qualify)
         assert all(p == (ops.PREC_BF16 if fp16 else ops.PREC_F32) for _, p in seen_conv), sorted(set(seen_conv))
         results[fp16] = ({k: float(v) for k, v in loss_dict.items()},
                          [None if p.grad is None else bool(torch.isfinite(p.grad).all()) for p in model.parameters()],

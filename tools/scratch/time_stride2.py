@@ -51,3 +51,26 @@ for C, K, H, W in SHAPES:
         tot[n] = tot.get(n, 0.0) + v
     print("%4d->%3d @%3dx%4d s2  fwd+bwd: f32 %.3f ms | bf16 + casts %.3f | bf16 channels_last + casts %.3f" % (C, K, H, W, r["f32"], r["bf16"], r["bf16_cl"]))
 print("sum", {k: round(v, 3) for k, v in tot.items()})
+
+# ---- the same layers through space-to-depth on our stride-1 Winograd kernels (ops.conv3x3_stride2), exact fp32 and bf16 operands
+from dcd_amd import _ext, ops
+for prec in ("f32", "bf16"):
+    tot_s = 0.0
+    for C, K, H, W in SHAPES:
+        x = torch.randn(B, C, H, W, device=dev, requires_grad=True)
+        w = (torch.randn(K, C, 3, 3, device=dev) / (C * 9) ** 0.5).requires_grad_(True)
+        gy = torch.randn(B, K, H // 2, W // 2, device=dev)
+
+        def ours():
+            with _ext.precision_scope(prec):
+                y = ops.conv3x3_stride2(x, w)
+            return torch.autograd.grad(y, (x, w), gy)
+
+        ref = F.conv2d(x, w, None, 2, 1)
+        with _ext.precision_scope(prec):
+            got = ops.conv3x3_stride2(x, w)
+        err = (got - ref).abs().max().item() / ref.abs().max().item()
+        v = t(ours)
+        tot_s += v
+        print("%4d->%3d @%3dx%4d s2  space-to-depth %s fwd+bwd %.3f ms   (rel err vs stock %.1e)" % (C, K, H, W, prec, v, err))
+    print("sum s2d", prec, round(tot_s, 3))
