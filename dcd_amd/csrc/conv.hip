@@ -384,12 +384,12 @@ __global__ __launch_bounds__(WN_NT) void wino_conv3x3_f32(const float *__restric
 constexpr int WS_CH = 16;
 
 template <int NB>
-__global__ void wino_prep_weights_split(const float *__restrict__ w, unsigned *__restrict__ us, int Cc, int Kk, int mode, int nchunk,
-                                        int nz)
+__device__ __forceinline__ void wino_prep_split_body(const float *__restrict__ w, unsigned *__restrict__ us, int Cc, int Kk, int mode,
+                                                     int nchunk, int nz, int first, int step)
 {
     constexpr int KS = 32 * NB;
     const int n = nz * nchunk * KS * 2 * 4;                       // one thread per (z, chunk, kk, parity, dword): 16 positions x (hi, lo)
-    for (int idx = blockIdx.x * blockDim.x + threadIdx.x; idx < n; idx += gridDim.x * blockDim.x) {
+    for (int idx = first; idx < n; idx += step) {
         int r = idx;
         const int d = r & 3; r >>= 2;
         const int h = r & 1; r >>= 1;
@@ -441,6 +441,30 @@ __global__ void wino_prep_weights_split(const float *__restrict__ w, unsigned *_
 // NP = 3: split-bf16 (hi*hi + hi*lo + lo*hi).  NP = 1 (DCD_PREC_BF16): ONE bf16 product per operand pair -- both operands rounded
 // to bf16 (round to nearest even), fp32 accumulate: the mixed-precision form (MODEL.FP16); the lo halves of the prepared weights
 // are neither copied to LDS nor read, the transformed inputs are converted (v_cvt_pk_bf16_f32) instead of split.
+template <int NB>
+__global__ void wino_prep_weights_split(const float *__restrict__ w, unsigned *__restrict__ us, int Cc, int Kk, int mode, int nchunk,
+                                        int nz)
+{
+    wino_prep_split_body<NB>(w, us, Cc, Kk, mode, nchunk, nz, blockIdx.x * blockDim.x + threadIdx.x, gridDim.x * blockDim.x);
+}
+
+// The split-form transform for MANY layers in one launch (blockIdx.z = table entry, blockIdx.y = direction), like
+// wino_prep_weights_table: same five-word entries, the two output pointers being the layer's split-layout buffers.
+__global__ void wino_prep_weights_split_table(const long long *__restrict__ table)
+{
+    const long long *e = table + 5 * (size_t)blockIdx.z;
+    const float *w = reinterpret_cast<const float *>(e[0]);
+    const int mode = blockIdx.y;
+    unsigned *us = reinterpret_cast<unsigned *>(e[1 + mode]);
+    if (!w || !us) return;
+    const int Cin = (int)e[3], Cout = (int)e[4];
+    const int Cc = mode ? Cout : Cin, Kk = mode ? Cin : Cout;
+    const int nb = Kk <= 32 ? 1 : 2, nchunk = (Cc + WS_CH - 1) / WS_CH, nz = (Kk + 32 * nb - 1) / (32 * nb);
+    const int first = blockIdx.x * blockDim.x + threadIdx.x, step = gridDim.x * blockDim.x;
+    if (nb == 2) wino_prep_split_body<2>(w, us, Cc, Kk, mode, nchunk, nz, first, step);
+    else wino_prep_split_body<1>(w, us, Cc, Kk, mode, nchunk, nz, first, step);
+}
+
 template <int NB, int NP>
 __global__ __launch_bounds__(WN_NT) void wino_conv3x3_split(const float *__restrict__ x, const unsigned *__restrict__ us, float *y,
                                                             float *__restrict__ part, const float *__restrict__ bias,
@@ -1231,6 +1255,15 @@ int dcd_conv3x3_split_transform_weights(void *stream_, const float *weight, int 
         if (nb == 2) hipLaunchKernelGGL(wino_prep_weights_split<2>, dim3(grid), dim3(256), 0, stream, weight, dst, Cc, Kk, mode, nchunk, nz);
         else hipLaunchKernelGGL(wino_prep_weights_split<1>, dim3(grid), dim3(256), 0, stream, weight, dst, Cc, Kk, mode, nchunk, nz);
     }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3_split_transform_weights_table(void *stream_, const long long *table, int entries)
+{
+    (void)hipGetLastError();
+    if (!table || entries <= 0 || entries > 65535) return DCD_ERR_BAD_ARG;
+    // 64 blocks x 256 threads per (layer, direction): the largest DGDE layer (512 -> 512) has 65 536 items of 32 stores each
+    hipLaunchKernelGGL(wino_prep_weights_split_table, dim3(64, 2, entries), dim3(256), 0, (hipStream_t)stream_, table);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

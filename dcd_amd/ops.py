@@ -898,8 +898,9 @@ class _PreparedWeights:
     model registers its convolutions or a parameter's storage moves -- a handful of times per process, a few MB each), so a live
     graph replays against memory that is still ours -- stale for a layer that no longer exists, never recycled."""
 
-    def __init__(self):
-        self.entries = {}          # id(weight) -> [weakref, data_ptr, forward buffer, backward buffer, version at refresh]
+    def __init__(self, split=False):
+        self.split = split         # entries hold the split-bf16 layout (DCD_PREC_BF16X3 / DCD_PREC_BF16) instead of the fp32 one
+        self.entries = {}          # id(weight) -> [weakref, data_ptr, forward buffer, backward buffer, version at refresh, idle]
         self.table = None          # device int64 (n, 5) the kernel reads
         self.order = []
         self.dirty = False
@@ -912,6 +913,7 @@ class _PreparedWeights:
             return None
         if not self.captured and torch.cuda.is_current_stream_capturing():
             self.captured = True
+        e[5] = 0                                       # in use
         return e
 
     def register(self, weight):
@@ -923,15 +925,21 @@ class _PreparedWeights:
             return
         L = _lib.lib()
         Co, Ci = weight.shape[0], weight.shape[1]
-        tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device)
-        tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device)
-        self.entries[id(weight)] = [weakref.ref(weight), weight.data_ptr(), tf, tb, -1]
+        if self.split:
+            tf = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device)
+            tb = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device)
+        else:
+            tf = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 0) // 4, dtype=torch.float32, device=weight.device)
+            tb = torch.empty(L.dcd_conv3x3_weights_bytes(Ci, Co, 1) // 4, dtype=torch.float32, device=weight.device)
+        self.entries[id(weight)] = [weakref.ref(weight), weight.data_ptr(), tf, tb, -1, 0]
         self.dirty = True
 
     def refresh(self):
         if not self.entries or not _PREP_TABLE:
             return
-        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[1]]
+        # an entry no convolution has looked up for three refreshes leaves the table (a model that changed its precision mode
+        # would otherwise have BOTH layouts of every layer transformed every step); it re-enters at its next use
+        dead = [k for k, e in self.entries.items() if e[0]() is None or e[0]().data_ptr() != e[1] or e[5] >= 3]
         if (dead or self.dirty) and torch.cuda.is_current_stream_capturing():
             return                                     # no table upload inside a capture: the calls transform their own weights
         if torch.cuda.is_current_stream_capturing():
@@ -954,13 +962,15 @@ class _PreparedWeights:
                 self._immortal.append(self.table)      # a live graph may still launch the transform on the old table
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.dirty = False
-        st = _lib.lib().dcd_conv3x3_transform_weights_table(_lib.stream_of(self.table), self.table.data_ptr(), len(self.order))
-        _lib.check(st, "dcd_conv3x3_transform_weights_table")
+        L = _lib.lib()
+        fn = L.dcd_conv3x3_split_transform_weights_table if self.split else L.dcd_conv3x3_transform_weights_table
+        _lib.check(fn(_lib.stream_of(self.table), self.table.data_ptr(), len(self.order)), "dcd_conv3x3_transform_weights_table")
         for e in self.order:
             e[4] = e[0]()._version
+            e[5] += 1
 
 
-_PREPARED = {}                     # device index -> _PreparedWeights
+_PREPARED = {}                     # (device index, split layout?) -> _PreparedWeights
 
 
 def invalidate_conv_weights(device=None):
@@ -969,10 +979,11 @@ def invalidate_conv_weights(device=None):
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    p = _PREPARED.get(idx)
-    if p is not None:
-        for e in p.entries.values():
-            e[4] = -1
+    for split in (False, True):
+        p = _PREPARED.get((idx, split))
+        if p is not None:
+            for e in p.entries.values():
+                e[4] = -1
 
 
 def conv3x3_step_weights(weight, like):
@@ -980,12 +991,15 @@ def conv3x3_step_weights(weight, like):
     current (no launch), else transformed now -- both directions, one launch -- and the layer is registered for the next
     `refresh_conv_weights`."""
     prec = _conv_prec(like)
-    if prec == PREC_F32:
-        prepared = _PREPARED.setdefault(like.device.index, _PreparedWeights())
-        e = prepared.lookup(weight)
-        if e is not None:
-            return e[2], e[3]
-        prepared.register(weight)
+    split = prec != PREC_F32
+    key = (like.device.index, split)
+    prepared = _PREPARED.get(key)
+    if prepared is None:
+        prepared = _PREPARED[key] = _PreparedWeights(split)
+    e = prepared.lookup(weight)
+    if e is not None:
+        return (SplitWeights(e[2], prec), SplitWeights(e[3], prec)) if split else (e[2], e[3])
+    prepared.register(weight)
     return conv3x3_transform_weights(weight, prec=prec)
 
 
@@ -996,9 +1010,10 @@ def refresh_conv_weights(device=None):
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    p = _PREPARED.get(idx)
-    if p is not None:
-        p.refresh()
+    for split in (False, True):
+        p = _PREPARED.get((idx, split))
+        if p is not None:
+            p.refresh()
 _WRW_ENABLED = os.environ.get("DCD_CONV_WRW", "1") != "0"        # 0: weight gradient on the stock op (A/B timing)
 
 

@@ -513,6 +513,9 @@ int dcd_conv3x3_prepared(void *stream, const float *input, const float *transfor
  * are not read). */
 size_t dcd_conv3x3_split_weights_bytes(int Cin, int Cout, int backward_data);
 int dcd_conv3x3_split_transform_weights(void *stream, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out);
+/* The split-layout transform for many layers in ONE launch: the table of dcd_conv3x3_transform_weights_table (five 64-bit words per
+ * entry: weight, forward_out, backward_out, Cin, Cout) with the layer's split-layout buffers as outputs. */
+int dcd_conv3x3_split_transform_weights_table(void *stream, const long long *table, int entries);
 size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout);
 int dcd_conv3x3_split_prepared(void *stream, const float *input, const void *transformed, const float *bias, const float *residual,
                                float *output, int B, int Cin, int H, int W, int Cout, int backward_data, int precision, void *workspace,

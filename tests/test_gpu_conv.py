@@ -85,7 +85,7 @@ def test_prepared_weight_table_one_launch_for_all_layers(cuda):
     shapes = [(64, 64), (128, 64), (72, 80), (256, 512), (64, 27)]
     ws = [torch.nn.Parameter(torch.randn(k, c, 3, 3, device=cuda, generator=g) / (c * 9) ** 0.5) for c, k in shapes]
     x = [torch.randn(1, c, 24, 80, device=cuda, generator=g, requires_grad=True) for c, _ in shapes]
-    prepared = ops._PREPARED.setdefault(cuda.index if cuda.index is not None else torch.cuda.current_device(), ops._PreparedWeights())
+    prepared = ops._PREPARED.setdefault((cuda.index if cuda.index is not None else torch.cuda.current_device(), False), ops._PreparedWeights())
     first = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # registers the five layers (each transforms its own copy)
     assert all(prepared.lookup(wi) is None for wi in ws)
     ops.refresh_conv_weights()
@@ -107,6 +107,25 @@ def test_prepared_weight_table_one_launch_for_all_layers(cuda):
     ops.refresh_conv_weights()
     assert prepared.lookup(ws[1]) is not None
     assert torch.equal(ops.conv3x3(x[1], ws[1]), y)
+    # the split-bf16 layout has a table of its own (the bf16 precision modes): one launch, bitwise equal to the per-layer transform
+    from dcd_amd import _ext
+    with _ext.precision_scope("bf16"):
+        split = ops._PREPARED.setdefault((cuda.index if cuda.index is not None else torch.cuda.current_device(), True), ops._PreparedWeights(True))
+        a = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # registers the layers in the split table
+        assert all(split.lookup(wi) is None for wi in ws)
+        ops.refresh_conv_weights()
+        for wi in ws:
+            e = split.lookup(wi)
+            assert e is not None
+            tf, tb = ops.conv3x3_transform_weights(wi)
+            assert torch.equal(e[2], tf.tensor) and torch.equal(e[3], tb.tensor)
+        b = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # served from the table
+        for u, v in zip(a, b):
+            assert torch.equal(u, v)
+    # entries nobody looks up any more leave their table after three refreshes (the fp32 ones were last used above)
+    for _ in range(4):
+        ops.refresh_conv_weights()
+    assert not prepared.entries and not split.entries
 
 
 def test_conv_with_skip_sums_both_gradients_in_the_kernel(cuda):
@@ -495,3 +514,38 @@ def test_conv3x3_mixed_bf16_form(cuda, monkeypatch, B, C, K, H, W):
         _close(xg.grad.cpu(), ref_gx, "bf16 autograd grad_input", 1.5e-2)
         _close(wg.grad.cpu(), ref_gw, "bf16 autograd grad_weight", 1.5e-2)
         assert (wg.grad - gw32).abs().max().item() > 1e-4 * gw32.abs().max().item()     # the backward kept the forward's precision
+
+
+@pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80)])
+def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
+    """ops.conv3x3_stride2: the stride-2 / pad-1 3x3 convolution of the DLA levels as a stride-1 convolution of the pixel-unshuffled
+    input with the regrouped filter, on our Winograd kernels -- output and both gradients against conv2d in fp64: exact-fp32 form
+    at 2e-5, one-product bf16 form (the mode that routes there by default) at 1.5e-2; the module dispatch takes it inside a bf16
+    precision scope and keeps the stock solver in fp32."""
+    from dcd_amd import _ext, ops
+    from dcd_amd.model.layers.conv import Conv2d
+    g = torch.Generator().manual_seed(C + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    gy = torch.randn(B, K, H // 2, W // 2, generator=g)
+    ref = F.conv2d(x.double(), w.double(), None, 2, 1)
+    ref_gx = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), stride=2, padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride=2, padding=1)
+    for prec, tol in (("f32", 2e-5), ("bf16", 1.5e-2)):
+        xd, wd = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+        with _ext.precision_scope(prec):
+            y = ops.conv3x3_stride2(xd, wd)
+        y.backward(gy.to(cuda))
+        _close(y.detach().cpu(), ref, "s2d %s forward" % prec, tol)
+        _close(xd.grad.cpu(), ref_gx, "s2d %s grad_input" % prec, tol)
+        _close(wd.grad.cpu(), ref_gw, "s2d %s grad_weight" % prec, tol)
+    conv = Conv2d(C, K, 3, stride=2, padding=1, bias=False).to(cuda)
+    xd = x.to(cuda)
+    calls = []
+    real = ops.conv3x3_stride2
+    monkeypatch.setattr(ops, "conv3x3_stride2", lambda a, b: (calls.append(1), real(a, b))[1])
+    conv(xd)
+    assert not calls, "exact fp32 keeps the stock solver for the stride-2 layers"
+    with _ext.precision_scope("bf16"):
+        out = conv(xd)
+    assert calls and (out - F.conv2d(xd, conv.weight, None, 2, 1)).abs().max().item() <= 1.5e-2 * out.abs().max().item()

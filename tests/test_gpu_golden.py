@@ -458,7 +458,7 @@ def test_graphed_train_step_equals_eager(cuda, data_parallel):
     # the replays stepped the optimizer behind autograd's version counters: no 3x3 layer's prepared (Winograd-domain) weights may
     # pass for current in an eager forward that follows (ops.invalidate_conv_weights in GraphedTrainStep.replay)
     from dcd_amd import ops
-    table = ops._PREPARED.get(cuda.index if cuda.index is not None else torch.cuda.current_device())
+    table = ops._PREPARED.get((cuda.index if cuda.index is not None else torch.cuda.current_device(), False))
     assert table is not None and table.entries and all(table.lookup(e[0]()) is None for e in table.entries.values() if e[0]() is not None)
 
 

@@ -72,7 +72,7 @@ def test_prepared_weights_keep_what_a_capture_has_seen(monkeypatch):
     bufs = {id(w): (torch.zeros(3), torch.zeros(3)) for w in (w1, w2)}
     import weakref
     for w in (w1, w2):
-        p.entries[id(w)] = [weakref.ref(w), w.data_ptr(), bufs[id(w)][0], bufs[id(w)][1], w._version]
+        p.entries[id(w)] = [weakref.ref(w), w.data_ptr(), bufs[id(w)][0], bufs[id(w)][1], w._version, 0]
     p.table = torch.zeros(2, 5, dtype=torch.int64)
     old_table = p.table
     capturing = {"on": True}
