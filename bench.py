@@ -338,7 +338,7 @@ def run_gpu(args):
     dcn_count = args.dcn_steps if use_graph else args.steps
     dcn_ms = timer.total_ms() / max(dcn_count, 1)                       # per step, this rank's share of the batch
     by, fl = dcn_algorithmic(per_rank)
-    traffic, mfma_busy, pmc_source, pmc_commit = load_pmc(per_rank)
+    traffic, mfma_busy, pmc_source, pmc_commit = load_pmc(per_rank, prec)
     out = None
     if rank == 0:
         out = {
@@ -445,12 +445,15 @@ def run_gpu(args):
     return out
 
 
-def load_pmc(per_rank):
+def load_pmc(per_rank, prec="f32"):
     """Counter evidence for the DCN kernels, from separate `rocprofv3 --pmc` passes over THIS command (tools/pmc_kernels.py ->
-    profiles/dcn_pmc_r04.json, falling back to the earlier rounds' files): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
+    profiles/dcn_pmc_r05.json, falling back to the earlier rounds' files): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
     MI355X_MICROARCH.md prescribes) and the time-weighted matrix-pipe busy fraction, plus the commit the passes were made from.
-    (None, None, "absent", None) when the passes have not been made for this batch."""
-    for name in ("dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
+    (None, None, "absent", None) when the passes have not been made for this batch / precision (the committed passes are the
+    fp32 step's; the mixed-precision kernels' counters are profiles/amp_pmc_r05.json, together with the Winograd kernels')."""
+    if prec != "f32":
+        return None, None, "absent for this precision", None
+    for name in ("dcn_pmc_r05.json", "dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:

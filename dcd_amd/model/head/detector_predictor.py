@@ -22,6 +22,32 @@ from dcd_amd.model.layers.conv import Conv2d
 from dcd_amd.model.head import trunk_moments
 
 import os
+
+_EDGE_FAST = os.environ.get("DCD_EDGE_BRANCH_GEMM", "1") != "0"      # 0: the edge-fusion branches on the stock Conv1d / BatchNorm1d (A/B timing)
+
+
+class EdgeBranch(nn.Sequential):
+    """`nn.Sequential(Conv1d(k3, replicate), BatchNorm1d | Identity, ReLU | Identity, Conv1d(k1))` of the edge fusion
+    (DGDE/model/head/detector_predictor.py:124-131) -- same modules, same state-dict keys.  On the device the first convolution
+    is one GEMM over the unfolded border row (ops.conv1d_k3_replicate) and a training-mode BatchNorm1d + ReLU runs on
+    csrc/norm.hip (one launch each way: (B, C, K) is a (B, C, K, 1) map to it); anything else -- host tensors, another kernel
+    size, a converted SyncBatchNorm, eval mode -- takes the modules as they are."""
+
+    def forward(self, x):
+        conv1, bn, act, conv2 = self[0], self[1], self[2], self[3]
+        if not (_EDGE_FAST and x.is_cuda and x.dtype == torch.float32 and x.dim() == 3 and isinstance(conv1, nn.Conv1d)
+                and conv1.kernel_size == (3,) and conv1.stride == (1,) and conv1.dilation == (1,) and conv1.groups == 1
+                and conv1.padding_mode == "replicate" and conv1.padding == (1,) and conv1.bias is not None):
+            return super().forward(x)
+        y = ops.conv1d_k3_replicate(x, conv1.weight, conv1.bias)
+        relu = isinstance(act, nn.ReLU)
+        if (type(bn) is nn.BatchNorm1d and bn.training and bn.affine and bn.track_running_stats and bn.momentum is not None
+                and isinstance(act, (nn.ReLU, nn.Identity))):
+            y = ops.batch_norm_act(y.unsqueeze(-1), None, bn.weight, bn.bias, bn.running_mean, bn.running_var,
+                                   bn.num_batches_tracked, bn.momentum, bn.eps, relu).squeeze(-1)
+        else:
+            y = act(bn(y))
+        return conv2(y)
 _HEAD_FUSED = os.environ.get("DCD_HEAD_FUSED", "1") != "0"      # 0: stock 1x1 conv + separate gather (A/B timing)
 _HEAD_ROWS = os.environ.get("DCD_HEAD_ROWS", "1") != "0"        # 0: one F.linear per regression head (A/B timing, CPU tests)
 
@@ -111,7 +137,7 @@ class _predictor(nn.Module):
 
             def edge_branch(out_ch):
                 act = nn.ReLU(inplace=True) if self.edge_fusion_relu else nn.Identity()
-                return nn.Sequential(
+                return EdgeBranch(
                     nn.Conv1d(self.head_conv, self.head_conv, kernel_size=k, padding=k // 2, padding_mode='replicate'),
                     norm1d(self.head_conv), act, nn.Conv1d(self.head_conv, out_ch, kernel_size=1))
             self.trunc_heatmap_conv = edge_branch(classes)

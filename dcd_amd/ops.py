@@ -551,6 +551,50 @@ def conv1x1_of_cat(xs, weight):
     return _Conv1x1OfCat.apply(weight, *xs)
 
 
+class _Conv1dK3Replicate(torch.autograd.Function):
+    """conv1d(x, weight (O, C, 3), bias, padding 1, padding_mode 'replicate') on (B, C, K) rows as ONE batched GEMM over the
+    unfolded row -- the first layer of the two edge-fusion branches (DGDE/model/head/detector_predictor.py:124-131: Conv1d 256 ->
+    256 along the <= 832 border cells).  MIOpen runs this 2.6 GFLOP layer as an NHWC implicit GEMM between four layout transposes
+    (60 / 45 / 53 us forward / input gradient / weight gradient at bs 8 plus ~10 small launches each way); here: pad, one copy
+    into (B, 3C, K) patch rows [index c * 3 + t, the order of weight.view(O, -1)], one GEMM with the bias as its addend; backward
+    = two GEMMs, the fold of the patch gradient (col2im) and the padding's adjoint."""
+
+    @staticmethod
+    def forward(ctx, x, weight, bias):
+        B, C, K = x.shape
+        O = weight.shape[0]
+        xp = torch.nn.functional.pad(x, (1, 1), mode="replicate")                       # (B, C, K + 2)
+        cols = xp.unfold(2, 3, 1).permute(0, 1, 3, 2).reshape(B, 3 * C, K)               # one copy
+        w2 = weight.reshape(O, 3 * C)
+        out = torch.baddbmm(bias.view(1, O, 1), w2.unsqueeze(0).expand(B, O, 3 * C), cols)
+        ctx.save_for_backward(cols, w2)
+        ctx.geom = (B, C, K, O, tuple(weight.shape))
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        cols, w2 = ctx.saved_tensors
+        B, C, K, O, wshape = ctx.geom
+        g = g.contiguous()
+        gx = gw = gb = None
+        if ctx.needs_input_grad[0]:
+            gcols = torch.bmm(w2.t().unsqueeze(0).expand(B, 3 * C, O), g)                # (B, 3C, K)
+            gxp = torch.nn.functional.fold(gcols, (1, K + 2), (1, 3)).view(B, C, K + 2)  # sum over the three taps
+            gx = gxp[:, :, 1:K + 1].clone()                                              # adjoint of the replicate padding
+            gx[:, :, 0] += gxp[:, :, 0]
+            gx[:, :, K - 1] += gxp[:, :, K + 1]
+        if ctx.needs_input_grad[1]:
+            gw = torch.bmm(g, cols.transpose(1, 2)).sum(0).view(wshape)
+        if ctx.needs_input_grad[2]:
+            gb = g.sum((0, 2))
+        return gx, gw, gb
+
+
+def conv1d_k3_replicate(x, weight, bias):
+    return _Conv1dK3Replicate.apply(x, weight, bias)
+
+
 def scatter_add_at(fmap, vals, index):
     """fmap (B,C,H,W) += vals (B,M,C) at the linear cell indices index (B,M); returns fmap (updated in place)."""
     return _ScatterAddAt.apply(fmap, vals, index)

@@ -326,3 +326,52 @@ def test_target_encoding_matches_oracle_on_random_scenes(cuda):
                 assert np.abs(got.astype(np.float64) - np.asarray(val, np.float64)).max() <= 1e-6 * scale, name
         kept += int(ref["reg_mask"].sum())
     assert kept > 40
+
+
+@pytest.mark.parametrize("relu,norm", [(True, True), (False, True), (True, False)])
+def test_edge_branch_on_the_device_matches_the_stock_modules(cuda, relu, norm):
+    """EdgeBranch (detector_predictor.py: GEMM-form Conv1d + BatchNorm1d / ReLU on csrc/norm.hip) against the same four stock
+    modules evaluated in float64 at the size of the step (8 x 256 x 832 border cells): output, input gradient, every parameter
+    gradient and the BatchNorm running estimates, 2e-5 of each tensor's scale (fp32 sums in another order)."""
+    from torch import nn
+    from dcd_amd.model.head.detector_predictor import EdgeBranch
+    torch.manual_seed(3)
+    C, K, B = 256, 832, 8
+
+    def mods():
+        return (nn.Conv1d(C, C, 3, padding=1, padding_mode="replicate"), nn.BatchNorm1d(C) if norm else nn.Identity(),
+                nn.ReLU(inplace=True) if relu else nn.Identity(), nn.Conv1d(C, 2, 1))
+    fast = EdgeBranch(*mods()).to(cuda).train()
+    ref = nn.Sequential(*mods()).double().train()
+    ref.load_state_dict({k: v.double() if v.is_floating_point() else v for k, v in fast.state_dict().items()})
+    if norm:
+        with torch.no_grad():
+            fast[1].weight.uniform_(0.5, 1.5)
+            fast[1].bias.uniform_(-0.5, 0.5)
+            ref[1].weight.copy_(fast[1].weight.double().cpu())
+            ref[1].bias.copy_(fast[1].bias.double().cpu())
+    x = torch.randn(B, C, K)
+    g = torch.randn(B, 2, K)
+    xf = x.to(cuda).transpose(1, 2).contiguous().transpose(1, 2).requires_grad_(True)    # a (B, K, C) buffer viewed as (B, C, K), like the gather's
+    xr = x.double().requires_grad_(True)
+    yf = fast(xf)
+    yf.backward(g.to(cuda))
+    yr = ref(xr)
+    yr.backward(g.double())
+
+    def close(a, b, what):
+        err = (a.double().cpu() - b).abs().max().item()
+        assert err <= 2e-5 * max(b.abs().max().item(), 1e-6), (what, err, b.abs().max().item())
+    close(yf, yr, "output")
+    close(xf.grad, xr.grad, "grad_input")
+    for (n, p), q in zip(fast.named_parameters(), ref.parameters()):
+        if n == "0.bias" and norm:
+            # in front of a BatchNorm the bias gradient is exactly zero (the mean is removed): what is left is the fp32 rounding
+            # of a sum of B * K = 6 656 gradient values of order one that cancel
+            assert p.grad.abs().max().item() <= 1e-4 and q.grad.abs().max().item() <= 1e-10
+            continue
+        close(p.grad, q.grad, n)
+    if norm:
+        close(fast[1].running_mean, ref[1].running_mean, "running_mean")
+        close(fast[1].running_var, ref[1].running_var, "running_var")
+        assert int(fast[1].num_batches_tracked) == 1

@@ -94,3 +94,40 @@ def test_prepared_weights_keep_what_a_capture_has_seen(monkeypatch):
     kept = [x for item in p._immortal for x in (item if isinstance(item, tuple) else (item,))]
     assert any(x is old_table for x in kept), "the table a live graph may still launch on was released"
     assert sum(1 for x in kept if x.shape == (3,)) == 2, "the removed entry's buffers were released"
+
+
+def test_edge_branch_gemm_form_equals_the_stock_conv1d():
+    """ops.conv1d_k3_replicate (pad + unfold + one GEMM; its hand-written backward: two GEMMs, fold, the padding's adjoint) against
+    nn.Conv1d(kernel 3, padding 1, padding_mode 'replicate') -- the first layer of the edge-fusion branches
+    (DGDE/model/head/detector_predictor.py:124-131) -- in float64 on the host: output, input, weight and bias gradients."""
+    from torch import nn
+    from dcd_amd import ops
+    torch.manual_seed(0)
+    for B, C, K, O in ((2, 5, 11, 4), (1, 8, 3, 8), (3, 16, 64, 7)):
+        conv = nn.Conv1d(C, O, 3, padding=1, padding_mode="replicate").double()
+        x = torch.randn(B, C, K, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(B, O, K, dtype=torch.float64)
+        conv(x).backward(g)
+        x2 = x.detach().clone().requires_grad_(True)
+        w = conv.weight.detach().clone().requires_grad_(True)
+        b = conv.bias.detach().clone().requires_grad_(True)
+        y2 = ops.conv1d_k3_replicate(x2, w, b)
+        y2.backward(g)
+        assert torch.allclose(y2, conv(x), atol=1e-12)
+        assert torch.allclose(x2.grad, x.grad, atol=1e-12)
+        assert torch.allclose(w.grad, conv.weight.grad, atol=1e-12)
+        assert torch.allclose(b.grad, conv.bias.grad, atol=1e-12)
+
+
+def test_edge_branch_keeps_the_reference_modules_and_keys():
+    """EdgeBranch is an nn.Sequential of the reference's four modules: same state-dict keys, and host tensors take the modules as
+    they are (the stock result, bit for bit)."""
+    from torch import nn
+    from dcd_amd.model.head.detector_predictor import EdgeBranch
+    torch.manual_seed(1)
+    mods = lambda: (nn.Conv1d(8, 8, 3, padding=1, padding_mode="replicate"), nn.BatchNorm1d(8), nn.ReLU(inplace=True), nn.Conv1d(8, 2, 1))
+    a, b = EdgeBranch(*mods()), nn.Sequential(*mods())
+    b.load_state_dict(a.state_dict())
+    assert list(a.state_dict().keys()) == list(b.state_dict().keys())
+    x = torch.randn(2, 8, 13)
+    assert torch.equal(a(x), b(x))
