@@ -43,6 +43,8 @@ const char *dcd_version(void);
  *   DCD_SWEEP_WIDE *     0: one-pass backward for Cout <= 64 only (round 3's limit).  Default: Cout <= 128, and 256 where the
  *                        dense path does not apply.
  *   DCD_SWEEP_SLOTS *    waves of a one-pass backward launch (0: one work unit per wave).  Default: one round of resident waves.
+ *   DCD_SWEEP_MIN_ROWS   fewest rows of a one-pass backward work unit (a unit pays ~5 rows of ring warm-up).  Default 3
+ *                        (8: the segment choice of rounds 3-4 on under-filled launches).
  *   DCD_DCN_DENSE *      0: never the column-buffer path; 1: every geometry it can take; default: Cin >= 256 only.
  *   DCD_NO_TILE *        set: the workgroup-tiled LDS kernels (forward, generic backward) stand down for the register-gather ones.
  *   DCD_TILE_ROWS        4: forward regions of 4 rows always.  Default 8 rows when that fills the chip.
