@@ -219,9 +219,9 @@ def patch_moments(x, positions=None):
     """S1 (9C,) and G (9C, 9C) in fp64 [index c*9 + tap] from the autocorrelation matrices of x (see above); with `positions`
     (B, n) also the 3x3 patches at those cells (B, 9C, n) from the same node, else None as third value."""
     mode = os.environ.get("DCD_TRUNK_GRAM", "auto")
-    # auto: the autocorrelation form pays from two 96x320 images per rank on (17.2 vs 17.8 ms per step; one image: 13.8 either
-    # way -- with the border terms as ~60 small launches, rounds 2-3, the threshold was 100k pixels)
-    small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 40000
+    # auto: the autocorrelation form from one 96x320 image per rank on (round 5, one image: 12.50 vs 12.70 ms per step; with the
+    # border terms as ~60 small launches, rounds 2-3, the threshold was 100k pixels, in round 4 two images)
+    small = x.is_cuda and x.shape[0] * x.shape[2] * x.shape[3] < 20000
     if mode == "bmm" or (mode == "auto" and small) or x.shape[2] < 5 or x.shape[3] < 5:
         return patch_moments_gram(x) + (None,)
     B, C, H, W = x.shape
