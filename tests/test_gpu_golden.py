@@ -726,12 +726,19 @@ def test_whole_train_step_at_baseline_size(cuda):
 
     eager, graph, split, fp16 = run("eager"), run("graph"), run("split"), run("fp16")
     # (d) MODEL.FP16 (BASELINE config 3's arithmetic at config 1's size): the bf16 precision scope around backbone and predictor
+    # Step 1 (same weights) within 3 % of fp32, step 2 within 15 %.  Step 3 is only required to be finite and below 1.5x the first
+    # loss: AdamW's first updates move every weight by ~lr whatever the size of its gradient, so the SIGN of every near-zero
+    # gradient component decides the third loss -- noise at fp32 accuracy already (see below), and bf16 products put many more
+    # components there: the same code gave 19.9, 20.6 and 25.3 at step 3 over three boxes of one day (fp32: 19.2-20.2).
     assert abs(fp16[0] - eager[0]) <= 0.03 * eager[0], (eager, fp16)
-    for a, b in zip(eager[1:], fp16[1:]):
-        assert abs(a - b) <= 0.15 * a, (eager, fp16)
+    assert abs(fp16[1] - eager[1]) <= 0.15 * eager[1], (eager, fp16)
+    assert fp16[2] == fp16[2] and 0.0 < fp16[2] < 1.5 * eager[0] and min(fp16[1:]) < fp16[0], (eager, fp16)
     for ls in (eager, graph, split, fp16):
         assert all(l == l and 0.0 < l < 1e4 for l in ls), ls
-        assert ls[2] < ls[0], ls                                   # three steps on one batch: the loss comes down
+        # three steps on one batch: the loss comes down -- not necessarily monotonically (the same sign noise: a 120-step run of
+        # this step at bs 4 goes 21.6, 21.2, 24.1, 17.2, ... 4.6 in fp32 and 21.6, 21.2, 19.2, 17.2, ... 4.5 in mixed precision,
+        # profiles/r05_train_sanity.txt)
+        assert min(ls[1:]) < ls[0] and ls[2] < 1.5 * ls[0], ls
     # step 1 starts from identical weights: graph == eager to fp32 noise, split-bf16 within north_star's 1e-3.  Steps 2-3 follow
     # AdamW's first updates, which move every weight by ~lr whatever the size of its gradient -- the sign of a near-zero gradient
     # component is noise (fp32 atomics), so two runs of the SAME eager code are a few per cent apart by step 3 (measured here:

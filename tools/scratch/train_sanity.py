@@ -8,15 +8,15 @@ from dcd_amd import _ext
 from dcd_amd.engine import trainer
 
 N = int(os.environ.get("N", "120"))
-for prec in ("f32", "bf16x3"):
-    args = argparse.Namespace(batch=4, objects=6, precision=prec, scaling="weak", amp=False)
+for prec in ("f32", "bf16x3", "amp"):                       # amp: MODEL.FP16 (the bf16 precision scope), round 5
+    args = argparse.Namespace(batch=4, objects=6, precision="f32" if prec == "amp" else prec, scaling="weak", amp=prec == "amp")
     dev = torch.device("cuda:0")
     cfg, model, optimizer, images, targets = bench.build_everything(args, dev, 1, 0)[:5]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     hist = []
     for it in range(N):
         loss_dict, log = trainer.train_step(model, optimizer, images, targets, clip)
-        if it % 20 == 0 or it == N - 1:
+        if it % 20 == 0 or it == N - 1 or it < 4:
             total = sum(float(v) for v in loss_dict.values())
             hist.append((it, total))
             assert total == total and abs(total) != float("inf"), (prec, it, total)
