@@ -204,13 +204,14 @@ def build_everything(args, device, world, local_rank):
     model = model.to(device).train()
     optimizer = build_optimizer(model, cfg)
     per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
-    # Whole-step HIP graph: at <= 2 images per rank the step is launch-bound (bs 1: 23.1 -> 15.9 ms, bs 2: 21.9 -> 20.3, bs 4: no gain);
+    # Whole-step HIP graph: at <= 4 images per rank the step is launch-bound (round 5: bs 2 19.0 -> 16.2 ms, bs 4 24.2 -> 23.3; bs 8
+    # 38.0 eager against 38.4 graphed: the GPU is the bound there and the eager host runs ahead);
     # under data parallelism at EVERY batch -- the 136 SyncBN all-reduces issued from Python cost the eager step 6-11 ms
     # (DDP + SyncBN forced on one GPU: bs 8 52.3 -> 46.5 ms, bs 4 38.4 -> 30.1, bs 1 33.9 -> 17.2), inside the graph they are
     # stream work between kernels.  DCD_STEP_GRAPH=1 / 0 forces it on / off.
     graph_env = os.environ.get("DCD_STEP_GRAPH")
     data_parallel = world > 1 or force_ddp
-    use_graph = graph_env == "1" or (graph_env is None and (per_rank <= 2 or data_parallel))
+    use_graph = graph_env == "1" or (graph_env is None and (per_rank <= 4 or data_parallel))
     if data_parallel and use_graph:
         model = prepare_data_parallel(model, cfg)            # bare module: the graphed step reduces the gradients itself
     else:

@@ -6,10 +6,10 @@ from dcd_amd import _ext
 
 dev = torch.device("cuda:0")
 torch.manual_seed(0)
-for (C, Co, H, W) in ((64, 64, 96, 320), (128, 64, 48, 160), (128, 128, 48, 160)):
+for (C, Co, H, W) in ((256, 64, 24, 80), (256, 256, 24, 80), (512, 256, 12, 40), (256, 128, 24, 80)):
     B = 8
     x = torch.randn(B, C, H, W, device=dev)
-    off = torch.randn(B, 18, H, W, device=dev) * 0.5
+    off = torch.randn(B, 18, H, W, device=dev) * float(os.environ.get('OFF', '0.5'))
     far = torch.rand(B, 18, H, W, device=dev) < 0.004
     off = torch.where(far, off * 20, off)
     m = torch.sigmoid(torch.randn(B, 9, H, W, device=dev))
