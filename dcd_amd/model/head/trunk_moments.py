@@ -330,6 +330,70 @@ class _TrunkScaleShift(torch.autograd.Function):
         return dWd.float().view(T, O, K), dGS[:, K], dGS[:, :K], dgamma.view(T, O), dbeta.view(T, O), None, None, None
 
 
+def _sum_rows(t):
+    """(T, B, M, O) -> (T, O), the sum over B and M in steps of at most 64 elements per output: a reduction that short runs in
+    one workgroup per output tile.  ATen's ONE-step form of the same sum (what autograd's broadcast backward issues) is a
+    multi-block kernel whose scratch semaphore is cleared by hipMemsetAsync -- a memset node inside a captured graph, which on
+    this stack is not ordered reliably against its kernel (profiles/r02_graph_memset_hazard.txt)."""
+    T, B, M, O = t.shape
+    while M > 1:
+        c = next(d for d in range(min(M, 64), 0, -1) if M % d == 0)
+        t = t.reshape(T, B, M // c, c, O).sum(3)
+        M = M // c
+    return t.reshape(T, B, O).sum(1)
+
+
+class _AffineRelu(torch.autograd.Function):
+    """relu(y * scale + shift) for y (T, B, M, O) and per-(trunk, channel) scale / shift (T, O), with the gradients of scale and
+    shift summed by `_sum_rows`.  As plain tensor operations the broadcast's backward is a one-step reduction over B x M rows with
+    a memset-cleared semaphore: in the whole-step HIP graph it returned wrong sums in some replays (the trunk's BatchNorm gradients
+    up to 85x too large; a graphed training run left the eager trajectory after ~40 steps -- round 5, tools/scratch/graph_twin2.py)."""
+
+    @staticmethod
+    def forward(ctx, y, scale, shift):
+        T, O = scale.shape
+        out = torch.relu(torch.addcmul(shift.view(T, 1, 1, O), y, scale.view(T, 1, 1, O)))
+        ctx.save_for_backward(y, scale, out)
+        return out
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, g):
+        y, scale, out = ctx.saved_tensors
+        T, O = scale.shape
+        gz = g * (out > 0).to(g.dtype)
+        gy = gz * scale.view(T, 1, 1, O) if ctx.needs_input_grad[0] else None
+        gscale = _sum_rows(gz * y) if ctx.needs_input_grad[1] else None
+        gshift = _sum_rows(gz) if ctx.needs_input_grad[2] else None
+        return gy, gscale, gshift
+
+
+class _PatchLinear(torch.autograd.Function):
+    """y[b, m, o] = sum_k X[b, k, m] W[o, k] (`einsum('bkm,ok->bmo')`) for the one trunk that is also evaluated at the ~832 border
+    cells, as BATCHED products both ways.  The einsum's own weight gradient is ONE skinny product with a 6 656-long contraction
+    (B x 832 positions) -- the BLAS library runs that as a split-K kernel that accumulates into a memset-initialised buffer, and
+    inside a replayed HIP graph memset nodes are not ordered reliably on this stack (profiles/r02_graph_memset_hazard.txt): the
+    graphed step's gradient of that trunk came out up to 85x too large in some replays and a graphed training run left the eager
+    trajectory after ~40 steps (round 5; tools/scratch/graph_twin2.py).  Per-image products summed over the batch by an
+    element-wise reduction have no such accumulator."""
+
+    @staticmethod
+    def forward(ctx, X, W):
+        B, K, M = X.shape
+        ctx.save_for_backward(X, W)
+        return torch.bmm(X.transpose(1, 2), W.t().unsqueeze(0).expand(B, K, W.shape[0]))          # (B, M, O)
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        X, W = ctx.saved_tensors
+        B, K, M = X.shape
+        gy = gy.contiguous()
+        gX = torch.bmm(W.t().unsqueeze(0).expand(B, K, W.shape[0]), gy.transpose(1, 2)) if ctx.needs_input_grad[0] else None   # (B, K, M)
+        gW = torch.bmm(gy.transpose(1, 2), X.transpose(1, 2)).sum(0) if ctx.needs_input_grad[1] else None                       # (O, K)
+        return gX, gW
+
+
 def trunks_at(x, trunks, centers, extra=None, stacked=False):
     """BN + ReLU outputs of every trunk at `centers` (B, M) linear pixel indices -> list of (B, M, Cout); `extra` = (trunk index,
     positions (B, Ke)) appends that trunk's outputs at further positions (the border cells of the edge-fusion branch).  Updates the
@@ -406,13 +470,13 @@ def trunks_at(x, trunks, centers, extra=None, stacked=False):
             return xp.gather(2, idx).reshape(B, K, n)                                          # (B, C, 9, n) -> (B, 9C, n)
     Xc = patches(centers, True)                                                                # (B, 9C, M)
     y = torch.einsum('bkm,tok->tbmo', Xc, Wall)
-    at_centres = torch.relu(y * scale.view(T, 1, 1, -1) + shift.view(T, 1, 1, -1))
+    at_centres = _AffineRelu.apply(y, scale, shift)
     at_extra = None
     if extra is not None:
         i, pos = extra
         Xe = patches(pos, False)
-        ye = torch.einsum('bkm,ok->bmo', Xe, Wall[i])
-        at_extra = torch.relu(ye * scale[i].view(1, 1, -1) + shift[i].view(1, 1, -1))
+        ye = _PatchLinear.apply(Xe, Wall[i]) if x.is_cuda else torch.einsum('bkm,ok->bmo', Xe, Wall[i])
+        at_extra = _AffineRelu.apply(ye.unsqueeze(0), scale[i:i + 1], shift[i:i + 1])[0]
     if stacked:
         return at_centres, at_extra
     out = list(at_centres.unbind(0))

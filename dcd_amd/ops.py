@@ -487,7 +487,11 @@ class _HeadOutAndGather(torch.autograd.Function):
         _lib.check(st, "dcd_poi_scatter_add")
         # the transposed operand is the small one (go^T, 0.7 MB): bmm may copy it, never the 251 MB feature map
         gw = torch.bmm(x.view(B, C, H * W), go.transpose(1, 2)).sum(0).t().reshape(ctx.wshape)
-        gb = go.sum((0, 2)) if ctx.has_bias else None
+        # NOT go.sum((0, 2)): with one class that is a flat reduction of B*H*W values into one, which ATen runs as a multi-block
+        # kernel with a memset-initialised accumulator -- inside a replayed HIP graph it returned a wrong sum from the second replay
+        # on (the hazard of profiles/r02_graph_memset_hazard.txt; found in round 5 as a training run that left the eager
+        # trajectory after ~40 graphed steps: tools/scratch/graph_lr0.py).  The two-stage sums of csrc/norm.hip zero-fill with kernels.
+        gb = channel_sums(_f32c(gout)) if ctx.has_bias else None
         return gx.view(B, C, H, W), gw, gb, None
 
 
@@ -587,7 +591,7 @@ class _Conv1dK3Replicate(torch.autograd.Function):
         if ctx.needs_input_grad[1]:
             gw = torch.bmm(g, cols.transpose(1, 2)).sum(0).view(wshape)
         if ctx.needs_input_grad[2]:
-            gb = g.sum((0, 2))
+            gb = channel_sums(g) if g.is_cuda and g.dtype == torch.float32 else g.sum((0, 2))     # (two-stage sums: safe inside a replayed graph)
         return gx, gw, gb
 
 

@@ -1,6 +1,8 @@
 import os
 import sys
 
+os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")     # before torch loads MIOpen: see dcd_amd/__init__.py
+
 import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))

@@ -748,3 +748,66 @@ def test_whole_train_step_at_baseline_size(cuda):
     assert abs(split[0] - eager[0]) <= 1e-3 * eager[0], (eager, split)
     for other in (graph, split):
         assert abs(eager[1] - other[1]) <= 0.1 * eager[1] and abs(eager[2] - other[2]) <= 0.25 * eager[2], (eager, other)
+
+
+def test_graphed_training_gradients_track_an_eager_twin(cuda):
+    """The whole-step HIP graph TRAINING (learning rate on) at bs 8, 384x1280: every five replays an eager twin takes the graphed
+    model's weights and buffers and runs `trainer.train_step` with its learning rates at zero; the next replay's (clipped)
+    gradients -- computed from the same weights -- must be the twin's.  split-bf16 products (forward and backward repeat to
+    5e-6 eagerly; fp32 does not: MIOpen's stride-2 solvers split K with atomics): bar 2e-3 of each gradient's range.
+
+    Round 5 found this the hard way: ATen reductions whose scratch semaphore is cleared by hipMemsetAsync (the broadcast backward
+    of the head trunks' scale / shift, a flat bias-gradient sum) and MIOpen's memset + accumulate backward-data solver became
+    memset nodes of the captured graph and returned wrong sums in some replays -- one trunk's BatchNorm gradients up to 85x too
+    large at replay 10, 20, 25, ..., invisible in the loss of the first steps, and a graphed training run left the eager
+    trajectory after ~40 steps (profiles/r05_graph_vs_eager.txt).  Every such site now reduces in kernels without memsets."""
+    import argparse
+    import os
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    if root not in sys.path:
+        sys.path.insert(0, root)
+    import bench
+    from dcd_amd import _ext
+    from dcd_amd.engine import trainer
+
+    def build(zero_lr):
+        args = argparse.Namespace(batch=8, objects=6, precision="bf16x3", scaling="weak", amp=False)
+        r = bench.build_everything(args, cuda, 1, 0)[:5]
+        if zero_lr:
+            for g in r[2].param_groups:
+                g["lr"].fill_(0.0)
+                g["weight_decay"] = 0.0
+        return r
+    try:
+        cfg, A, optA, images, targets = build(False)
+        _, B, optB, _, _ = build(True)
+        clip = cfg.SOLVER.GRAD_NORM_CLIP
+        step = trainer.GraphedTrainStep(A, optA, clip)
+        worst_seen = 0.0
+        for it in range(41):
+            check = it > 0 and it % 5 == 0                    # (the wrong sums came and went: 7 of 12 such checks in one run, 0 of 4 in another)
+            if check:
+                torch.cuda.synchronize()
+                with torch.no_grad():
+                    for p, q in zip(A.parameters(), B.parameters()):
+                        q.copy_(p)
+                    for p, q in zip(A.buffers(), B.buffers()):
+                        q.copy_(p)
+                ld_b, _ = trainer.train_step(B, optB, images, targets, clip)
+                torch.cuda.synchronize()
+                gb = {n: p.grad.detach().clone() for n, p in B.named_parameters() if p.grad is not None}
+            ld, _ = step(images, targets)
+            if check:
+                torch.cuda.synchronize()
+                assert abs(float(sum(ld.values())) - float(sum(ld_b.values()))) <= 1e-5 * float(sum(ld_b.values()))
+                for n, p in A.named_parameters():
+                    # (a bias in front of a BatchNorm has a zero gradient: what is there is rounding noise of either run)
+                    if p.grad is None or n.endswith("conv.bias") or float(gb[n].abs().max()) < 1e-7:
+                        continue
+                    rel = float((p.grad - gb[n]).abs().max() / gb[n].abs().max())
+                    worst_seen = max(worst_seen, rel)
+                    assert rel <= 2e-3, "replay %d: gradient of %s differs from the eager twin's by %.2e of its range" % (it, n, rel)
+        assert worst_seen > 0.0
+    finally:
+        _ext.set_precision("f32")
