@@ -9,12 +9,12 @@ from dcd_amd.engine import trainer
 
 N = int(os.environ.get("N", "300"))
 dev = torch.device("cuda:0")
-for mode in ("eager", "graph", "amp"):
-    args = argparse.Namespace(batch=8, objects=6, precision="f32", scaling="weak", amp=mode == "amp")
+for mode in os.environ.get("MODES", "eager,graph,amp,amp_graph").split(","):
+    args = argparse.Namespace(batch=8, objects=6, precision="f32", scaling="weak", amp=mode.startswith("amp"))
     cfg, model, optimizer, images, targets = bench.build_everything(args, dev, 1, 0)[:5]
     clip = cfg.SOLVER.GRAD_NORM_CLIP
     batches = [make_batch(8, seed=200 + i, n_objects=6, device=dev) for i in range(4)]
-    step = trainer.GraphedTrainStep(model, optimizer, clip) if mode == "graph" else None
+    step = trainer.GraphedTrainStep(model, optimizer, clip) if mode.endswith("graph") else None
     hist, mem20 = [], None
     for it in range(N):
         im, tg = batches[it % 4]
