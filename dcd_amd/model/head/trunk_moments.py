@@ -371,11 +371,10 @@ class _AffineRelu(torch.autograd.Function):
 class _PatchLinear(torch.autograd.Function):
     """y[b, m, o] = sum_k X[b, k, m] W[o, k] (`einsum('bkm,ok->bmo')`) for the one trunk that is also evaluated at the ~832 border
     cells, as BATCHED products both ways.  The einsum's own weight gradient is ONE skinny product with a 6 656-long contraction
-    (B x 832 positions) -- the BLAS library runs that as a split-K kernel that accumulates into a memset-initialised buffer, and
-    inside a replayed HIP graph memset nodes are not ordered reliably on this stack (profiles/r02_graph_memset_hazard.txt): the
-    graphed step's gradient of that trunk came out up to 85x too large in some replays and a graphed training run left the eager
-    trajectory after ~40 steps (round 5; tools/scratch/graph_twin2.py).  Per-image products summed over the batch by an
-    element-wise reduction have no such accumulator."""
+    (B x 832 positions), the shape for which BLAS libraries pick split-K kernels that accumulate into a cleared buffer; per-image
+    products summed over the batch by an element-wise reduction have no such accumulator.  A precaution taken while the captured
+    step's wrong gradients were hunted (round 5: they turned out to come from `_AffineRelu`'s predecessor, see there), kept
+    because it also drops a transposed copy of X."""
 
     @staticmethod
     def forward(ctx, X, W):
