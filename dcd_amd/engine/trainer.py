@@ -9,6 +9,8 @@ Mirrors the semantics of the reference's harness without copying it:
 import math
 import weakref
 
+import os
+
 import torch
 from torch import nn
 
@@ -473,6 +475,11 @@ class GraphedTrainStep:
 
     def _capture(self, images, targets):
         import copy
+        if images.is_cuda and os.environ.get("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS") != "0":
+            import warnings
+            warnings.warn("capturing the train step with MIOpen's memset + accumulate backward-data solver enabled: export "
+                          "MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS=0 before `import torch` (INTEGRATION.md section 4: "
+                          "memset nodes are not ordered reliably inside a replayed HIP graph on this stack)")
         entry = {"static": self._static_copy(images, targets)}
         self._copy_in(entry, images, targets)
         st_images, st_targets = entry["static"][0], entry["static"][1]
