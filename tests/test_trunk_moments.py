@@ -127,3 +127,36 @@ def test_trunks_at_with_synchronised_statistics_two_ranks(tmp_path):
     mp.spawn(_sync_worker, args=(2, port, str(tmp_path)), nprocs=2, join=True)
     for r in range(2):
         assert torch.load(os.path.join(str(tmp_path), "tm%d.pt" % r))["ok"]
+
+
+def test_affine_relu_and_patch_linear_nodes_equal_the_plain_tensor_operations():
+    """`_AffineRelu` (relu(y scale + shift) with the scale / shift gradients summed in short steps, trunk_moments._sum_rows) and
+    `_PatchLinear` (einsum('bkm,ok->bmo') as batched products) against the plain formulas differentiated by autograd, float64."""
+    import torch
+    from dcd_amd.model.head import trunk_moments as TM
+    torch.manual_seed(0)
+    for T, B, M, O in ((3, 2, 40, 8), (1, 2, 832, 4), (2, 3, 7, 5)):
+        y = torch.randn(T, B, M, O, dtype=torch.float64, requires_grad=True)
+        sc = torch.randn(T, O, dtype=torch.float64, requires_grad=True)
+        sh = torch.randn(T, O, dtype=torch.float64, requires_grad=True)
+        g = torch.randn(T, B, M, O, dtype=torch.float64)
+        ref = torch.relu(y * sc.view(T, 1, 1, O) + sh.view(T, 1, 1, O))
+        ref.backward(g)
+        want = (ref.detach().clone(), y.grad.clone(), sc.grad.clone(), sh.grad.clone())
+        y.grad = sc.grad = sh.grad = None
+        out = TM._AffineRelu.apply(y, sc, sh)
+        out.backward(g)
+        for a, b in zip((out.detach(), y.grad, sc.grad, sh.grad), want):
+            assert torch.allclose(a, b, atol=1e-12)
+        assert torch.allclose(TM._sum_rows(g), g.sum((1, 2)), atol=1e-12)
+    X = torch.randn(2, 18, 11, dtype=torch.float64, requires_grad=True)
+    W = torch.randn(5, 18, dtype=torch.float64, requires_grad=True)
+    g = torch.randn(2, 11, 5, dtype=torch.float64)
+    ref = torch.einsum('bkm,ok->bmo', X, W)
+    ref.backward(g)
+    want = (ref.detach().clone(), X.grad.clone(), W.grad.clone())
+    X.grad = W.grad = None
+    out = TM._PatchLinear.apply(X, W)
+    out.backward(g)
+    for a, b in zip((out.detach(), X.grad, W.grad), want):
+        assert torch.allclose(a, b, atol=1e-12)
