@@ -438,6 +438,8 @@ __device__ __forceinline__ void wino_prep_split_body(const float *__restrict__ w
     }
 }
 
+#include "conv_direct_bf16.inc"
+
 // NP = 3: split-bf16 (hi*hi + hi*lo + lo*hi).  NP = 1 (DCD_PREC_BF16): ONE bf16 product per operand pair -- both operands rounded
 // to bf16 (round to nearest even), fp32 accumulate: the mixed-precision form (MODEL.FP16); the lo halves of the prepared weights
 // are neither copied to LDS nor read, the transformed inputs are converted (v_cvt_pk_bf16_f32) instead of split.
@@ -1105,6 +1107,52 @@ static ConvPlan conv_plan_split(int B, int Cc, int H, int W, int Kk)
     return p;
 }
 
+// direct one-product form (conv_direct_bf16.inc): rows per wave P (plan.geom) = 4 or 2, i.e. 16 x 32 or 8 x 32 px regions
+static bool conv_direct_ok(int Cc, int H, int W)
+{
+    return (int64_t)(Cc + DC_CH) * H * W < (1ll << 29);
+}
+
+static ConvPlan conv_plan_direct(int B, int Cc, int H, int W, int Kk)
+{
+    static const int pin = dcd_env("DCD_CONV_DIRECT_P") ? atoi(dcd_env("DCD_CONV_DIRECT_P")) : 0;
+    const int cus = device_cus();
+    ConvPlan best{};
+    int64_t best_cost = -1;
+    for (int P = 2; P <= 4; P += 2) {
+        if (P != (pin == 4 ? 4 : 2)) continue;                       // 16 x 32 px regions (one workgroup per CU) only when pinned
+        ConvPlan p;
+        p.geom = P;
+        p.tiles_x = (W + 31) / 32;
+        p.tiles_y = (H + 4 * P - 1) / (4 * P);
+        p.nchunk = (Cc + DC_CH - 1) / DC_CH;
+        p.nb = Kk <= 32 ? 1 : 2;
+        p.nz = (Kk + 32 * p.nb - 1) / (32 * p.nb);
+        const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
+        // three workgroups share a CU (164 registers); split the contraction while slots would stay empty and a split keeps 16 chunks
+        // (256 -> 256 @ 24x80 x 8: 46.5 us split in two or not, and the split pays a wino_sum_partials launch)
+        static const int min_chunks = dcd_env("DCD_CONV_DIRECT_MINCHUNK") ? atoi(dcd_env("DCD_CONV_DIRECT_MINCHUNK")) : 16;
+        int ks = 1;
+        while (ks < 8 && wgs * (ks * 2) <= 3 * cus && p.nchunk / (ks * 2) >= min_chunks) ks *= 2;
+        p.ksplit = ks;
+        best = p;
+    }
+    (void)best_cost;
+    return best;
+}
+
+template <int NB, int P, bool SA>
+static int conv_launch_direct(hipStream_t stream, const ConvPlan &pl, const float *input, const unsigned *wd, float *output, float *part,
+                              const float *bias, const float *residual, int B, int Cc, int H, int W, int Kk)
+{
+    static LdsLimit lds_limit;
+    const size_t ldsb = ((size_t)2 * (4 * P + 2) * DC_RS + (size_t)2 * 9 * NB * 64) * 16;
+    if (!lds_limit.raise((int)ldsb, conv3x3_direct_bf16<NB, P, SA>)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL((conv3x3_direct_bf16<NB, P, SA>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(DC_NT), ldsb, stream, input,
+                       wd, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    return DCD_OK;
+}
+
 static size_t tw_dwords_split(int Cin, int Cout, int backward_data)
 {
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
@@ -1296,6 +1344,81 @@ int dcd_conv3x3_split_prepared(void *stream_, const float *input, const void *tr
                                      : conv_launch_split<2, 3>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk))
                               : (one ? conv_launch_split<1, 1>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk)
                                      : conv_launch_split<1, 3>(stream, pl, input, us, output, part, bias, residual, B, Cc, H, W, Kk));
+    if (st != DCD_OK) return st;
+    if (pl.ksplit > 1) {
+        const size_t n4 = img / 4;
+        const int nb = (int)((n4 + 255) / 256 < 2048 ? (n4 + 255) / 256 : 2048);
+        hipLaunchKernelGGL(wino_sum_partials, dim3(nb), dim3(256), 0, stream, output, (const float *)part, n4, pl.ksplit - 1);
+    }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+// ---- the one-product form as a direct implicit GEMM (conv_direct_bf16.inc): its own weight layout, same call shape
+size_t dcd_conv3x3_bf16_weights_bytes(int Cin, int Cout, int backward_data)
+{
+    if (Cin <= 0 || Cout <= 0) return 0;
+    return 16 * (backward_data ? dc_weight_slots(Cout, Cin) : dc_weight_slots(Cin, Cout));
+}
+
+int dcd_conv3x3_bf16_transform_weights(void *stream_, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!weight || Cin <= 0 || Cout <= 0 || (!forward_out && !backward_out)) return DCD_ERR_BAD_ARG;
+    DirectPrep p;
+    size_t nmax = 0;
+    for (int mode = 0; mode < 2; ++mode) {
+        p.ud[mode] = (unsigned *)(mode ? backward_out : forward_out);
+        p.Cc[mode] = mode ? Cout : Cin;
+        p.Kk[mode] = mode ? Cin : Cout;
+        const size_t n = p.ud[mode] ? dc_weight_slots(p.Cc[mode], p.Kk[mode]) : 0;
+        if (n > nmax) nmax = n;
+    }
+    nmax /= 9;                                                             // one thread per nine slots
+    const int nb = (int)((nmax + 255) / 256 < 2048 ? (nmax + 255) / 256 : 2048);
+    hipLaunchKernelGGL(direct_prep_weights_both, dim3(nb, 2), dim3(256), 0, stream, weight, p);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3_bf16_transform_weights_table(void *stream_, const long long *table, int entries)
+{
+    (void)hipGetLastError();
+    if (!table || entries <= 0 || entries > 65535) return DCD_ERR_BAD_ARG;
+    // 32 blocks x 256 threads per (layer, direction): the largest DGDE layer (512 -> 512) has 16 384 items of nine slots = 2 per thread
+    hipLaunchKernelGGL(direct_prep_weights_table, dim3(32, 2, entries), dim3(256), 0, (hipStream_t)stream_, table);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+size_t dcd_conv3x3_bf16_workspace_bytes(int B, int Cin, int H, int W, int Cout)
+{
+    if (B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return 0;
+    const size_t pf = (size_t)(conv_plan_direct(B, Cin, H, W, Cout).ksplit - 1) * B * Cout * H * W;
+    const size_t pd = (size_t)(conv_plan_direct(B, Cout, H, W, Cin).ksplit - 1) * B * Cin * H * W;
+    return (pf > pd ? pf : pd) * sizeof(float) + 16;
+}
+
+int dcd_conv3x3_bf16_prepared(void *stream_, const float *input, const void *transformed, const float *bias, const float *residual,
+                              float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                              size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!input || !transformed || !output || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
+    if (bias && backward_data) return DCD_ERR_BAD_ARG;
+    const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
+    if (!conv_direct_ok(Cc, H, W) || (int64_t)Kk * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    const ConvPlan pl = conv_plan_direct(B, Cc, H, W, Kk);
+    const size_t img = (size_t)B * Kk * H * W;
+    const size_t need = (size_t)(pl.ksplit - 1) * img * sizeof(float);
+    if (need && (!workspace || workspace_bytes < need)) return DCD_ERR_WORKSPACE;
+    if (pl.ksplit > 1 && (img & 3)) return DCD_ERR_BAD_ARG;               // wino_sum_partials adds float4s
+    float *part = (float *)workspace;
+    const unsigned *wd = (const unsigned *)transformed;
+    static const bool sa = !(dcd_env("DCD_CONV_DIRECT_SA") && atoi(dcd_env("DCD_CONV_DIRECT_SA")) == 0);
+#define DCD_DIRECT(NB_, P_, SA_) conv_launch_direct<NB_, P_, SA_>(stream, pl, input, wd, output, part, bias, residual, B, Cc, H, W, Kk)
+    const int st = pl.nb == 2 ? (pl.geom == 4 ? DCD_DIRECT(2, 4, false) : sa ? DCD_DIRECT(2, 2, true) : DCD_DIRECT(2, 2, false))
+                              : (pl.geom == 4 ? DCD_DIRECT(1, 4, false) : sa ? DCD_DIRECT(1, 2, true) : DCD_DIRECT(1, 2, false));
+#undef DCD_DIRECT
     if (st != DCD_OK) return st;
     if (pl.ksplit > 1) {
         const size_t n4 = img / 4;

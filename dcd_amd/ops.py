@@ -860,6 +860,24 @@ class SplitWeights:
         self.prec = prec
 
 
+class Bf16Weights(SplitWeights):
+    """bf16-rounded weights in the operand order of the direct one-product kernel (dcd_conv3x3_bf16_transform_weights,
+    csrc/conv_direct_bf16.inc): what DCD_PREC_BF16 runs on unless DCD_CONV_BF16_DIRECT=0 keeps the Winograd form (A/B timing)."""
+
+    def __init__(self, tensor):
+        super().__init__(tensor, PREC_BF16)
+
+
+_BF16_DIRECT = os.environ.get("DCD_CONV_BF16_DIRECT", "1") != "0"
+
+
+def _layout(prec):
+    """Which prepared-weight layout a precision runs on: "f32" (Winograd, fp32), "split" (Winograd, hi | lo bf16), "bf16" (direct)."""
+    if prec == PREC_F32:
+        return "f32"
+    return "bf16" if prec == PREC_BF16 and _BF16_DIRECT else "split"
+
+
 def conv3x3_transform_weights(weight, forward=True, backward=True, like=None, prec=None):
     """Winograd-domain weights of a (Cout, Cin, 3, 3) filter for the forward and / or the backward-data call, ONE launch
     (split-bf16 form: one launch per direction).  like: the tensor the convolution will run on (decides the form, see _conv_prec);
@@ -867,6 +885,12 @@ def conv3x3_transform_weights(weight, forward=True, backward=True, like=None, pr
     L = _lib.lib()
     Co, Ci = weight.shape[0], weight.shape[1]
     prec = _conv_prec(like) if prec is None else prec
+    if _layout(prec) == "bf16":
+        tf = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device) if forward else None
+        tb = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device) if backward else None
+        _lib.check(L.dcd_conv3x3_bf16_transform_weights(_lib.stream_of(weight), weight.data_ptr(), Ci, Co, _lib.ptr(tf), _lib.ptr(tb)),
+                   "dcd_conv3x3_bf16_transform_weights")
+        return (Bf16Weights(tf) if forward else None), (Bf16Weights(tb) if backward else None)
     if prec != PREC_F32:
         tf = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device) if forward else None
         tb = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device) if backward else None
@@ -900,6 +924,13 @@ def _conv3x3_call(inp, weight, out_channels, backward_data, bias=None, residual=
         prec = _conv_prec(inp) if prec is None else prec
         if prec != PREC_F32:
             transformed = conv3x3_transform_weights(weight, not backward_data, backward_data, prec=prec)[1 if backward_data else 0]
+    if isinstance(transformed, Bf16Weights):
+        n = L.dcd_conv3x3_bf16_workspace_bytes(B, Ci, H, W, Co)
+        ws = torch.empty(max(n, 16), dtype=torch.uint8, device=inp.device)
+        st = L.dcd_conv3x3_bf16_prepared(_lib.stream_of(inp), inp.data_ptr(), transformed.tensor.data_ptr(), _lib.ptr(bias),
+                                         _lib.ptr(residual), out.data_ptr(), B, Ci, H, W, Co, 1 if backward_data else 0, ws.data_ptr(), n)
+        _lib.check(st, "dcd_conv3x3_bf16_prepared")
+        return out
     if isinstance(transformed, SplitWeights):
         n = L.dcd_conv3x3_split_workspace_bytes(B, Ci, H, W, Co)
         ws = torch.empty(max(n, 16), dtype=torch.uint8, device=inp.device)
@@ -947,7 +978,9 @@ class _PreparedWeights:
     graph replays against memory that is still ours -- stale for a layer that no longer exists, never recycled."""
 
     def __init__(self, split=False):
-        self.split = split         # entries hold the split-bf16 layout (DCD_PREC_BF16X3 / DCD_PREC_BF16) instead of the fp32 one
+        # entries hold: False the fp32 layout, True the split-bf16 one (DCD_PREC_BF16X3; DCD_PREC_BF16 on the Winograd form),
+        # "bf16" the direct one-product kernel's
+        self.split = split
         self.entries = {}          # id(weight) -> [weakref, data_ptr, forward buffer, backward buffer, version at refresh, idle]
         self.table = None          # device int64 (n, 5) the kernel reads
         self.order = []
@@ -973,7 +1006,10 @@ class _PreparedWeights:
             return
         L = _lib.lib()
         Co, Ci = weight.shape[0], weight.shape[1]
-        if self.split:
+        if self.split == "bf16":
+            tf = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device)
+            tb = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device)
+        elif self.split:
             tf = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 0) // 4, dtype=torch.int32, device=weight.device)
             tb = torch.empty(L.dcd_conv3x3_split_weights_bytes(Ci, Co, 1) // 4, dtype=torch.int32, device=weight.device)
         else:
@@ -1011,14 +1047,16 @@ class _PreparedWeights:
             self.table = torch.tensor(rows, dtype=torch.int64).to(dev)
             self.dirty = False
         L = _lib.lib()
-        fn = L.dcd_conv3x3_split_transform_weights_table if self.split else L.dcd_conv3x3_transform_weights_table
+        fn = (L.dcd_conv3x3_bf16_transform_weights_table if self.split == "bf16" else
+              L.dcd_conv3x3_split_transform_weights_table if self.split else L.dcd_conv3x3_transform_weights_table)
         _lib.check(fn(_lib.stream_of(self.table), self.table.data_ptr(), len(self.order)), "dcd_conv3x3_transform_weights_table")
         for e in self.order:
             e[4] = e[0]()._version
             e[5] += 1
 
 
-_PREPARED = {}                     # (device index, split layout?) -> _PreparedWeights
+_PREPARED = {}                     # (device index, layout: False fp32 | True split | "bf16" direct) -> _PreparedWeights
+_LAYOUT_KEYS = (False, True, "bf16")
 
 
 def invalidate_conv_weights(device=None):
@@ -1027,7 +1065,7 @@ def invalidate_conv_weights(device=None):
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    for split in (False, True):
+    for split in _LAYOUT_KEYS:
         p = _PREPARED.get((idx, split))
         if p is not None:
             for e in p.entries.values():
@@ -1039,13 +1077,15 @@ def conv3x3_step_weights(weight, like):
     current (no launch), else transformed now -- both directions, one launch -- and the layer is registered for the next
     `refresh_conv_weights`."""
     prec = _conv_prec(like)
-    split = prec != PREC_F32
+    split = {"f32": False, "split": True, "bf16": "bf16"}[_layout(prec)]
     key = (like.device.index, split)
     prepared = _PREPARED.get(key)
     if prepared is None:
         prepared = _PREPARED[key] = _PreparedWeights(split)
     e = prepared.lookup(weight)
     if e is not None:
+        if split == "bf16":
+            return Bf16Weights(e[2]), Bf16Weights(e[3])
         return (SplitWeights(e[2], prec), SplitWeights(e[3], prec)) if split else (e[2], e[3])
     prepared.register(weight)
     return conv3x3_transform_weights(weight, prec=prec)
@@ -1058,7 +1098,7 @@ def refresh_conv_weights(device=None):
     if not torch.cuda.is_available():
         return
     idx = torch.cuda.current_device() if device is None else torch.device(device).index
-    for split in (False, True):
+    for split in _LAYOUT_KEYS:
         p = _PREPARED.get((idx, split))
         if p is not None:
             p.refresh()

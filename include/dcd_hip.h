@@ -58,6 +58,10 @@ const char *dcd_version(void);
  *   DCD_DW_ORDER         0: the generic grad_weight kernel walks its tiles row by row.  Default: down column strips.
  *   DCD_CONV_GEOM *      0 | 1: pin the Winograd region shape (8 x 32 / 12 x 20 px), no split contraction.  Default: by cost model.
  *   DCD_CONV_MINCHUNK    smallest number of 8-channel chunks a split of the Winograd contraction keeps.  Default 4.
+ *   DCD_CONV_DIRECT_MINCHUNK  the same for the direct bf16 form's 16-channel chunks.  Default 16.
+ *   DCD_CONV_DIRECT_P *  4: 16 x 32 px regions (one workgroup per CU) instead of 8 x 32 in the direct bf16 form.  Default 2.
+ *   DCD_CONV_DIRECT_SA * 0: the direct bf16 form keeps a chunk's weights in registers and streams the window (two workgroups per CU
+ *                        instead of three).  Default 1.
  *   DCD_BN_SMALL         0: no single-workgroup-per-channel BatchNorm kernels for small maps.  Default on.
  *   DCD_CHANNEL_SUM_ONE_LAUNCH   1 | 0: pin the per-channel sums to the one-launch / two-launch form.  Default: by grid size.
  *   DCD_UP_FWD_OLD, DCD_UP_BWD_OLD   set: the round-1 depthwise up-sampling kernels.
@@ -522,6 +526,21 @@ size_t dcd_conv3x3_split_workspace_bytes(int B, int Cin, int H, int W, int Cout)
 int dcd_conv3x3_split_prepared(void *stream, const float *input, const void *transformed, const float *bias, const float *residual,
                                float *output, int B, int Cin, int H, int W, int Cout, int backward_data, int precision, void *workspace,
                                size_t workspace_bytes);
+
+/* The ONE-product form (DCD_PREC_BF16, MODEL.FP16: DGDE/model/detector.py:34-36) as a DIRECT implicit GEMM on
+ * v_mfma_f32_32x32x16_bf16 (csrc/conv_direct_bf16.inc): inputs and weights rounded to bf16 once (nearest even), no Winograd
+ * transform -- on the bf16 matrix pipe the transform's vector / LDS work, not the multiplies, was the kernel's time -- fp32
+ * accumulate, fp32 tensors in HBM.  Own weight layout (both directions, either pointer may be NULL; the table form takes the
+ * five-word entries of dcd_conv3x3_transform_weights_table with buffers of dcd_conv3x3_bf16_weights_bytes); workspace: the partial
+ * images of a split contraction.  Any Cin / Cout / H / W with (max(Cin, Cout) + 16) H W < 2^29; a split contraction
+ * (dcd_conv3x3_bf16_workspace_bytes > 16) needs B Cout H W % 4 == 0.  bias only with backward_data == 0. */
+size_t dcd_conv3x3_bf16_weights_bytes(int Cin, int Cout, int backward_data);
+int dcd_conv3x3_bf16_transform_weights(void *stream, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out);
+int dcd_conv3x3_bf16_transform_weights_table(void *stream, const long long *table, int entries);
+size_t dcd_conv3x3_bf16_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int dcd_conv3x3_bf16_prepared(void *stream, const float *input, const void *transformed, const float *bias, const float *residual,
+                              float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
+                              size_t workspace_bytes);
 
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).

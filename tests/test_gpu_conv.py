@@ -107,25 +107,32 @@ def test_prepared_weight_table_one_launch_for_all_layers(cuda):
     ops.refresh_conv_weights()
     assert prepared.lookup(ws[1]) is not None
     assert torch.equal(ops.conv3x3(x[1], ws[1]), y)
-    # the split-bf16 layout has a table of its own (the bf16 precision modes): one launch, bitwise equal to the per-layer transform
+    # the bf16 precision modes have tables of their own -- split-bf16 layout (bf16x3, maps of at least 7 680 px) and the direct
+    # one-product kernel's (bf16): one launch, bitwise equal to the per-layer transform
     from dcd_amd import _ext
-    with _ext.precision_scope("bf16"):
-        split = ops._PREPARED.setdefault((cuda.index if cuda.index is not None else torch.cuda.current_device(), True), ops._PreparedWeights(True))
-        a = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # registers the layers in the split table
-        assert all(split.lookup(wi) is None for wi in ws)
-        ops.refresh_conv_weights()
-        for wi in ws:
-            e = split.lookup(wi)
-            assert e is not None
-            tf, tb = ops.conv3x3_transform_weights(wi)
-            assert torch.equal(e[2], tf.tensor) and torch.equal(e[3], tb.tensor)
-        b = [ops.conv3x3(xi, wi) for xi, wi in zip(x, ws)]              # served from the table
-        for u, v in zip(a, b):
-            assert torch.equal(u, v)
+    idx = cuda.index if cuda.index is not None else torch.cuda.current_device()
+    tables = []
+    for mode, key, xs in (("bf16x3", True, [torch.randn(1, c, 96, 80, device=cuda, generator=g, requires_grad=True) for c, _ in shapes]),
+                          ("bf16", "bf16" if ops._BF16_DIRECT else True, x)):
+        with _ext.precision_scope(mode):
+            split = ops._PREPARED.setdefault((idx, key), ops._PreparedWeights(key))
+            tables.append(split)
+            a = [ops.conv3x3(xi, wi) for xi, wi in zip(xs, ws)]             # registers the layers in the mode's table
+            assert all(split.lookup(wi) is None for wi in ws)
+            ops.refresh_conv_weights()
+            for wi in ws:
+                e = split.lookup(wi)
+                assert e is not None
+                tf, tb = ops.conv3x3_transform_weights(wi, like=xs[0])
+                assert isinstance(tf, ops.Bf16Weights) == (key == "bf16")
+                assert torch.equal(e[2], tf.tensor) and torch.equal(e[3], tb.tensor)
+            b = [ops.conv3x3(xi, wi) for xi, wi in zip(xs, ws)]             # served from the table
+            for u, v in zip(a, b):
+                assert torch.equal(u, v)
     # entries nobody looks up any more leave their table after three refreshes (the fp32 ones were last used above)
     for _ in range(4):
         ops.refresh_conv_weights()
-    assert not prepared.entries and not split.entries
+    assert not prepared.entries and not any(t.entries for t in tables)
 
 
 def test_conv_with_skip_sums_both_gradients_in_the_kernel(cuda):
