@@ -1122,18 +1122,30 @@ static ConvPlan conv_plan_direct(int B, int Cc, int H, int W, int Kk)
     for (int P = 2; P <= 4; P += 2) {
         if (P != (pin == 4 ? 4 : 2)) continue;                       // 16 x 32 px regions (one workgroup per CU) only when pinned
         ConvPlan p;
-        p.geom = P;
-        p.tiles_x = (W + 31) / 32;
+        // 8 x 64 px regions (eight waves) where the width divides: a third less L2 traffic for the column halo
+        static const int wxpin = dcd_env("DCD_CONV_DIRECT_WX") ? atoi(dcd_env("DCD_CONV_DIRECT_WX")) : 0;
+        const int wx = P == 2 && wxpin == 2 ? 2 : 1;
+        p.geom = P | (wx << 4);
+        p.tiles_x = (W + 32 * wx - 1) / (32 * wx);
         p.tiles_y = (H + 4 * P - 1) / (4 * P);
         p.nchunk = (Cc + DC_CH - 1) / DC_CH;
         p.nb = Kk <= 32 ? 1 : 2;
         p.nz = (Kk + 32 * p.nb - 1) / (32 * p.nb);
         const int64_t wgs = (int64_t)p.tiles_x * p.tiles_y * B * p.nz;
-        // three workgroups share a CU (164 registers); split the contraction while slots would stay empty and a split keeps 16 chunks
-        // (256 -> 256 @ 24x80 x 8: 46.5 us split in two or not, and the split pays a wino_sum_partials launch)
+        // Three workgroups share a CU.  A long contraction is split while slots would stay empty and a split keeps 16 chunks
+        // (256 -> 256 @ 24x80 x 8: 46.5 us split in two or not, and the split pays a wino_sum_partials launch); a launch of less
+        // than 1.5 workgroups per CU (one or two images per GPU) is split down to two chunks -- there a workgroup's chunks are a
+        // serial chain of load latencies (256 -> 256 @ 24x80 x 1: 27.7 us unsplit against the Winograd form's 14.5).
         static const int min_chunks = dcd_env("DCD_CONV_DIRECT_MINCHUNK") ? atoi(dcd_env("DCD_CONV_DIRECT_MINCHUNK")) : 16;
         int ks = 1;
-        while (ks < 8 && wgs * (ks * 2) <= 3 * cus && p.nchunk / (ks * 2) >= min_chunks) ks *= 2;
+        while (ks < 8) {
+            const int64_t next = wgs * ks * 2;
+            const int left = p.nchunk / (ks * 2);
+            const bool fill = next <= 3 * cus && left >= min_chunks;
+            const bool small = 2 * next <= 3 * cus && left >= 2;
+            if (!fill && !small) break;
+            ks *= 2;
+        }
         p.ksplit = ks;
         best = p;
     }
@@ -1141,15 +1153,21 @@ static ConvPlan conv_plan_direct(int B, int Cc, int H, int W, int Kk)
     return best;
 }
 
-template <int NB, int P, bool SA>
+template <int NB, int P, int MODE, int WX>
 static int conv_launch_direct(hipStream_t stream, const ConvPlan &pl, const float *input, const unsigned *wd, float *output, float *part,
                               const float *bias, const float *residual, int B, int Cc, int H, int W, int Kk)
 {
     static LdsLimit lds_limit;
-    const size_t ldsb = ((size_t)2 * (4 * P + 2) * DC_RS + (size_t)2 * 9 * NB * 64) * 16;
-    if (!lds_limit.raise((int)ldsb, conv3x3_direct_bf16<NB, P, SA>)) return DCD_ERR_LAUNCH;
-    hipLaunchKernelGGL((conv3x3_direct_bf16<NB, P, SA>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(DC_NT), ldsb, stream, input,
-                       wd, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    const size_t ldsb = ((size_t)2 * (4 * P + 2) * (32 * WX + 8) + (size_t)2 * 9 * NB * 64) * 16;
+    if constexpr (MODE == 2) {
+        if (!lds_limit.raise((int)ldsb, conv3x3_direct_bf16_w4<NB, P, WX>)) return DCD_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv3x3_direct_bf16_w4<NB, P, WX>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(DC_NT * WX), ldsb,
+                           stream, input, wd, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    } else {
+        if (!lds_limit.raise((int)ldsb, conv3x3_direct_bf16<NB, P, MODE, WX>)) return DCD_ERR_LAUNCH;
+        hipLaunchKernelGGL((conv3x3_direct_bf16<NB, P, MODE, WX>), dim3(pl.tiles_x * pl.tiles_y, B, pl.nz * pl.ksplit), dim3(DC_NT * WX), ldsb,
+                           stream, input, wd, output, part, bias, residual, Cc, H, W, Kk, pl.tiles_x, pl.nchunk, pl.nz);
+    }
     return DCD_OK;
 }
 
@@ -1406,7 +1424,7 @@ int dcd_conv3x3_bf16_prepared(void *stream_, const float *input, const void *tra
     if (!input || !transformed || !output || B <= 0 || Cin <= 0 || Cout <= 0 || H <= 0 || W <= 0) return DCD_ERR_BAD_ARG;
     if (bias && backward_data) return DCD_ERR_BAD_ARG;
     const int Cc = backward_data ? Cout : Cin, Kk = backward_data ? Cin : Cout;
-    if (!conv_direct_ok(Cc, H, W) || (int64_t)Kk * H * W >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    if (!conv_direct_ok(Cc, H, W) || (int64_t)Kk * H * W >= (1ll << 31) || (W & 3)) return DCD_ERR_BAD_ARG;
     const ConvPlan pl = conv_plan_direct(B, Cc, H, W, Kk);
     const size_t img = (size_t)B * Kk * H * W;
     const size_t need = (size_t)(pl.ksplit - 1) * img * sizeof(float);
@@ -1414,10 +1432,17 @@ int dcd_conv3x3_bf16_prepared(void *stream_, const float *input, const void *tra
     if (pl.ksplit > 1 && (img & 3)) return DCD_ERR_BAD_ARG;               // wino_sum_partials adds float4s
     float *part = (float *)workspace;
     const unsigned *wd = (const unsigned *)transformed;
-    static const bool sa = !(dcd_env("DCD_CONV_DIRECT_SA") && atoi(dcd_env("DCD_CONV_DIRECT_SA")) == 0);
-#define DCD_DIRECT(NB_, P_, SA_) conv_launch_direct<NB_, P_, SA_>(stream, pl, input, wd, output, part, bias, residual, B, Cc, H, W, Kk)
-    const int st = pl.nb == 2 ? (pl.geom == 4 ? DCD_DIRECT(2, 4, false) : sa ? DCD_DIRECT(2, 2, true) : DCD_DIRECT(2, 2, false))
-                              : (pl.geom == 4 ? DCD_DIRECT(1, 4, false) : sa ? DCD_DIRECT(1, 2, true) : DCD_DIRECT(1, 2, false));
+    // DCD_CONV_DIRECT_MODE: 0 weights resident, 1 window resident, 2 both streamed (default: 2 with 8 x 64 regions, else 1)
+    static const int mpin = dcd_env("DCD_CONV_DIRECT_MODE") ? atoi(dcd_env("DCD_CONV_DIRECT_MODE")) : -1;
+    const int P = pl.geom & 15, wx = pl.geom >> 4;
+    const int mode = P == 4 ? 0 : (mpin >= 0 ? mpin : 1);
+#define DCD_DIRECT(NB_, P_, M_, WX_) conv_launch_direct<NB_, P_, M_, WX_>(stream, pl, input, wd, output, part, bias, residual, B, Cc, H, W, Kk)
+#define DCD_DIRECT_NB(NB_)                                                                                                              \
+    (P == 4 ? DCD_DIRECT(NB_, 4, 0, 1)                                                                                                  \
+            : wx == 2 ? (mode == 2 ? DCD_DIRECT(NB_, 2, 2, 2) : DCD_DIRECT(NB_, 2, 1, 2))                                               \
+                      : (mode == 2 ? DCD_DIRECT(NB_, 2, 2, 1) : mode == 1 ? DCD_DIRECT(NB_, 2, 1, 1) : DCD_DIRECT(NB_, 2, 0, 1)))
+    const int st = pl.nb == 2 ? DCD_DIRECT_NB(2) : DCD_DIRECT_NB(1);
+#undef DCD_DIRECT_NB
 #undef DCD_DIRECT
     if (st != DCD_OK) return st;
     if (pl.ksplit > 1) {
@@ -1465,6 +1490,18 @@ int dcd_conv3x3_wrw(void *stream_, const float *input, const float *grad_output,
     wrw_partition(B, Cin, H, W, Cout, nog, ncg, S, strips_x, KO);
     const int nblk = nog * ncg;
     if (workspace_bytes < (size_t)nblk * S * 12 * KO * 64 * sizeof(float)) return DCD_ERR_WORKSPACE;
+    static const bool wrw_direct = !(dcd_env("DCD_CONV_WRW_DIRECT") && atoi(dcd_env("DCD_CONV_WRW_DIRECT")) == 0);
+    if (bf && KO == 64 && wrw_direct && (int64_t)B * (Cin > Cout ? Cin : Cout) * H * W < (1ll << 29)) {
+        // one-product form, more than 32 outputs: the direct kernel (conv_direct_bf16.inc), same partition and workspace
+        static LdsLimit lds_limit;
+        const size_t ldsb = (size_t)DW_LDS * sizeof(unsigned);
+        if (!lds_limit.raise((int)ldsb, conv3x3_wrw_direct_bf16)) return DCD_ERR_LAUNCH;
+        hipLaunchKernelGGL(conv3x3_wrw_direct_bf16, dim3(nblk * S), dim3(DW_NT), ldsb, stream, input, grad_output, (float *)workspace, Cin,
+                           Cout, B, H, W, strips_x, S, ncg, nblk);
+        hipLaunchKernelGGL(conv3x3_wrw_direct_reduce, dim3(64, 3, nblk), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cin, Cout,
+                           S, ncg);
+        return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+    }
     if (KO == 64) {
         static LdsLimit lds_limit;
         const size_t ldsb = (size_t)2 * WrwGeom<2>::BUF * sizeof(float);

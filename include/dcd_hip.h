@@ -60,8 +60,10 @@ const char *dcd_version(void);
  *   DCD_CONV_MINCHUNK    smallest number of 8-channel chunks a split of the Winograd contraction keeps.  Default 4.
  *   DCD_CONV_DIRECT_MINCHUNK  the same for the direct bf16 form's 16-channel chunks.  Default 16.
  *   DCD_CONV_DIRECT_P *  4: 16 x 32 px regions (one workgroup per CU) instead of 8 x 32 in the direct bf16 form.  Default 2.
- *   DCD_CONV_DIRECT_SA * 0: the direct bf16 form keeps a chunk's weights in registers and streams the window (two workgroups per CU
- *                        instead of three).  Default 1.
+ *   DCD_CONV_WRW_DIRECT * 0: the one-product weight gradient stays on the Winograd-domain kernel.  Default 1 (direct, Cout > 32).
+ *   DCD_CONV_DIRECT_MODE * operand residency of the direct bf16 form: 0 weights in registers, 1 window operands in registers, 2 both
+ *                        streamed from LDS (four waves per SIMD).  Default 1.
+ *   DCD_CONV_DIRECT_WX * 2: 8 x 64 px regions (eight waves) in the direct bf16 form.  Default 1 (8 x 32).
  *   DCD_BN_SMALL         0: no single-workgroup-per-channel BatchNorm kernels for small maps.  Default on.
  *   DCD_CHANNEL_SUM_ONE_LAUNCH   1 | 0: pin the per-channel sums to the one-launch / two-launch form.  Default: by grid size.
  *   DCD_UP_FWD_OLD, DCD_UP_BWD_OLD   set: the round-1 depthwise up-sampling kernels.
@@ -532,7 +534,7 @@ int dcd_conv3x3_split_prepared(void *stream, const float *input, const void *tra
  * transform -- on the bf16 matrix pipe the transform's vector / LDS work, not the multiplies, was the kernel's time -- fp32
  * accumulate, fp32 tensors in HBM.  Own weight layout (both directions, either pointer may be NULL; the table form takes the
  * five-word entries of dcd_conv3x3_transform_weights_table with buffers of dcd_conv3x3_bf16_weights_bytes); workspace: the partial
- * images of a split contraction.  Any Cin / Cout / H / W with (max(Cin, Cout) + 16) H W < 2^29; a split contraction
+ * images of a split contraction.  W % 4 == 0; any Cin / Cout / H with (max(Cin, Cout) + 16) H W < 2^29; a split contraction
  * (dcd_conv3x3_bf16_workspace_bytes > 16) needs B Cout H W % 4 == 0.  bias only with backward_data == 0. */
 size_t dcd_conv3x3_bf16_weights_bytes(int Cin, int Cout, int backward_data);
 int dcd_conv3x3_bf16_transform_weights(void *stream, const float *weight, int Cin, int Cout, void *forward_out, void *backward_out);

@@ -29,6 +29,11 @@ GROUPS = [
 ]
 
 
+# PMC_EXTRA="A,B;C,D": additional counter groups (one pass each), e.g. the TCP / TCC latency counters for one kernel
+if os.environ.get("PMC_EXTRA"):
+    GROUPS = GROUPS + [g.split(",") for g in os.environ["PMC_EXTRA"].split(";") if g]
+
+
 def short(name):
     name = re.sub(r"\(anonymous namespace\)::", "", name)
     name = re.sub(r"^void\s+", "", name)
