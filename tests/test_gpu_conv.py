@@ -479,10 +479,11 @@ def test_conv3x3_split_bf16_form(cuda, monkeypatch, B, C, K, H, W):
 
 @pytest.mark.parametrize("B,C,K,H,W", CASES + [(2, 64, 27, 24, 64), (1, 128, 27, 12, 40), (8, 64, 64, 96, 320)])
 def test_conv3x3_mixed_bf16_form(cuda, monkeypatch, B, C, K, H, W):
-    """`_ext.precision_scope("bf16")` (MODEL.FP16): forward and input gradient on wino_conv3x3_split<., 1> and the weight gradient on
-    wino_wrw3x3_f32<., true> -- the Winograd-domain products as ONE product of bf16-rounded operands on the bf16 matrix cores, fp32
-    accumulate -- against conv2d in fp64.  Operand rounding is 2^-9 each, on TRANSFORMED values (sums of up to four inputs / nine
-    weights): held to 1.5e-2 of the output scale, required to be above 1e-4 (it is not the fp32 kernel), with bias and residual; the
+    """`_ext.precision_scope("bf16")` (MODEL.FP16): forward and input gradient on conv3x3_direct_bf16 and the weight gradient on
+    conv3x3_wrw_direct_bf16 (Cout > 32; wino_wrw3x3_f32<1, true> below) -- ONE product of bf16-rounded operands on the bf16 matrix
+    cores, fp32 accumulate -- against conv2d in fp64 (DCD_CONV_BF16_DIRECT=0 / DCD_CONV_WRW_DIRECT=0 run the Winograd-domain forms
+    wino_conv3x3_split<., 1> / wino_wrw3x3_f32<2, true> through the same test).  Operand rounding is 2^-9 each (in the Winograd
+    forms on TRANSFORMED values, sums of up to four inputs / nine weights): held to 1.5e-2 of the output scale, required to be above 1e-4 (it is not the fp32 kernel), with bias and residual; the
     autograd node remembers the scope for its backward (which runs outside it)."""
     from dcd_amd import _ext, ops
     g = torch.Generator().manual_seed(C * 7 + K)
@@ -521,6 +522,59 @@ def test_conv3x3_mixed_bf16_form(cuda, monkeypatch, B, C, K, H, W):
         _close(xg.grad.cpu(), ref_gx, "bf16 autograd grad_input", 1.5e-2)
         _close(wg.grad.cpu(), ref_gw, "bf16 autograd grad_weight", 1.5e-2)
         assert (wg.grad - gw32).abs().max().item() > 1e-4 * gw32.abs().max().item()     # the backward kept the forward's precision
+
+
+@pytest.mark.parametrize("B,C,K,H,W", [(2, 64, 64, 16, 32), (2, 72, 80, 10, 36), (1, 512, 72, 12, 40), (1, 256, 64, 9, 32), (3, 27, 64, 14, 44),
+                                       (1, 64, 27, 24, 64), (1, 16, 16, 96, 128), (2, 128, 256, 24, 80)])
+def test_conv3x3_direct_bf16_is_the_exact_product_of_rounded_operands(cuda, B, C, K, H, W):
+    """The direct one-product kernels through the C ABI (dcd_conv3x3_bf16_*, dcd_conv3x3_wrw with DCD_PREC_BF16): they round inputs
+    and weights to bf16 ONCE and accumulate in fp32, so against conv2d in fp64 of the SAME bf16-rounded operands only the fp32
+    accumulation is left -- 2e-5 of the output scale (the 1.5e-2 of the test above is the rounding itself).  Ragged channel counts
+    (72, 27: the last chunk reads past the tensor and must get zeros), odd heights, partial regions, split contractions (small
+    maps, one image), bias / residual; and the entry points' argument checks."""
+    from dcd_amd import _lib, ops
+    L = _lib.lib()
+    g = torch.Generator().manual_seed(C * 11 + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    bias = torch.randn(K, generator=g)
+    res = torch.randn(B, K, H, W, generator=g)
+    gy = torch.randn(B, K, H, W, generator=g)
+    r = lambda t: t.bfloat16().double()
+    ref = F.conv2d(r(x), r(w), bias.double(), padding=1) + res.double()
+    ref_gx = torch.nn.grad.conv2d_input(x.shape, r(w), r(gy), padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(r(x), w.shape, r(gy), padding=1)
+    xd, wd, bd, gd = x.to(cuda), w.to(cuda), bias.to(cuda), gy.to(cuda)
+    st = _lib.stream_of(xd)
+    tf = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(C, K, 0) // 4, dtype=torch.int32, device=cuda)
+    tb = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(C, K, 1) // 4, dtype=torch.int32, device=cuda)
+    assert L.dcd_conv3x3_bf16_transform_weights(st, wd.data_ptr(), C, K, tf.data_ptr(), tb.data_ptr()) == 0
+    n = L.dcd_conv3x3_bf16_workspace_bytes(B, C, H, W, K)
+    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=cuda)
+    y = res.to(cuda).clone()
+    assert L.dcd_conv3x3_bf16_prepared(st, xd.data_ptr(), tf.data_ptr(), bd.data_ptr(), y.data_ptr(), y.data_ptr(), B, C, H, W, K, 0,
+                                       ws.data_ptr(), n) == 0
+    gx = torch.empty_like(xd)
+    assert L.dcd_conv3x3_bf16_prepared(st, gd.data_ptr(), tb.data_ptr(), None, None, gx.data_ptr(), B, C, H, W, K, 1, ws.data_ptr(), n) == 0
+    _close(y.cpu(), ref, "direct forward", 2e-5)
+    _close(gx.cpu(), ref_gx, "direct grad_input", 2e-5)
+    if W % 4 == 0 and H % 2 == 0:
+        gw = ops._conv3x3_wrw_call(xd, gd, w.shape, ops.PREC_BF16)
+        if K > 32:                                           # the direct weight gradient; <= 32 outputs run the Winograd-domain form
+            _close(gw.cpu(), ref_gw, "direct grad_weight", 2e-5)
+        else:
+            _close(gw.cpu(), ref_gw, "grad_weight", 1.5e-2)
+    # argument checks: W % 4, bias with backward_data, a null pointer, a workspace too small for a split contraction
+    bad = torch.randn(1, 64, 8, 30, device=cuda)
+    t64 = torch.empty(L.dcd_conv3x3_bf16_weights_bytes(64, 64, 0) // 4, dtype=torch.int32, device=cuda)
+    assert L.dcd_conv3x3_bf16_prepared(st, bad.data_ptr(), t64.data_ptr(), None, None, bad.data_ptr(), 1, 64, 8, 30, 64, 0, ws.data_ptr(), n) == 1
+    assert L.dcd_conv3x3_bf16_prepared(st, gd.data_ptr(), tb.data_ptr(), bd.data_ptr(), None, gx.data_ptr(), B, C, H, W, K, 1, ws.data_ptr(), n) == 1
+    assert L.dcd_conv3x3_bf16_prepared(st, None, tb.data_ptr(), None, None, gx.data_ptr(), B, C, H, W, K, 1, ws.data_ptr(), n) == 1
+    assert L.dcd_conv3x3_bf16_transform_weights(st, wd.data_ptr(), C, K, None, None) == 1
+    if n > 16:                                               # at least one direction splits its contraction
+        codes = {L.dcd_conv3x3_bf16_prepared(st, xd.data_ptr(), tf.data_ptr(), None, None, y.data_ptr(), B, C, H, W, K, 0, ws.data_ptr(), 16),
+                 L.dcd_conv3x3_bf16_prepared(st, gd.data_ptr(), tb.data_ptr(), None, None, gx.data_ptr(), B, C, H, W, K, 1, ws.data_ptr(), 16)}
+        assert 2 in codes and codes <= {0, 2}
 
 
 @pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80)])
