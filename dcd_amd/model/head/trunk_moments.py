@@ -326,7 +326,9 @@ class _TrunkScaleShift(torch.autograd.Function):
         _lib.check(L.dcd_trunk_grad_wg(st, dsums.data_ptr(), Wd.data_ptr(), R, K, dWG.data_ptr()), "dcd_trunk_grad_wg")
         # sum y^2 = sum_k WG[r][k] Wd[r][k] depends on Wd twice: through the product and directly
         dWd = torch.addcmul(dWG @ GS.t(), dsums[:, 1:2], WG[:, :K])
-        dGS = Wd.t() @ dWG                                                                      # (K, K + 1)
+        # (K, K + 1); the transposed view as the first operand makes hipBLASLt pick a 159 us fp64 kernel at DGDE's 2816 x 576 where
+        # the same product from a contiguous copy takes 59 (+ 8 for the copy): tools/scratch/f64_gemm_variants.py
+        dGS = (Wd.t().contiguous() @ dWG) if Wd.is_cuda else Wd.t() @ dWG
         return dWd.float().view(T, O, K), dGS[:, K], dGS[:, :K], dgamma.view(T, O), dbeta.view(T, O), None, None, None
 
 
