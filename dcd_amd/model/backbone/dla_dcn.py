@@ -109,7 +109,12 @@ class Tree(nn.Module):
     def forward(self, x, residual=None, children=None):
         children = [] if children is None else children
         bottom = self.downsample(x) if self.downsample else x
-        residual = self.project(bottom) if self.project else bottom
+        if (self.project is not None and _ROOT_SPLIT and bottom.is_cuda and bottom.dtype == torch.float32
+                and ops._conv_prec(bottom) == ops.PREC_BF16):
+            # MODEL.FP16: the 1x1 projection on the bf16 pointwise kernel (csrc/conv1x1_bf16.inc) like the Roots
+            residual = self.project[1](ops.conv1x1_of_cat([bottom], self.project[0].weight))
+        else:
+            residual = self.project(bottom) if self.project else bottom
         if self.level_root:
             children.append(bottom)
         x1 = self.tree1(x, residual)

@@ -513,6 +513,16 @@ class _Conv1x1OfCat(torch.autograd.Function):
         B, _, H, W = xs[0].shape
         O = weight.shape[0]
         w2 = weight.reshape(O, -1)
+        # MODEL.FP16 (the bf16 precision scope): one launch of csrc/conv1x1_bf16.inc over all inputs, the backward on the same file
+        # (from 7 680 pixels per launch on: below, a workgroup's channel loop is a serial chain the library's split GEMMs beat --
+        # 512+512+256 -> 512 @ 12x40 x 8: 96 us against 77)
+        ctx.bf16 = (_PW_BF16 and _conv_prec(xs[0]) == PREC_BF16 and len(xs) <= 4 and (H * W) % 4 == 0 and B * H * W >= _PW_MIN_PIXELS
+                    and all(x.shape[1] % 16 == 0 for x in xs) and weight.dtype == torch.float32 and w2.is_contiguous())
+        if ctx.bf16:
+            out = _pw_conv_bf16(w2, 0, False, xs, O)
+            ctx.save_for_backward(w2, *xs)
+            ctx.wshape = weight.shape
+            return out
         out = torch.empty((B, O, H, W), dtype=torch.float32, device=xs[0].device)
         o3 = out.view(B, O, H * W)
         c0 = 0
@@ -534,6 +544,21 @@ class _Conv1x1OfCat(torch.autograd.Function):
         w2, *xs = ctx.saved_tensors
         g = _f32c(g)
         B, O, H, W = g.shape
+        if ctx.bf16:
+            L = _lib.lib()
+            gw = torch.empty_like(w2)
+            Ct, HW = w2.shape[1], H * W
+            gxs, c0 = [], 0
+            for i, x in enumerate(xs):
+                Ci = x.shape[1]
+                gxs.append(_pw_conv_bf16(w2, c0, True, [g], Ci) if ctx.needs_input_grad[1 + i] else None)
+                if ctx.needs_input_grad[0]:
+                    n = L.dcd_conv1x1_wrw_bf16_workspace_bytes(B, O, Ci, HW)
+                    ws = torch.empty(max(n, 16), dtype=torch.uint8, device=g.device)
+                    _lib.check(L.dcd_conv1x1_wrw_bf16(_lib.stream_of(g), g.data_ptr(), x.data_ptr(), gw.data_ptr() + 4 * c0, Ct, B, O, Ci, HW,
+                                                      ws.data_ptr(), n), "dcd_conv1x1_wrw_bf16")
+                c0 += Ci
+            return ((gw.reshape(ctx.wshape) if ctx.needs_input_grad[0] else None),) + tuple(gxs)
         g3 = g.view(B, O, H * W)
         gw = torch.empty_like(w2)
         gxs, c0 = [], 0
@@ -548,6 +573,26 @@ class _Conv1x1OfCat(torch.autograd.Function):
             torch.sum(torch.bmm(g3, x3.transpose(1, 2)), 0, out=gw[:, c0:c0 + Ci])
             c0 += Ci
         return (gw.reshape(ctx.wshape),) + tuple(gxs)
+
+
+_PW_BF16 = os.environ.get("DCD_CONV1X1_BF16", "1") != "0"        # 0: the 1x1 convolutions stay fp32 library GEMMs under MODEL.FP16 (A/B)
+_PW_MIN_PIXELS = int(os.environ.get("DCD_CONV1X1_BF16_MIN_PIXELS", "7680"))
+
+
+def _pw_conv_bf16(w2, col0, transposed, xs, M):
+    """out (B, M, H, W) = A . cat(xs) on csrc/conv1x1_bf16.inc: A = w2 (M = rows), or w2[:, col0:col0 + M]^T (`transposed`: the input
+    gradient of that column slice, xs = [grad_output])."""
+    import ctypes
+    L = _lib.lib()
+    B, _, H, W = xs[0].shape
+    n = len(xs)
+    ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
+    chs = (ctypes.c_int * n)(*[x.shape[1] for x in xs])
+    out = torch.empty((B, M, H, W), dtype=torch.float32, device=xs[0].device)
+    st = L.dcd_conv1x1_bf16(_lib.stream_of(xs[0]), w2.data_ptr() + 4 * col0, w2.shape[1], 1 if transposed else 0, n, ptrs, chs,
+                            out.data_ptr(), B, M, H * W)
+    _lib.check(st, "dcd_conv1x1_bf16")
+    return out
 
 
 def conv1x1_of_cat(xs, weight):

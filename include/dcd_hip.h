@@ -544,6 +544,20 @@ int dcd_conv3x3_bf16_prepared(void *stream, const float *input, const void *tran
                               float *output, int B, int Cin, int H, int W, int Cout, int backward_data, void *workspace,
                               size_t workspace_bytes);
 
+/* 1x1 convolutions (DLA's Roots and projections: DGDE/model/backbone/dla_dcn.py:187-207, 239-245) in the one-product form
+ * (DCD_PREC_BF16; csrc/conv1x1_bf16.inc), fp32 tensors, operands rounded to bf16, fp32 accumulate:
+ *   dcd_conv1x1_bf16      output (B, M, HW) = A x, x = the concatenation along the channels of n_inputs (<= 4) tensors
+ *                         (B, channels[i], HW) that is never formed; A[m][k] = weight[m * ldw + k], or weight[k * ldw + m] when
+ *                         `transposed` (the input gradient of a column slice: pass weight + first column).  inputs / channels are
+ *                         HOST arrays.  HW % 4 == 0, channels[i] % 16 == 0.
+ *   dcd_conv1x1_wrw_bf16  grad_weight[o * ldw + c] = sum_{b, p} grad_output[b][o][p] input[b][c][p] (overwrites the O x C block;
+ *                         partial sums in a fixed order); workspace: dcd_conv1x1_wrw_bf16_workspace_bytes. */
+int dcd_conv1x1_bf16(void *stream, const float *weight, int ldw, int transposed, int n_inputs, const float *const *inputs,
+                     const int *channels, float *output, int B, int M, long long HW);
+size_t dcd_conv1x1_wrw_bf16_workspace_bytes(int B, int O, int C, long long HW);
+int dcd_conv1x1_wrw_bf16(void *stream, const float *grad_output, const float *input, float *grad_weight, int ldw, int B, int O, int C,
+                         long long HW, void *workspace, size_t workspace_bytes);
+
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).

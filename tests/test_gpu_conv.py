@@ -577,6 +577,46 @@ def test_conv3x3_direct_bf16_is_the_exact_product_of_rounded_operands(cuda, B, C
         assert 2 in codes and codes <= {0, 2}
 
 
+@pytest.mark.parametrize("B,cs,O,H,W", [(2, (64, 64), 64, 24, 80), (1, (128, 128, 64, 128), 128, 12, 40), (2, (64,), 128, 16, 20),
+                                        (1, (512, 512, 256), 512, 12, 40), (3, (16, 32), 48, 6, 10), (8, (64, 64), 64, 96, 320)])
+def test_conv1x1_of_cat_in_the_bf16_scope(cuda, monkeypatch, B, cs, O, H, W):
+    """ops.conv1x1_of_cat under `_ext.precision_scope("bf16")` (MODEL.FP16): forward, input gradients and weight gradient on
+    csrc/conv1x1_bf16.inc -- the exact product of the bf16-rounded operands with fp32 accumulation: 2e-5 of the output scale against
+    conv2d in fp64 of the SAME rounded operands (and within 1.5e-2 of the unrounded fp64 result); several inputs, a pixel count that
+    is not a multiple of the 512-pixel workgroup tile or of the 64-pixel weight-gradient strip, 48 outputs (a partial 64-row slice);
+    the backward keeps the forward's precision outside the scope."""
+    from dcd_amd import _ext, ops
+    monkeypatch.setattr(ops, "_PW_MIN_PIXELS", 0)              # the small launches too (the dispatch keeps them on the library)
+    g = torch.Generator().manual_seed(sum(cs) + O)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    C = sum(cs)
+    w = torch.randn(O, C, 1, 1, generator=g) / C ** 0.5
+    gy = torch.randn(B, O, H, W, generator=g)
+    r = lambda t: t.bfloat16().double()
+    xcat = torch.cat(xs, 1)
+    ref = F.conv2d(r(xcat), r(w))
+    ref_gx = torch.nn.grad.conv2d_input(xcat.shape, r(w), r(gy))
+    ref_gw = torch.nn.grad.conv2d_weight(r(xcat), w.shape, r(gy))
+    exact = F.conv2d(xcat.double(), w.double())
+    xd = [x.to(cuda).requires_grad_(True) for x in xs]
+    wd = w.to(cuda).requires_grad_(True)
+    with _ext.precision_scope("bf16"):
+        y = ops.conv1x1_of_cat(xd, wd)
+    assert _ext.get_precision() == "f32"
+    y.backward(gy.to(cuda))
+    _close(y.detach().cpu(), ref, "1x1 forward", 2e-5)
+    _close(y.detach().cpu(), exact, "1x1 forward vs unrounded", 1.5e-2)
+    assert (y.detach().cpu().double() - exact).abs().max().item() > 1e-4 * exact.abs().max().item()      # it IS the bf16 form
+    c0 = 0
+    for x, c in zip(xd, cs):
+        _close(x.grad.cpu(), ref_gx[:, c0:c0 + c], "1x1 grad_input", 2e-5)
+        c0 += c
+    _close(wd.grad.cpu(), ref_gw, "1x1 grad_weight", 2e-5)
+    # the fp32 form of the same call (outside the scope) is untouched
+    y32 = ops.conv1x1_of_cat([x.detach() for x in xd], wd.detach())
+    _close(y32.cpu(), exact, "1x1 fp32 forward", 2e-5)
+
+
 @pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80)])
 def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     """ops.conv3x3_stride2: the stride-2 / pad-1 3x3 convolution of the DLA levels as a stride-1 convolution of the pixel-unshuffled
