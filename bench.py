@@ -29,7 +29,6 @@ import argparse
 import json
 import os
 
-os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")     # before torch loads MIOpen: see dcd_amd/__init__.py
 import subprocess
 import sys
 import time

@@ -15,11 +15,12 @@ import os as _os
 
 __version__ = "0.1.0"
 
-# MIOpen's composable-kernel "grouped conv backward data" solver (picked for one of DLA's stride-2 3x3 layers) zero-fills its
-# output with hipMemsetAsync and accumulates into it.  Inside a captured HIP graph that is a memset node, and memset nodes are
-# not ordered reliably against their kernels on this stack (profiles/r02_graph_memset_hazard.txt; round 5: the graphed train
-# step's ATen reductions with memset-cleared semaphores returned wrong sums in some replays).  With the solver off MIOpen takes
-# its assembly Winograd kernel for that layer (same step time, 38.13 vs 38.21 ms); set the variable yourself to keep the solver.
-# MIOpen reads it when the library is loaded, i.e. at `import torch`: a process that imports torch before this package must
-# export it itself (bench.py, tests/conftest.py and __graft_entry__.py do).
-_os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")
+# MIOpen's composable-kernel "grouped conv backward data" solver (its pick for the input gradient of DLA's stride-2 3x3 layers at
+# bs 8) zero-fills its output with hipMemsetAsync and accumulates into it.  Inside a captured HIP graph that is a memset node, and
+# memset nodes are not ordered reliably against their kernels on this stack (profiles/r02_graph_memset_hazard.txt; round 5: ATen
+# reductions with memset-cleared semaphores returned wrong sums in some replays of the graphed train step).  Round 5 first tried to
+# switch the solver off through MIOPEN_DEBUG_* variables: the name it exported is not read by the MIOpen build inside PyTorch, and
+# the three names that build does read (..._3D_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS, ..._HIP_GROUP_BWD_XDLOPS, ..._HIP_BWD_XDLOPS) did
+# not keep the solver out either (tools/scratch/miopen_env_probe.py; tools/check_graph_memsets.sh caught it at bs 8).  What does:
+# a process that builds a whole-step graph runs these layers on our own kernels (ops.stride2_on_own_kernels, called by
+# engine.trainer.GraphedTrainStep) -- no MIOpen convolution is left in the captured step.  No environment is touched here.

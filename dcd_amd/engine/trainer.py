@@ -373,6 +373,8 @@ class GraphedTrainStep:
         (every few thousand steps costs nothing measurable: a capture is ~3 eager steps); `recapture()` does it on demand.  The
         count is per call of this object, so data-parallel ranks re-capture in the same call."""
         self.model, self.optimizer, self.clip, self.warmup = model, optimizer, grad_norm_clip, warmup
+        if any(p.is_cuda for p in model.parameters()):
+            ops.stride2_on_own_kernels()                   # no MIOpen backward-data solver (memset + accumulate) in the captured step
         self.distributed, self.group = distributed, group
         self.recapture_every, self._replays = recapture_every, 0
         self._graphs = {}
@@ -475,11 +477,6 @@ class GraphedTrainStep:
 
     def _capture(self, images, targets):
         import copy
-        if images.is_cuda and os.environ.get("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS") != "0":
-            import warnings
-            warnings.warn("capturing the train step with MIOpen's memset + accumulate backward-data solver enabled: export "
-                          "MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS=0 before `import torch` (INTEGRATION.md section 4: "
-                          "memset nodes are not ordered reliably inside a replayed HIP graph on this stack)")
         entry = {"static": self._static_copy(images, targets)}
         self._copy_in(entry, images, targets)
         st_images, st_targets = entry["static"][0], entry["static"][1]

@@ -109,9 +109,9 @@ class Tree(nn.Module):
     def forward(self, x, residual=None, children=None):
         children = [] if children is None else children
         bottom = self.downsample(x) if self.downsample else x
-        if (self.project is not None and _ROOT_SPLIT and bottom.is_cuda and bottom.dtype == torch.float32
-                and ops._conv_prec(bottom) == ops.PREC_BF16):
-            # MODEL.FP16: the 1x1 projection on the bf16 pointwise kernel (csrc/conv1x1_bf16.inc) like the Roots
+        if self.project is not None and _ROOT_SPLIT and bottom.is_cuda and bottom.dtype == torch.float32:
+            # the 1x1 projection as a (one-input) `conv1x1_of_cat` like the Roots: batched GEMMs in exact fp32, the bf16 pointwise
+            # kernel (csrc/conv1x1_bf16.inc) under MODEL.FP16 -- no MIOpen call, no NHWC transposes
             residual = self.project[1](ops.conv1x1_of_cat([bottom], self.project[0].weight))
         else:
             residual = self.project(bottom) if self.project else bottom

@@ -1246,7 +1246,19 @@ def conv3x3_with_skip(x, weight):
 # on the stride-1 Winograd kernels, through space-to-depth
 # ----------------------------------------------------------------------------------------------
 _S2D_INDEX = {}
-_S2D_MODE = os.environ.get("DCD_CONV_S2D", "auto")      # 1: always, 0: never (stock solver), auto: in the bf16 precision modes
+_S2D_MODE = os.environ.get("DCD_CONV_S2D", "auto")      # 1: always, 0: never (stock solver), auto: in the bf16 precision modes (and everywhere once a whole-step graph is built)
+
+
+def stride2_on_own_kernels():
+    """From now on the stride-2 3x3 convolutions of this process take the space-to-depth path on our kernels in exact fp32 too (what
+    DCD_CONV_S2D=1 selects at start-up).  Called by `engine.trainer.GraphedTrainStep`: MIOpen's pick for these layers' input
+    gradient at bs 8 can be a composable-kernel solver that zero-fills its output with hipMemsetAsync and accumulates -- a memset
+    node in the captured step -- and no MIOPEN_DEBUG_* switch of the MIOpen build inside PyTorch
+    turned it off reliably (tools/scratch/miopen_env_probe.py); with the layers on our kernels the traced bs-8 graph has no
+    memset and no MIOpen convolution left.  Costs the graphed fp32 step 0.4-0.6 ms (the regrouped filter's 4x multiplies)."""
+    global _S2D_MODE
+    if _S2D_MODE == "auto":
+        _S2D_MODE = "1"
 
 
 def _s2d_index(K, C, device):
@@ -1294,7 +1306,8 @@ def conv3x3_stride2_supported(x, weight):
     if _S2D_MODE == "0" or not (x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
         return False
     if _S2D_MODE != "1" and _conv_prec() == PREC_F32:
-        return False
+        return False                                   # exact fp32 keeps the stock solver (2.72 against 3.75 ms per bs-8 step) unless
+                                                       # a whole-step graph is in use (stride2_on_own_kernels)
     H, W = x.shape[2], x.shape[3]
     return H % 4 == 0 and W % 8 == 0 and 4 * weight.shape[1] >= 64 and (H // 2) * (W // 2) >= _CONV_MIN_MAP
 

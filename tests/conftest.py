@@ -1,7 +1,6 @@
 import os
 import sys
 
-os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")     # before torch loads MIOpen: see dcd_amd/__init__.py
 
 import pytest
 

@@ -2,7 +2,6 @@
 evaluated op by op, during eager training: instance A trains with the loss graph, instance B (learning rate zero, loss graph off)
 takes A's weights every five steps; A's next step's gradients against B's."""
 import argparse, os, sys
-os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import bench

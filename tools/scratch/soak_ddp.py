@@ -1,7 +1,6 @@
 """One-rank data-parallel soak (SyncBN + gradient all-reduce over a world-size-1 RCCL group): the graphed distributed step and the
 eager DDP step against the plain eager step, 150 steps over four batches."""
 import argparse, os, sys
-os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")
 os.environ["DCD_FORCE_DDP"] = "1"
 os.environ.setdefault("MASTER_ADDR", "127.0.0.1"); os.environ.setdefault("MASTER_PORT", "29577")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))

@@ -1,7 +1,6 @@
 """GMW train step: 120 steps on one synthetic batch with the extractor graphs (default) and without (DCD_GMW_GRAPH=0): the losses
 must follow the same trajectory (deterministic-ish GEMM / Conv1d kernels: any gap is the graph)."""
 import os, sys
-os.environ.setdefault("MIOPEN_DEBUG_GROUP_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS", "0")
 sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
 import torch
 import bench
