@@ -131,3 +131,22 @@ def test_edge_branch_keeps_the_reference_modules_and_keys():
     assert list(a.state_dict().keys()) == list(b.state_dict().keys())
     x = torch.randn(2, 8, 13)
     assert torch.equal(a(x), b(x))
+
+
+def test_graph_processes_run_the_stride2_layers_on_own_kernels(monkeypatch):
+    """`ops.stride2_on_own_kernels()` (called by GraphedTrainStep for a model on the GPU) turns the "auto" dispatch of the stride-2
+    3x3 convolutions into "always space-to-depth on our kernels": MIOpen's input-gradient solver for these layers memsets its
+    output, and a memset node inside a captured step is not ordered reliably on this stack.  An explicit
+    DCD_CONV_S2D=0 / 1 is left alone; a CPU model does not flip it."""
+    import torch
+    from dcd_amd import ops
+    from dcd_amd.engine import trainer
+    monkeypatch.setattr(ops, "_S2D_MODE", "auto")
+    model = torch.nn.Linear(4, 4)
+    trainer.GraphedTrainStep(model, torch.optim.SGD(model.parameters(), lr=0.1))
+    assert ops._S2D_MODE == "auto"                       # host model: nothing to capture, nothing changed
+    ops.stride2_on_own_kernels()
+    assert ops._S2D_MODE == "1"
+    monkeypatch.setattr(ops, "_S2D_MODE", "0")
+    ops.stride2_on_own_kernels()
+    assert ops._S2D_MODE == "0"
