@@ -1,0 +1,27 @@
+"""Train the bench model 36 steps (split-bf16, bs 8), then capture image 0 of every DCN layer's forward arguments of one more
+forward (+ the grad_output of its backward) into /tmp/dcn_layers.pt."""
+import argparse, os, sys
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "..", ".."))
+import torch
+import bench
+from dcd_amd.engine import trainer
+from dcd_amd.model.backbone.DCNv2 import dcn_v2 as D
+dev = torch.device("cuda:0")
+args = argparse.Namespace(batch=8, objects=6, precision="bf16x3", scaling="weak", amp=False)
+cfg, A, optA, images, targets = bench.build_everything(args, dev, 1, 0)[:5]
+for it in range(int(os.environ.get("STEPS", "36"))):
+    trainer.train_step(A, optA, images, targets, cfg.SOLVER.GRAD_NORM_CLIP)
+layers = []
+orig = D._backend.dcn_v2_forward
+def spy(input, weight, bias, offset, mask, *geom, **kw):
+    sel = [0, 3, 7] if os.environ.get("IMAGES", "3") == "3" else list(range(input.shape[0]))
+    layers.append({"x": input[sel].detach().cpu(), "w": weight.detach().cpu(), "b": bias.detach().cpu(), "off": offset[sel].detach().cpu(),
+                   "m": mask[sel].detach().cpu(), "geom": geom})
+    return orig(input, weight, bias, offset, mask, *geom, **kw)
+D._backend.dcn_v2_forward = spy
+A(images, targets)
+D._backend.dcn_v2_forward = orig
+torch.save(layers, "/tmp/dcn_layers.pt")
+for i, l in enumerate(layers):
+    o = l["off"]
+    print("layer %2d  %s -> %d  off |max| %.1f px, far(>=3px) %.4f" % (i, tuple(l["x"].shape), l["w"].shape[0], float(o.abs().max()), float((o.abs() >= 3).float().mean())))
