@@ -453,6 +453,19 @@ def load_pmc(per_rank, prec="f32"):
     MI355X_MICROARCH.md prescribes) and the time-weighted matrix-pipe busy fraction, plus the commit the passes were made from.
     (None, None, "absent", None) when the passes have not been made for this batch / precision (the committed passes are the
     fp32 step's; the mixed-precision kernels' counters are profiles/amp_pmc_r05.json, together with the Winograd kernels')."""
+    if prec == "bf16" and per_rank == 8:
+        # the mixed-precision step's passes cover the DCN, Winograd and GEMM kernels together: take the DCN kernels' rows
+        try:
+            with open(os.path.join(ROOT, "profiles", "amp_pmc_r05.json")) as f:
+                d = json.load(f)
+            steps = d["summary"]["steps_profiled"]
+            rows = [v for k, v in d["kernels"].items() if k.startswith("dcn_") or k.startswith("sgemm_bf16")]
+            by = sum(v["hbm_bytes_per_dispatch"] * v["dispatches"] for v in rows) / steps
+            wt = sum(v["avg_us_profiled"] * v["dispatches"] for v in rows)
+            busy = sum(v["mfma_busy"] * v["avg_us_profiled"] * v["dispatches"] for v in rows) / wt
+            return int(by), float(busy), "profiles/amp_pmc_r05.json (dcn_* and sgemm_bf16* rows)", d.get("commit", "unknown")
+        except (OSError, ValueError, KeyError, ZeroDivisionError):
+            return None, None, "absent for this precision", None
     if prec != "f32":
         return None, None, "absent for this precision", None
     for name in ("dcn_pmc_r05.json", "dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
