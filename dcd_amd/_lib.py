@@ -75,6 +75,9 @@ SIGNATURES = {
     "dcd_conv1x1_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t]),
+    "dcd_conv1x1_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
+    "dcd_conv1x1_wrw_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
+    "dcd_conv1x1_wrw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t]),
     "dcd_conv3x3_bf16_weights_bytes": (c_size_t, [c_int] * 3),
     "dcd_conv3x3_bf16_transform_weights": (c_int, [c_void_p, c_void_p, c_int, c_int, c_void_p, c_void_p]),
     "dcd_conv3x3_bf16_transform_weights_table": (c_int, [c_void_p, c_void_p, c_int]),

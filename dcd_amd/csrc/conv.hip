@@ -440,6 +440,7 @@ __device__ __forceinline__ void wino_prep_split_body(const float *__restrict__ w
 
 #include "conv_direct_bf16.inc"
 #include "conv1x1_bf16.inc"
+#include "conv1x1_f32.inc"
 
 // NP = 3: split-bf16 (hi*hi + hi*lo + lo*hi).  NP = 1 (DCD_PREC_BF16): ONE bf16 product per operand pair -- both operands rounded
 // to bf16 (round to nearest even), fp32 accumulate: the mixed-precision form (MODEL.FP16); the lo halves of the prepared weights
@@ -1515,6 +1516,70 @@ int dcd_conv1x1_wrw_bf16(void *stream_, const float *grad_output, const float *i
     if (!lds_limit.raise((int)ldsb, pw_wrw_bf16)) return DCD_ERR_LAUNCH;
     hipLaunchKernelGGL(pw_wrw_bf16, dim3(S, ncg, nog), dim3(PWW_NT), ldsb, stream, grad_output, input, (float *)workspace, B, O, C, HW, S);
     hipLaunchKernelGGL(pw_wrw_reduce, dim3(64, 4 * ncg, nog), dim3(256), 0, stream, (const float *)workspace, grad_weight, O, C, ldw, S, ncg);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+// ---- the same layers in exact fp32 (conv1x1_f32.inc)
+int dcd_conv1x1_f32(void *stream_, const float *weight, int ldw, int transposed, int n_inputs, const float *const *inputs,
+                    const int *channels, float *output, int B, int M, long long HW)
+{
+    (void)hipGetLastError();
+    if (!weight || !inputs || !channels || !output || n_inputs < 1 || n_inputs > 4 || B <= 0 || M <= 0 || HW <= 0 || (HW & 3) || ldw <= 0)
+        return DCD_ERR_BAD_ARG;
+    PwArgs a;
+    a.n_in = n_inputs;
+    a.K = 0;
+    for (int i = 0; i < 4; ++i) {
+        a.in[i] = i < n_inputs ? inputs[i] : nullptr;
+        a.ch[i] = i < n_inputs ? channels[i] : 0;
+        if (i < n_inputs && (!inputs[i] || channels[i] <= 0 || (channels[i] & 15) || (int64_t)channels[i] * HW >= (1ll << 29)))
+            return DCD_ERR_BAD_ARG;
+        a.K += a.ch[i];
+    }
+    if ((int64_t)M * HW >= (1ll << 31)) return DCD_ERR_BAD_ARG;
+    a.w = weight; a.ldw = ldw; a.wt = transposed ? 1 : 0; a.out = output; a.M = M; a.HW = HW;
+    const int nb = M <= 32 ? 1 : 2;
+    dim3 grid((unsigned)((HW + 511) / 512), B, (M + 32 * nb - 1) / (32 * nb));
+    if (nb == 2) hipLaunchKernelGGL(pw_conv_f32<2>, grid, dim3(PW_NT), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(pw_conv_f32<1>, grid, dim3(PW_NT), 0, (hipStream_t)stream_, a);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+static void pw_wrw_f32_partition(int B, int O, int C, long long HW, int &nog, int &ncg, int &S)
+{
+    nog = (O + 63) / 64;
+    ncg = (C + 63) / 64;
+    const int64_t T = (int64_t)B * ((HW + 63) / 64);
+    int64_t s = 2 * (int64_t)device_cus() / (nog * ncg);           // two workgroups per CU
+    if (s > T / 4) s = T / 4;
+    if (s < 1) s = 1;
+    S = (int)s;
+}
+
+size_t dcd_conv1x1_wrw_f32_workspace_bytes(int B, int O, int C, long long HW)
+{
+    if (B <= 0 || O <= 0 || C <= 0 || HW <= 0) return 0;
+    int nog, ncg, S;
+    pw_wrw_f32_partition(B, O, C, HW, nog, ncg, S);
+    return (size_t)nog * ncg * S * 64 * 64 * sizeof(float);
+}
+
+int dcd_conv1x1_wrw_f32(void *stream_, const float *grad_output, const float *input, float *grad_weight, int ldw, int B, int O, int C,
+                        long long HW, void *workspace, size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!grad_output || !input || !grad_weight || !workspace || B <= 0 || O <= 0 || C <= 0 || HW <= 0 || (HW & 3) || ldw < C)
+        return DCD_ERR_BAD_ARG;
+    if ((int64_t)B * (O > C ? O : C) * HW >= (1ll << 29)) return DCD_ERR_BAD_ARG;
+    int nog, ncg, S;
+    pw_wrw_f32_partition(B, O, C, HW, nog, ncg, S);
+    if (workspace_bytes < (size_t)nog * ncg * S * 64 * 64 * sizeof(float)) return DCD_ERR_WORKSPACE;
+    static LdsLimit lds_limit;
+    const size_t ldsb = (size_t)PWWF_LDS * sizeof(float);
+    if (!lds_limit.raise((int)ldsb, pw_wrw_f32)) return DCD_ERR_LAUNCH;
+    hipLaunchKernelGGL(pw_wrw_f32, dim3(S, ncg, nog), dim3(PWW_NT), ldsb, stream, grad_output, input, (float *)workspace, B, O, C, HW, S);
+    hipLaunchKernelGGL(pw_wrw_reduce_f32, dim3(64, 4 * ncg, nog), dim3(256), 0, stream, (const float *)workspace, grad_weight, O, C, ldw, S, ncg);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -339,7 +339,13 @@ def _sum_rows(t):
     this stack is not ordered reliably against its kernel (profiles/r02_graph_memset_hazard.txt)."""
     T, B, M, O = t.shape
     while M > 1:
+        # the largest divisor of M up to 64; an M whose smallest prime factor exceeds 64 (MAX_OBJECTS = 67, a border walk of
+        # 16 * 67 cells) has none but 1: zero-pad to a multiple of 64 instead, so every pass shrinks M
         c = next(d for d in range(min(M, 64), 0, -1) if M % d == 0)
+        if c == 1:
+            c = 64
+            t = torch.nn.functional.pad(t, (0, 0, 0, (-M) % c))
+            M = t.shape[2]
         t = t.reshape(T, B, M // c, c, O).sum(3)
         M = M // c
     return t.reshape(T, B, O).sum(1)

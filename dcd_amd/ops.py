@@ -516,10 +516,22 @@ class _Conv1x1OfCat(torch.autograd.Function):
         # MODEL.FP16 (the bf16 precision scope): one launch of csrc/conv1x1_bf16.inc over all inputs, the backward on the same file
         # (from 7 680 pixels per launch on: below, a workgroup's channel loop is a serial chain the library's split GEMMs beat --
         # 512+512+256 -> 512 @ 12x40 x 8: 96 us against 77)
-        ctx.bf16 = (_PW_BF16 and _conv_prec(xs[0]) == PREC_BF16 and len(xs) <= 4 and (H * W) % 4 == 0 and B * H * W >= _PW_MIN_PIXELS
-                    and all(x.shape[1] % 16 == 0 for x in xs) and weight.dtype == torch.float32 and w2.is_contiguous())
-        if ctx.bf16:
-            out = _pw_conv_bf16(w2, 0, False, xs, O)
+        # Own pointwise kernels (one launch over all inputs, the backward on the same files): csrc/conv1x1_bf16.inc inside the bf16
+        # precision scope, csrc/conv1x1_f32.inc (exact fp32, round 6) otherwise.  The gate covers the BACKWARD's launches too (the
+        # input gradient runs the same kernel transposed with grad_output as its input: O % 16, O HW < 2^29; the weight gradient:
+        # B max(O, C) HW < 2^29), so a layer that passes here never meets DCD_ERR_BAD_ARG inside backward.
+        HW = H * W
+        shapes_ok = (len(xs) <= 4 and HW % 4 == 0 and all(x.shape[1] % 16 == 0 for x in xs) and O % 16 == 0
+                     and weight.dtype == torch.float32 and w2.is_contiguous() and O * HW < (1 << 29)
+                     and all(B * max(O, x.shape[1]) * HW < (1 << 29) for x in xs))
+        bf16 = _conv_prec(xs[0]) == PREC_BF16
+        ctx.pw = None
+        if shapes_ok and bf16 and _PW_BF16 and B * HW >= _PW_MIN_PIXELS:
+            ctx.pw = "bf16"
+        elif shapes_ok and not bf16 and _PW_F32 and B * HW >= _PW_F32_MIN_PIXELS and O * w2.shape[1] <= _PW_F32_MAX_WEIGHTS:
+            ctx.pw = "f32"
+        if ctx.pw:
+            out = _pw_conv(ctx.pw, w2, 0, False, xs, O)
             ctx.save_for_backward(w2, *xs)
             ctx.wshape = weight.shape
             return out
@@ -544,19 +556,21 @@ class _Conv1x1OfCat(torch.autograd.Function):
         w2, *xs = ctx.saved_tensors
         g = _f32c(g)
         B, O, H, W = g.shape
-        if ctx.bf16:
+        if ctx.pw:
             L = _lib.lib()
+            wrw_bytes, wrw = ((L.dcd_conv1x1_wrw_bf16_workspace_bytes, L.dcd_conv1x1_wrw_bf16) if ctx.pw == "bf16" else
+                              (L.dcd_conv1x1_wrw_f32_workspace_bytes, L.dcd_conv1x1_wrw_f32))
             gw = torch.empty_like(w2)
             Ct, HW = w2.shape[1], H * W
             gxs, c0 = [], 0
             for i, x in enumerate(xs):
                 Ci = x.shape[1]
-                gxs.append(_pw_conv_bf16(w2, c0, True, [g], Ci) if ctx.needs_input_grad[1 + i] else None)
+                gxs.append(_pw_conv(ctx.pw, w2, c0, True, [g], Ci) if ctx.needs_input_grad[1 + i] else None)
                 if ctx.needs_input_grad[0]:
-                    n = L.dcd_conv1x1_wrw_bf16_workspace_bytes(B, O, Ci, HW)
+                    n = wrw_bytes(B, O, Ci, HW)
                     ws = torch.empty(max(n, 16), dtype=torch.uint8, device=g.device)
-                    _lib.check(L.dcd_conv1x1_wrw_bf16(_lib.stream_of(g), g.data_ptr(), x.data_ptr(), gw.data_ptr() + 4 * c0, Ct, B, O, Ci, HW,
-                                                      ws.data_ptr(), n), "dcd_conv1x1_wrw_bf16")
+                    _lib.check(wrw(_lib.stream_of(g), g.data_ptr(), x.data_ptr(), gw.data_ptr() + 4 * c0, Ct, B, O, Ci, HW,
+                                   ws.data_ptr(), n), "dcd_conv1x1_wrw_" + ctx.pw)
                 c0 += Ci
             return ((gw.reshape(ctx.wshape) if ctx.needs_input_grad[0] else None),) + tuple(gxs)
         g3 = g.view(B, O, H * W)
@@ -577,11 +591,17 @@ class _Conv1x1OfCat(torch.autograd.Function):
 
 _PW_BF16 = os.environ.get("DCD_CONV1X1_BF16", "1") != "0"        # 0: the 1x1 convolutions stay fp32 library GEMMs under MODEL.FP16 (A/B)
 _PW_MIN_PIXELS = int(os.environ.get("DCD_CONV1X1_BF16_MIN_PIXELS", "7680"))
+_PW_F32 = os.environ.get("DCD_CONV1X1_F32", "1") != "0"          # 0: exact fp32 keeps the batched library GEMMs (A/B, round 5's path)
+_PW_F32_MIN_PIXELS = int(os.environ.get("DCD_CONV1X1_F32_MIN_PIXELS", "7680"))
+# In fp32 the pointwise kernels win where the layer is bound by bytes or by skinny GEMM shapes (<= 128 outputs, the projections);
+# the 256-output Roots on the 24x80 maps are matrix-bound and the launch's 128 workgroups half-fill the chip: library GEMMs there
+# (91 against 57 us forward, profiles/r06_conv1x1_f32.txt).  The bound is on outputs x concatenated inputs.
+_PW_F32_MAX_WEIGHTS = int(os.environ.get("DCD_CONV1X1_F32_MAX_WEIGHTS", "65536"))
 
 
-def _pw_conv_bf16(w2, col0, transposed, xs, M):
-    """out (B, M, H, W) = A . cat(xs) on csrc/conv1x1_bf16.inc: A = w2 (M = rows), or w2[:, col0:col0 + M]^T (`transposed`: the input
-    gradient of that column slice, xs = [grad_output])."""
+def _pw_conv(kind, w2, col0, transposed, xs, M):
+    """out (B, M, H, W) = A . cat(xs) on csrc/conv1x1_bf16.inc (`kind` "bf16") or csrc/conv1x1_f32.inc ("f32"): A = w2 (M = rows), or
+    w2[:, col0:col0 + M]^T (`transposed`: the input gradient of that column slice, xs = [grad_output])."""
     import ctypes
     L = _lib.lib()
     B, _, H, W = xs[0].shape
@@ -589,9 +609,9 @@ def _pw_conv_bf16(w2, col0, transposed, xs, M):
     ptrs = (ctypes.c_void_p * n)(*[x.data_ptr() for x in xs])
     chs = (ctypes.c_int * n)(*[x.shape[1] for x in xs])
     out = torch.empty((B, M, H, W), dtype=torch.float32, device=xs[0].device)
-    st = L.dcd_conv1x1_bf16(_lib.stream_of(xs[0]), w2.data_ptr() + 4 * col0, w2.shape[1], 1 if transposed else 0, n, ptrs, chs,
-                            out.data_ptr(), B, M, H * W)
-    _lib.check(st, "dcd_conv1x1_bf16")
+    fn = L.dcd_conv1x1_bf16 if kind == "bf16" else L.dcd_conv1x1_f32
+    st = fn(_lib.stream_of(xs[0]), w2.data_ptr() + 4 * col0, w2.shape[1], 1 if transposed else 0, n, ptrs, chs, out.data_ptr(), B, M, H * W)
+    _lib.check(st, "dcd_conv1x1_" + kind)
     return out
 
 

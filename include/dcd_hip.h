@@ -558,6 +558,15 @@ size_t dcd_conv1x1_wrw_bf16_workspace_bytes(int B, int O, int C, long long HW);
 int dcd_conv1x1_wrw_bf16(void *stream, const float *grad_output, const float *input, float *grad_weight, int ldw, int B, int O, int C,
                          long long HW, void *workspace, size_t workspace_bytes);
 
+/* The same layers in EXACT fp32 (csrc/conv1x1_f32.inc, v_mfma_f32_32x32x2_f32; round 6): same arguments, same restrictions.  They
+ * replace, in the fp32 train step, the batched library GEMMs behind `torch.cat` + `nn.Conv2d(.., 1)` of the reference's Root
+ * (DGDE/model/backbone/dla_dcn.py:199-205): one launch over all concatenated inputs instead of one GEMM per input. */
+int dcd_conv1x1_f32(void *stream, const float *weight, int ldw, int transposed, int n_inputs, const float *const *inputs,
+                    const int *channels, float *output, int B, int M, long long HW);
+size_t dcd_conv1x1_wrw_f32_workspace_bytes(int B, int O, int C, long long HW);
+int dcd_conv1x1_wrw_f32(void *stream, const float *grad_output, const float *input, float *grad_weight, int ldw, int B, int O, int C,
+                        long long HW, void *workspace, size_t workspace_bytes);
+
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).

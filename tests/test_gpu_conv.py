@@ -617,6 +617,82 @@ def test_conv1x1_of_cat_in_the_bf16_scope(cuda, monkeypatch, B, cs, O, H, W):
     _close(y32.cpu(), exact, "1x1 fp32 forward", 2e-5)
 
 
+@pytest.mark.parametrize("B,cs,O,H,W", [(2, (64, 64), 64, 24, 80), (1, (128, 128, 64, 128), 128, 12, 40), (2, (64,), 128, 16, 20),
+                                        (1, (512, 512, 256), 512, 12, 40), (3, (16, 32), 48, 6, 10), (2, (32,), 64, 96, 320),
+                                        (8, (64, 64), 64, 96, 320)])
+def test_conv1x1_of_cat_on_the_fp32_pointwise_kernels(cuda, monkeypatch, B, cs, O, H, W):
+    """ops.conv1x1_of_cat in exact fp32 on csrc/conv1x1_f32.inc (round 6: forward, input gradients and weight gradient as own
+    kernels instead of batched library GEMMs) against conv2d(cat(...)) in fp64 at 2e-5 of the output scale (the bar of the other
+    fp32 convolution kernels): several inputs, a pixel count that is not a multiple of the 512-pixel workgroup tile or of the
+    64-pixel weight-gradient strip, 48 outputs (a partial block of 64), an input that needs no gradient; the library path
+    (DCD_CONV1X1_F32=0) gives the same numbers."""
+    from dcd_amd import _lib, ops
+    monkeypatch.setattr(ops, "_PW_F32_MIN_PIXELS", 0)          # the small launches too (the dispatch keeps them on the library)
+    monkeypatch.setattr(ops, "_PW_F32_MAX_WEIGHTS", 1 << 30)   # ... and the wide ones
+    g = torch.Generator().manual_seed(sum(cs) + O + 1)
+    xs = [torch.randn(B, c, H, W, generator=g) for c in cs]
+    C = sum(cs)
+    w = torch.randn(O, C, 1, 1, generator=g) / C ** 0.5
+    gy = torch.randn(B, O, H, W, generator=g)
+    xcat = torch.cat(xs, 1).double()
+    ref = F.conv2d(xcat, w.double())
+    ref_gx = torch.nn.grad.conv2d_input(xcat.shape, w.double(), gy.double())
+    ref_gw = torch.nn.grad.conv2d_weight(xcat, w.shape, gy.double())
+    last = len(cs) - 1
+    seen = []
+    L = _lib.lib()
+    for name in ("dcd_conv1x1_f32", "dcd_conv1x1_wrw_f32"):
+        fn = getattr(L, name)
+        def spy(*a, _fn=fn, _name=name):
+            seen.append(_name)
+            return _fn(*a)
+        monkeypatch.setattr(L, name, spy, raising=False)
+    xd = [x.to(cuda).requires_grad_(i != last or last == 0) for i, x in enumerate(xs)]
+    wd = w.to(cuda).requires_grad_(True)
+    y = ops.conv1x1_of_cat(xd, wd)
+    y.backward(gy.to(cuda))
+    assert "dcd_conv1x1_f32" in seen and "dcd_conv1x1_wrw_f32" in seen      # the own kernels ran, not the library
+    _close(y.detach().cpu(), ref, "1x1 fp32 forward", 2e-5)
+    c0 = 0
+    for i, (x, c) in enumerate(zip(xd, cs)):
+        if x.requires_grad:
+            _close(x.grad.cpu(), ref_gx[:, c0:c0 + c], "1x1 fp32 grad_input %d" % i, 2e-5)
+        else:
+            assert x.grad is None
+        c0 += c
+    _close(wd.grad.cpu(), ref_gw, "1x1 fp32 grad_weight", 2e-5)
+    monkeypatch.setattr(ops, "_PW_F32", False)
+    y_lib = ops.conv1x1_of_cat([x.detach() for x in xd], wd.detach())
+    _close(y_lib.cpu(), ref, "1x1 library forward", 2e-5)
+
+
+def test_conv1x1_fp32_argument_checks(cuda):
+    """dcd_conv1x1_f32 / dcd_conv1x1_wrw_f32 refuse what they cannot run: H W % 4, channel counts that are not multiples of 16, a
+    null pointer, more than four inputs, a workspace that is too small."""
+    import ctypes
+    from dcd_amd import _lib
+    L = _lib.lib()
+    x = torch.randn(1, 16, 4, 8, device=cuda)
+    w = torch.randn(16, 16, device=cuda)
+    o = torch.empty(1, 16, 4, 8, device=cuda)
+    st = _lib.stream_of(x)
+    one = lambda ch, n=1: ((ctypes.c_void_p * n)(*[x.data_ptr()] * n), (ctypes.c_int * n)(*[ch] * n))
+    p, c = one(16)
+    assert L.dcd_conv1x1_f32(st, w.data_ptr(), 16, 0, 1, p, c, o.data_ptr(), 1, 16, 32) == 0
+    assert L.dcd_conv1x1_f32(st, w.data_ptr(), 16, 0, 1, p, c, o.data_ptr(), 1, 16, 30) == 1
+    p8, c8 = one(8)
+    assert L.dcd_conv1x1_f32(st, w.data_ptr(), 16, 0, 1, p8, c8, o.data_ptr(), 1, 16, 32) == 1
+    assert L.dcd_conv1x1_f32(st, None, 16, 0, 1, p, c, o.data_ptr(), 1, 16, 32) == 1
+    p5, c5 = one(16, 5)
+    assert L.dcd_conv1x1_f32(st, w.data_ptr(), 16, 0, 5, p5, c5, o.data_ptr(), 1, 16, 32) == 1
+    n = L.dcd_conv1x1_wrw_f32_workspace_bytes(1, 16, 16, 32)
+    ws = torch.empty(n, dtype=torch.uint8, device=cuda)
+    gw = torch.empty(16, 16, device=cuda)
+    assert L.dcd_conv1x1_wrw_f32(st, o.data_ptr(), x.data_ptr(), gw.data_ptr(), 16, 1, 16, 16, 32, ws.data_ptr(), n) == 0
+    assert L.dcd_conv1x1_wrw_f32(st, o.data_ptr(), x.data_ptr(), gw.data_ptr(), 16, 1, 16, 16, 32, ws.data_ptr(), n - 1) == 2
+    assert L.dcd_conv1x1_wrw_f32(st, o.data_ptr(), x.data_ptr(), gw.data_ptr(), 8, 1, 16, 16, 32, ws.data_ptr(), n) == 1
+
+
 @pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80)])
 def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     """ops.conv3x3_stride2: the stride-2 / pad-1 3x3 convolution of the DLA levels as a stride-1 convolution of the pixel-unshuffled

@@ -135,7 +135,8 @@ def test_affine_relu_and_patch_linear_nodes_equal_the_plain_tensor_operations():
     import torch
     from dcd_amd.model.head import trunk_moments as TM
     torch.manual_seed(0)
-    for T, B, M, O in ((3, 2, 40, 8), (1, 2, 832, 4), (2, 3, 7, 5)):
+    # 67, 2 * 67 and 16 * 67: sizes whose only divisor up to 64 is 1 or 2 -- the first form of _sum_rows never returned for them
+    for T, B, M, O in ((3, 2, 40, 8), (1, 2, 832, 4), (2, 3, 7, 5), (1, 1, 67, 2), (2, 2, 134, 3), (1, 2, 1072, 2)):
         y = torch.randn(T, B, M, O, dtype=torch.float64, requires_grad=True)
         sc = torch.randn(T, O, dtype=torch.float64, requires_grad=True)
         sh = torch.randn(T, O, dtype=torch.float64, requires_grad=True)
