@@ -134,7 +134,7 @@ class OffsetStats:
         return {"mean_abs_px": round(float(t[:, 0].sum() / t[:, 3].sum()), 4), "max_abs_px": round(float(t[:, 1].max()), 3),
                 "far_fraction": float(t[:, 2].sum() / t[:, 4].sum()), "far_threshold_px": 3.0, "calls": len(self.rows),
                 "source": "offset tensors of the 16 DCN calls of one eager forward of the benchmarked model and batch "
-                          "(conv_offset_mask ~ N(0, 0.01^2), SURVEY 8d)"}
+                          "(conv_offset_mask ~ N(0, std^2), SURVEY 8d)"}
 
 
 def op_level_dcn(torch, ext, batch, sigma, prec, iters=3):
@@ -176,14 +176,15 @@ def op_level_lines(torch, ext, batch, prec):
     """`roofline_op_2px` (+ the same layers at 0.5 px, the ratio the review asks for)."""
     by, fl = dcn_algorithmic(batch)
     out = {}
-    for key, sigma in (("roofline_op_0p5px", 0.5), ("roofline_op_2px", 2.0)):
+    for key, sigma in (("roofline_op_0p5px", 0.5), ("roofline_op_1px", 1.0), ("roofline_op_2px", 2.0)):
         tf, tb = op_level_dcn(torch, ext, batch, sigma, prec)
         t = tf + tb
         out[key] = {"bound": "mfma", "kernel": "DCNv2 fwd+bwd, 16 layers through the C ABI, batch %d, offsets %g * randn px" % (batch, sigma),
                     "fwd_ms": round(tf, 3), "bwd_ms": round(tb, 3), "ms": round(t, 3), "achieved": fl / 1e9 / t, "peak": MFMA_PEAK_TFLOPS[prec],
                     "unit": "TFLOP/s", "frac": fl / 1e9 / t / MFMA_PEAK_TFLOPS[prec], "hbm_frac": by / 1e6 / t / HBM_PEAK_GBS,
                     "offset_sigma_px": sigma}
-    out["roofline_op_2px"]["ratio_to_0p5px"] = round(out["roofline_op_2px"]["ms"] / out["roofline_op_0p5px"]["ms"], 3)
+    for key in ("roofline_op_1px", "roofline_op_2px"):
+        out[key]["ratio_to_0p5px"] = round(out[key]["ms"] / out["roofline_op_0p5px"]["ms"], 3)
     return out
 
 
@@ -201,7 +202,7 @@ def build_everything(args, device, world, local_rank):
                         "MODEL.FP16", bool(args.amp)])
     torch.manual_seed(0)
     model = KeypointDetector(cfg)
-    init_like_trained(model, std=0.01, seed=0)
+    init_like_trained(model, std=getattr(args, "offset_std", 0.01), seed=0)
     model = model.to(device).train()
     optimizer = build_optimizer(model, cfg)
     per_rank = args.batch if args.scaling == "weak" else max(args.batch // world, 1)
@@ -257,7 +258,7 @@ def run_gpu(args):
     step_launch = "eager"
     if use_graph:
         from dcd_amd.engine.trainer import GraphedTrainStep, wrap_distributed
-        graphed = GraphedTrainStep(model, optimizer, clip, distributed=data_parallel)
+        graphed = GraphedTrainStep(model, optimizer, clip, distributed=data_parallel, recapture_every=args.recapture_every)
         # capture WITHOUT replaying, then one eager all-reduce of the outcome, then -- only if every rank captured -- replays.
         # (A rank that replayed before the vote would sit in the graph's SyncBN all-reduces while a failed peer issues the
         # 1-element flag all-reduce: mismatched collectives, a hang.  The capture itself issues none: its warm-up steps are
@@ -271,8 +272,12 @@ def run_gpu(args):
         if ok:
             step_launch = "one HIP graph per step" + (" (SyncBN + gradient all-reduce inside)" if data_parallel else "")
 
-            def step():
-                graphed.replay(images, targets)
+            if args.recapture_every:
+                def step():
+                    graphed(images, targets)                 # __call__: re-captures every N replays (all ranks count the same calls)
+            else:
+                def step():
+                    graphed.replay(images, targets)
         else:
             use_graph = False
             if data_parallel:
@@ -364,6 +369,12 @@ def run_gpu(args):
                                   else (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec]) if dcn_ms > 0 else None,
                          "mfma_frac": (fl / 1e12 / (dcn_ms / 1e3)) / MFMA_PEAK_TFLOPS[prec] if dcn_ms > 0 else None,
                          "traffic": traffic, "mfma_busy_pmc": mfma_busy, "pmc_source": pmc_source, "pmc_commit": pmc_commit,
+                         # the ATTAINABLE bound beside the spec bound, from the same counter passes: per DCN kernel
+                         # floor = matrix-pipe busy time + (vector instructions x 2.44 cycles at full occupancy) -- the f32-input MFMA
+                         # shares the vector lanes, so the two ADD -- never below HBM bytes / 8 TB/s; composite_frac = sum of the floors
+                         # over the sum of the kernels' times under the counters (tools/pmc_kernels.py)
+                         "composite_frac": PMC_EXTRA.get("composite_frac"), "floor_ms": PMC_EXTRA.get("floor_ms"),
+                         "kernel_ms_under_counters": PMC_EXTRA.get("kernel_ms"),
                          # what the counters say bounds these kernels (the algorithmic bound is "mfma": 196 FLOP/B): on gfx950 the
                          # f32-input MFMA executes on the vector ALUs' FP32 lanes -- one MFMA and one VALU instruction never
                          # overlap (tools/micro/mfma_valu_overlap.hip, profiles/r03_mfma_valu_overlap.txt) -- so the measured bound
@@ -410,6 +421,40 @@ def run_gpu(args):
                         "dcn_frac_of_own_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS[pname] if s_dcn > 0 else None,
                         "dcn_hbm_frac": (by / 1e9 / (s_dcn / 1e3)) / HBM_PEAK_GBS if s_dcn > 0 else None,
                         "note": "same model, data and step as `value`; the DCN and 3x3-convolution weight contractions change precision"}
+    # The same train step at LARGE sampling offsets.  The headline's offsets are sub-pixel by construction
+    # (conv_offset_mask ~ N(0, 0.01^2): `roofline.offsets`), the regime the one-pass DCN backward is built for; the reference's own
+    # op test samples at 2 * randn px (DGDE/model/backbone/DCNv2/DCN/testcuda.py:73).  A second model, same architecture, batch and
+    # seed with conv_offset_mask ~ N(0, std^2), std chosen so that mean |offset| is ~1.6 px (= E|2 randn|): what the step costs when
+    # the offsets have grown.  One GPU, eager step, fp32.
+    if (out is not None and world == 1 and not use_graph and not args.amp and args.precision == "f32" and not args.no_split_line
+            and args.offset_std_2px > 0):
+        import argparse as _ap
+        a2 = _ap.Namespace(**vars(args))
+        a2.offset_std = args.offset_std_2px
+        _, model2, opt2, images2, targets2 = build_everything(a2, device, world, local_rank)[:5]
+        for _ in range(max(args.warmup, 3)):
+            train_step(model2, opt2, images2, targets2, clip)
+        torch.cuda.synchronize()
+        timer3 = DcnTimer(torch, _ext)
+        timer3.enabled = True
+        s_steps = args.steps
+        t0 = time.perf_counter()
+        for _ in range(s_steps):
+            train_step(model2, opt2, images2, targets2, clip)
+        torch.cuda.synchronize()
+        s_el = time.perf_counter() - t0
+        timer3.enabled = False
+        with OffsetStats(torch, _ext) as st2, torch.no_grad():
+            model2(images2, targets2)
+        s_dcn = timer3.total_ms() / s_steps
+        out["step_2px"] = {"value": global_batch * s_steps / s_el, "unit": "images/s", "ms_per_step": 1e3 * s_el / s_steps,
+                           "ratio_to_headline": (global_batch * s_steps / s_el) / out["value"], "steps": s_steps,
+                           "offset_weight_std": args.offset_std_2px, "offsets": st2.summary(), "dcn_ms_per_step": s_dcn,
+                           "dcn_frac_of_fp32_mfma_peak": (fl / 1e12 / (s_dcn / 1e3)) / MFMA_PEAK_TFLOPS["f32"] if s_dcn > 0 else None,
+                           "layers": timer3.per_layer(s_steps, per_rank),
+                           "note": "same train step, model, batch and seed as `value` with conv_offset_mask ~ N(0, std^2) instead of "
+                                   "N(0, 0.01^2): sampling offsets of the size the reference's op test uses"}
+        del model2, opt2
     # N > 1, north_star's split as the headline: the weak-scaling number of the same job (8 images per rank, eager DDP step with
     # bucketed all-reduce overlapped with the backward) as an extra key -- what BASELINE.json configs[2] is at N = 4
     test_weak = force_ddp and os.environ.get("DCD_TEST_WEAK") == "1"        # one-GPU rehearsal of this branch (twice the batch)
@@ -447,6 +492,9 @@ def run_gpu(args):
     return out
 
 
+PMC_EXTRA = {}          # load_pmc: the counter file's attainable-bound figures (tools/pmc_kernels.py: composite_frac, floor_ms)
+
+
 def load_pmc(per_rank, prec="f32"):
     """Counter evidence for the DCN kernels, from separate `rocprofv3 --pmc` passes over THIS command (tools/pmc_kernels.py ->
     profiles/dcn_pmc_r05.json, falling back to the earlier rounds' files): HBM bytes per step (FETCH_SIZE / WRITE_SIZE, corrected as
@@ -468,7 +516,7 @@ def load_pmc(per_rank, prec="f32"):
             return None, None, "absent for this precision", None
     if prec != "f32":
         return None, None, "absent for this precision", None
-    for name in ("dcn_pmc_r05.json", "dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
+    for name in ("dcn_pmc_r06.json", "dcn_pmc_r05.json", "dcn_pmc_r04.json", "dcn_pmc_r03.json", "dcn_pmc_r02.json"):
         path = os.path.join(ROOT, "profiles", name)
         try:
             with open(path) as f:
@@ -476,6 +524,9 @@ def load_pmc(per_rank, prec="f32"):
             if "--batch" in d.get("command", "") or per_rank != 8:      # the committed passes are the default bs-8 single-GPU step
                 return None, None, "absent for this batch", None
             s_ = d["summary"]
+            PMC_EXTRA["composite_frac"] = s_.get("composite_frac_time_weighted")
+            PMC_EXTRA["floor_ms"] = s_.get("floor_ms_per_step")
+            PMC_EXTRA["kernel_ms"] = s_.get("kernel_ms_per_step")
             return int(s_["hbm_bytes_per_step"]), float(s_["mfma_busy_time_weighted"]), "profiles/" + name, d.get("commit", "unknown")
         except (OSError, ValueError, KeyError):
             continue
@@ -911,6 +962,12 @@ def main():
                                                         "contractions on the bf16 matrix cores, fp32 accumulate and storage) "
                                                         "(BASELINE config 3: --gpus 4 --batch 32 --amp)")
     ap.add_argument("--dcn-steps", type=int, default=5, help="eager steps used to time the DCN calls when the timed steps are graph replays")
+    ap.add_argument("--offset-std", type=float, default=0.01, help="std of the conv_offset_mask initialisation (SURVEY 8d: 0.01)")
+    ap.add_argument("--offset-std-2px", type=float, default=0.033,
+                    help="std of the extra `step_2px` model (mean |offset| ~1.6 px = E|2 randn|); 0 skips that leg")
+    ap.add_argument("--recapture-every", type=int, default=0,
+                    help="graphed step: capture the whole-step graph again every N replays (a captured graph freezes the DCN launch "
+                         "policy of its capture; long runs refresh it)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-batch", type=int, default=2, help="batch of the CPU baseline step (BASELINE.md section 3: bs 2)")
     ap.add_argument("--cpu-budget", type=float, default=40.0, help="seconds of TIMED CPU steps after the warm-up step (1..3 steps)")

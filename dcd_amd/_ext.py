@@ -10,14 +10,19 @@ import torch
 
 from . import _lib
 
+import threading
+
 PRECISION = {"f32": 0, "bf16x3": 1, "bf16": 2}
-_default_precision = "f32"
+_default_precision = "f32"             # process default (set_precision)
+_scoped = threading.local()            # the innermost precision_scope of THIS thread, if any: a forward running on another thread
+                                       # inside someone else's scope keeps its own precision
 
 
 def set_precision(name):
     """Select the MFMA path used for the weight contractions of the DCNv2 op and of the 3x3 convolutions:
     "f32" exact, "bf16x3" split-bf16 (~2^-16 per product), "bf16" mixed precision -- operands rounded to bf16, one
-    product on the bf16 matrix cores, fp32 accumulate (MODEL.FP16, DGDE/model/detector.py:34-36)."""
+    product on the bf16 matrix cores, fp32 accumulate (MODEL.FP16, DGDE/model/detector.py:34-36).  The process default; a
+    `precision_scope` of the calling thread takes precedence while it is open."""
     global _default_precision
     if name not in PRECISION:
         raise ValueError("precision must be one of %s" % sorted(PRECISION))
@@ -25,13 +30,13 @@ def set_precision(name):
 
 
 def get_precision():
-    return _default_precision
+    return getattr(_scoped, "name", None) or _default_precision
 
 
 class precision_scope:
-    """`with precision_scope("bf16"):` -- the contraction precision of every op whose FORWARD runs inside the block (autograd
-    nodes remember it for their backward).  What MODEL.FP16 wraps around the backbone and the predictor where the reference has
-    `torch.cuda.amp.autocast()` (DGDE/model/detector.py:34-36, head/detector_head.py:20-22)."""
+    """`with precision_scope("bf16"):` -- the contraction precision of every op whose FORWARD runs inside the block on this thread
+    (autograd nodes remember it for their backward).  What MODEL.FP16 wraps around the backbone and the predictor where the
+    reference has `torch.cuda.amp.autocast()` (DGDE/model/detector.py:34-36, head/detector_head.py:20-22)."""
 
     def __init__(self, name):
         if name is not None and name not in PRECISION:
@@ -39,16 +44,26 @@ class precision_scope:
         self.name = name
 
     def __enter__(self):
-        global _default_precision
-        self.saved = _default_precision
+        self.saved = getattr(_scoped, "name", None)
         if self.name is not None:
-            _default_precision = self.name
+            _scoped.name = self.name
         return self
 
     def __exit__(self, *exc):
-        global _default_precision
-        _default_precision = self.saved
+        _scoped.name = self.saved
         return False
+
+
+HANDOVER = {"never": 0, "always": 1, "auto": 2, None: -1}
+
+
+def set_handover(mode):
+    """Pin the DCNv2 backward's far-sample launch policy for this process ("never" / "always" / "auto"; None: back to the
+    DCD_DCN_HANDOVER environment default) -- include/dcd_hip.h "Per-layer launch policy".  Tests that compare two launch sequences
+    of the same step (a captured graph against an eager twin) pin it so that both take the same kernels."""
+    if mode not in HANDOVER:
+        raise ValueError("handover mode must be one of 'never', 'always', 'auto', None")
+    _lib.check(_lib.lib().dcd_dcn_v2_set_handover(HANDOVER[mode]), "dcd_dcn_v2_set_handover")
 
 
 def _check(input, weight, bias, offset, mask, kernel_h, kernel_w):
@@ -96,7 +111,7 @@ def dcn_v2_forward(input, weight, bias, offset, mask, kernel_h, kernel_w, stride
             deformable_group)
     ws, nbytes = _workspace(L, input, geom)
     output = torch.empty((B, Co, Ho, Wo), dtype=torch.float32, device=input.device)
-    prec = PRECISION[precision or _default_precision]
+    prec = PRECISION[precision or get_precision()]
     st = L.dcd_dcn_v2_forward(_lib.stream_of(input), input.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                               offset.data_ptr(), mask.data_ptr(), output.data_ptr(), *geom, prec,
                               ws.data_ptr(), nbytes)
@@ -129,7 +144,7 @@ def dcn_v2_backward(input, weight, bias, offset, mask, grad_output, kernel_h, ke
     grad_mask = torch.empty_like(mask)
     grad_weight = torch.empty_like(weight)
     grad_bias = torch.empty_like(bias)
-    prec = PRECISION[precision or _default_precision]
+    prec = PRECISION[precision or get_precision()]
     st = L.dcd_dcn_v2_backward(_lib.stream_of(input), input.data_ptr(), weight.data_ptr(), bias.data_ptr(),
                                offset.data_ptr(), mask.data_ptr(), grad_output.data_ptr(),
                                grad_input.data_ptr(), grad_offset.data_ptr(), grad_mask.data_ptr(),

@@ -48,6 +48,7 @@ SIGNATURES = {
     "dcd_dcn_v2_forget": (c_int, [c_void_p]),
     "dcd_dcn_v2_policy_state": (c_int, [c_void_p, c_void_p]),
     "dcd_dcn_v2_policy_free": (c_int, []),
+    "dcd_dcn_v2_set_handover": (c_int, [c_int]),
     "dcd_edge_depth_forward": (c_int, [c_void_p] * 6 + [c_int, c_int, c_int, c_float, c_float, c_int, c_int]
                                + [c_void_p] * 3),
     "dcd_edge_depth_backward": (c_int, [c_void_p] * 7 + [c_int, c_int, c_int, c_float, c_float, c_int]

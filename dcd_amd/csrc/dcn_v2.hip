@@ -31,6 +31,7 @@
 #include <stdint.h>
 #include <stdlib.h>
 #include <string.h>
+#include <atomic>
 #include <map>
 #include <vector>
 #include <mutex>
@@ -843,8 +844,11 @@ static std::map<std::pair<int, const void *>, HandoverState> g_handover;
 static std::map<int, std::vector<HandoverState>> g_handover_free;     // per device: report words of forgotten layers
 constexpr unsigned HANDOVER_UNKNOWN = 0xffffffffu;
 
+static std::atomic<int> g_handover_pin{-1};                            // dcd_dcn_v2_set_handover: >= 0 overrides the environment default
 static int handover_mode()
 {
+    const int pin = g_handover_pin.load(std::memory_order_relaxed);
+    if (pin >= 0) return pin;
     static const int m = [] {
         const char *e = dcd_env("DCD_DCN_HANDOVER");
         if (e && !strcmp(e, "always")) return 1;
@@ -894,6 +898,32 @@ static int handover_decide(hipStream_t stream, const void *weight, unsigned real
     *report = h.dev;
     const unsigned far = *(volatile unsigned *)h.host;
     return (far == HANDOVER_UNKNOWN || (uint64_t)far * 2 > real_limit) ? 1 : 0;
+}
+
+// Round 6: a far-DOMINATED call of a layer the column-buffer path also takes (dense_ok: Cin >= 256, or Cin, Cout >= 128) goes to that
+// path instead of the one-pass kernel + device-side hand-over to the generic three-pass kernels: at 2 px offsets (a quarter of the
+// samples far) the column-buffer backward takes 0.75 / 1.49 / 0.70 ms on 256->128 @ 24x80 / 128->128 @ 48x160 / 256->64 @ 24x80
+// where the handed-over call took 1.26 / 2.00 / 0.78 (gpurun_out/route_probe.txt, tools/route_probe.sh).  Host-side like the
+// policy above, from the layer's previous report; the column-buffer call reports its far count too, so the layer returns to the
+// one-pass kernel when its offsets shrink.  -> true: take the column-buffer path and store the far count to *report.
+static bool handover_far_dominated(const void *weight, unsigned real_limit, unsigned **report)
+{
+    *report = nullptr;
+    if (handover_mode() != 2) return false;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    std::lock_guard<std::mutex> lock(g_handover_mu);
+    auto it = g_handover.find(std::make_pair(dev, weight));
+    if (it == g_handover.end() || !it->second.host) return false;
+    const unsigned far = *(volatile unsigned *)it->second.host;
+    if (far == HANDOVER_UNKNOWN || far <= real_limit) return false;
+    *report = it->second.dev;
+    return true;
+}
+
+__global__ void dcn_far_report(const unsigned *__restrict__ scal, unsigned *__restrict__ report)
+{
+    if (threadIdx.x == 0 && blockIdx.x == 0) *report = scal[3] & ~FAR_BY_COUNT;
 }
 
 // Forward side of the same policy.  The tiled forward kernel takes far samples itself (per lane, from global memory); the call-wide
@@ -2576,7 +2606,10 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
     // the train step to hand the call to the generic kernels (1.9 vs 0.8 ms), which the dense path does not care about
     const bool use_sweep = sweep_ok(g) && (g.Cop <= 64 || (sweep_wide && (g.Cop <= 128 || !dense_ok(g, true)))) && dense_mode() != 1 &&
                            (sweep_mode() == 1 || !dense_ok(g, true));
-    if (!use_sweep && dense_ok(g, true)) {
+    unsigned *dense_report = nullptr;
+    const bool far_to_dense = use_sweep && dense_ok(g, true) &&
+                              handover_far_dominated(weight, far_count_limit(g, g.Co > 64), &dense_report);
+    if ((!use_sweep || far_to_dense) && dense_ok(g, true)) {
         ZeroRanges z;
         for (int r = 0; r < 8; ++r) { z.p[r] = nullptr; z.n[r] = 0; }
         z.p[0] = absmax; z.n[0] = 4;
@@ -2590,6 +2623,7 @@ int dcd_dcn_v2_backward(void *stream_, const float *input, const float *weight, 
         if (gsz > 512) gsz = 512;
         hipLaunchKernelGGL(dcn_offset_absmax, dim3(gsz), dim3(256), 0, stream, offset, noff, absmax, g.HoWo, dg * 2 * g.KK,
                            (g.HoWo + 31) / 32, far_flag, far_list);
+        if (dense_report) hipLaunchKernelGGL(dcn_far_report, dim3(1), dim3(64), 0, stream, (const unsigned *)absmax, dense_report);
         hipLaunchKernelGGL(dcn_offset_blockmax, bm_grid, dim3(64), 0, stream, offset, g, blockmax);
         hipLaunchKernelGGL(dcn_build_inverse, dim3((H * W + 255) / 256, dg * g.KK, B), dim3(256), 0, stream, offset, mask, inv, g);
         int splits = (int)(((int64_t)g.HoWo + 4095) / 4096);
@@ -2999,6 +3033,13 @@ int dcd_dcn_v2_policy_state(const float *weight, unsigned *far_count)
     if (far == HANDOVER_UNKNOWN) return 1;
     if (far_count) *far_count = far;
     return 2;
+}
+
+int dcd_dcn_v2_set_handover(int mode)
+{
+    if (mode < -1 || mode > 2) return DCD_ERR_BAD_ARG;
+    g_handover_pin.store(mode, std::memory_order_relaxed);
+    return DCD_OK;
 }
 
 int dcd_dcn_v2_policy_free(void)

@@ -127,11 +127,15 @@ int dcd_dcn_v2_backward(void *stream, const float *input, const float *weight, c
  *   dcd_dcn_v2_policy_state(weight, &far)   0: no entry; 1: entry, no report yet; 2: *far = the last reported far count; -1: error.
  *   dcd_dcn_v2_policy_free()    frees all policy state of the process (all devices).  Only when no captured graph containing
  *                               DCN backward calls will be replayed again.
+ *   dcd_dcn_v2_set_handover(mode)   pins the policy for the process: 0 never hand over, 1 always armed, 2 auto (the default), -1 back
+ *                               to the DCD_DCN_HANDOVER environment default.  For callers that need two runs of one step to take the
+ *                               same launch sequence (a captured graph and its eager twin).
  * A CAPTURED call freezes its decision: a graph captured while a layer's offsets were small replays the "never hand over" sequence
  * (correct for any offsets, slower beyond the far-count limit) until it is captured again. */
 int dcd_dcn_v2_forget(const float *weight);
 int dcd_dcn_v2_policy_state(const float *weight, unsigned *far_count);
 int dcd_dcn_v2_policy_free(void);
+int dcd_dcn_v2_set_handover(int mode);
 
 /* ------------------------------------------------------------------------------------------------
  * Edge-constraint depth solver.

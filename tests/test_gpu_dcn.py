@@ -390,6 +390,55 @@ def test_one_pass_backward_keeps_far_heavy_calls_once_the_layer_is_known_as_near
             close(g_.cpu(), r_, 5e-5, "far-heavy call, hand-over armed again: %s %s" % (name, (B, C, Co, H, W)))
 
 
+def test_far_dominated_wide_layers_take_the_column_buffer_path(cuda, oracle_dcn):
+    """Round 6 (dcn_v2.hip, `handover_far_dominated`): a layer both the one-pass kernel and the column-buffer path take (Cin, Cout
+    >= 128) whose PREVIOUS call reported more far coordinates than its hand-over limit runs the column-buffer backward (no
+    `dcn_bwd_sweep` launch), reports again, and returns to the one-pass kernel once its offsets are small.  Same weight tensor
+    (the policy's key) through four calls, each against the oracle; the pinned modes never take that route."""
+    import ctypes
+    from dcd_amd import _ext, _lib
+    L = _lib.lib()
+    B, C, Co, H, W = 1, 128, 128, 12, 36
+    x, w, b, off, m, gy = make_case(B, C, Co, H, W, off_scale=0.3, seed=31)
+    g = torch.Generator().manual_seed(131)
+    off_far = torch.randn(off.shape, generator=g) * 2.5                   # ~23 % of the coordinates beyond 3 px
+    dev = [t.to(cuda) for t in (x, w, b, off, m, gy)]
+    a = (3, 3, 1, 1, 1, 1, 1, 1, 1)
+    names = ("grad_input", "grad_offset", "grad_mask", "grad_weight", "grad_bias")
+
+    def far_reported():
+        torch.cuda.synchronize()
+        far = ctypes.c_uint(0)
+        assert L.dcd_dcn_v2_policy_state(dev[1].data_ptr(), ctypes.byref(far)) == 2
+        return far.value
+
+    def run(o, what):
+        ref = oracle_dcn.dcn_v2_backward(x, w, b, o, m, gy, *a)
+        got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], o.to(cuda), dev[4], dev[5], *a)
+        for name, g_, r_ in zip(names, got, ref):
+            close(g_.cpu(), r_, 5e-5, "%s: %s" % (what, name))
+
+    limit = B * 18 * H * W // 8                                           # far_count_limit: wide outputs, fewer than four images
+    try:
+        L.dcd_dcn_v2_forget(dev[1].data_ptr())
+        run(off_far, "first call (unknown layer: one-pass kernel, hand-over armed)")
+        n_far = far_reported()
+        assert n_far > limit, (n_far, limit)
+        run(off_far, "second call (far-dominated: column buffer)")
+        assert far_reported() == n_far                                    # the column-buffer call reported the same count
+        run(off, "third call (still routed by the last report: column buffer, near offsets)")
+        assert far_reported() == 0
+        run(off, "fourth call (near again: one-pass kernel)")
+        assert far_reported() == 0
+        _ext.set_handover("never")                                        # pinned: the route is never taken, results unchanged
+        run(off_far, "pinned never")
+        _ext.set_handover("always")
+        run(off_far, "pinned always")
+    finally:
+        _ext.set_handover(None)
+        L.dcd_dcn_v2_forget(dev[1].data_ptr())
+
+
 WIDE_SWEEP_CASES = [
     # B, C, Co, H, W, off_scale: one-pass backward with Cout > 64 (round 4): dcol over 2 / 4 blocks of 64 outputs, the masked
     # samples through the col buffer, grad_weight as one product

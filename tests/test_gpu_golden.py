@@ -759,7 +759,9 @@ def test_graphed_training_gradients_track_an_eager_twin(cuda):
     """The whole-step HIP graph TRAINING (learning rate on) at bs 8, 384x1280: every five replays an eager twin takes the graphed
     model's weights and buffers and runs `trainer.train_step` with its learning rates at zero; the next replay's (clipped)
     gradients -- computed from the same weights -- must be the twin's.  split-bf16 products (forward and backward repeat to
-    5e-6 eagerly; fp32 does not: MIOpen's stride-2 solvers split K with atomics): bar 1e-2 of each gradient's range.
+    5e-6 eagerly; fp32 does not: MIOpen's stride-2 solvers split K with atomics), the DCN launch policy pinned to "never hand over"
+    (`_ext.set_handover`: the graph keeps the launch sequence of its capture, an unpinned twin re-decides per call -- two correct
+    sequences a seventh digit apart, which the loss's discrete pair selection can amplify): bar 2e-3 of each gradient's range.
 
     Round 5 found this the hard way: ATen reductions whose scratch semaphore is cleared by hipMemsetAsync (the broadcast backward
     of the head trunks' scale / shift, a flat bias-gradient sum) and MIOpen's memset + accumulate backward-data solver became
@@ -785,6 +787,7 @@ def test_graphed_training_gradients_track_an_eager_twin(cuda):
                 g["weight_decay"] = 0.0
         return r
     try:
+        _ext.set_handover("never")
         cfg, A, optA, images, targets = build(False)
         _, B, optB, _, _ = build(True)
         clip = cfg.SOLVER.GRAD_NORM_CLIP
@@ -812,16 +815,13 @@ def test_graphed_training_gradients_track_an_eager_twin(cuda):
                         continue
                     rel = float((p.grad - gb[n]).abs().max() / gb[n].abs().max())
                     worst_seen = max(worst_seen, rel)
-                    # 1e-2 (2e-3 until the end of round 5).  Typical worst value over the eight checks: 3e-5 (five runs: 2.7e-5 .. 3.6e-5).
-                    # About once in 15 runs a check at replay 35-40 shows 1e-3 .. 5e-3 in the heads: the graph keeps the DCN launch
-                    # sequence of its capture while the twin re-decides per call (far-dominated layers on the generic fp32 kernels);
-                    # every DCN layer is the same in both sequences to 2e-7 and within 1.4e-5 of the oracle, but the loss's discrete
-                    # pair selection turns that seventh-digit difference into another selection when two candidates are that close
-                    # (caught and replayed: tools/scratch/twin_catch.py).  The hazard this test exists for
-                    # gave 85x.
-                    assert rel <= 1e-2, "replay %d: gradient of %s differs from the eager twin's by %.2e of its range" % (it, n, rel)
+                    # Typical worst value over the eight checks: 3e-5 (five runs: 2.7e-5 .. 3.6e-5).  With the policy unpinned about one
+                    # run in 15 showed 1e-3 .. 5e-3 in the heads at replay 35-40 (graph and twin on different, equally correct DCN
+                    # launch sequences: tools/twin_catch.py, docs/HISTORY.md); the hazard this test exists for gave 85x.
+                    assert rel <= 2e-3, "replay %d: gradient of %s differs from the eager twin's by %.2e of its range" % (it, n, rel)
         assert worst_seen > 0.0
         if os.environ.get("DCD_TEST_PRINT_GRAD_DEV"):
             print("worst graph-vs-twin gradient difference %.3e of a tensor's range" % worst_seen)
     finally:
+        _ext.set_handover(None)
         _ext.set_precision("f32")
