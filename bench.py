@@ -198,8 +198,9 @@ def build_everything(args, device, world, local_rank):
 
     _ext.set_precision(args.precision)
     force_ddp = os.environ.get("DCD_FORCE_DDP", "0") == "1"
+    in_w, in_h = (int(v) for v in getattr(args, "input", "1280x384").split("x"))
     cfg = get_cfg(opts=["MODEL.PRETRAIN", False, "MODEL.DEVICE", str(device), "MODEL.USE_SYNC_BN", world > 1 or force_ddp,
-                        "MODEL.FP16", bool(args.amp)])
+                        "MODEL.FP16", bool(args.amp), "INPUT.WIDTH_TRAIN", in_w, "INPUT.HEIGHT_TRAIN", in_h])
     torch.manual_seed(0)
     model = KeypointDetector(cfg)
     init_like_trained(model, std=getattr(args, "offset_std", 0.01), seed=0)
@@ -219,7 +220,7 @@ def build_everything(args, device, world, local_rank):
     else:
         model = wrap_distributed(model, cfg, local_rank)
     rank = int(os.environ.get("RANK", 0))
-    images, targets = make_batch(per_rank, seed=100 + rank, n_objects=args.objects, device=device)
+    images, targets = make_batch(per_rank, seed=100 + rank, n_objects=args.objects, input_size=(in_w, in_h), device=device)
     return cfg, model, optimizer, images, targets, per_rank, use_graph, data_parallel
 
 
@@ -336,6 +337,7 @@ def run_gpu(args):
         elapsed = float(t.item())
 
     global_batch = per_rank * world
+    size_hw = "x".join(reversed(getattr(args, "input", "1280x384").split("x")))      # "384x1280" (H x W, as BASELINE.json writes it)
     # MODEL.FP16: a precision scope around backbone and predictor -- every DCN / 3x3 contraction as ONE product of bf16-rounded
     # operands (DCD_PREC_BF16), fp32 accumulate and storage
     prec = "bf16" if args.amp else args.precision
@@ -349,15 +351,15 @@ def run_gpu(args):
     out = None
     if rank == 0:
         out = {
-            "metric": "images/sec DGDE train step (bs=%d, 384x1280)" % global_batch, "value": global_batch * args.steps / elapsed,
+            "metric": "images/sec DGDE train step (bs=%d, %s)" % (global_batch, size_hw), "value": global_batch * args.steps / elapsed,
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}[prec], "data": "synthetic",
-            "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI 384x1280 + random kpts_ann "
+            "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI " + size_hw + " + random kpts_ann "
                                    "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
                                        global_batch, "bf16 matrix operands, fp32 accumulate / storage (MODEL.FP16)" if args.amp
                                        else "fp32", world, args.objects),
-                       "global_batch": global_batch, "per_gpu_batch": per_rank, "input": "384x1280",
+                       "global_batch": global_batch, "per_gpu_batch": per_rank, "input": size_hw,
                        "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": step_launch,
                        "sync_bn": bool(data_parallel)},
             # The fused op has 196 FLOP per algorithmic byte (ridge of the part: 157.3 TF / 8 TB/s = 19.7), so the matrix pipe
@@ -962,6 +964,8 @@ def main():
                                                         "contractions on the bf16 matrix cores, fp32 accumulate and storage) "
                                                         "(BASELINE config 3: --gpus 4 --batch 32 --amp)")
     ap.add_argument("--dcn-steps", type=int, default=5, help="eager steps used to time the DCN calls when the timed steps are graph replays")
+    ap.add_argument("--input", default="1280x384", help="WxH of the synthetic frames (the metric's size is 1280x384; other sizes are for "
+                                                        "checks such as tools/check_graph_memsets.sh -- their line is not the metric)")
     ap.add_argument("--offset-std", type=float, default=0.01, help="std of the conv_offset_mask initialisation (SURVEY 8d: 0.01)")
     ap.add_argument("--offset-std-2px", type=float, default=0.033,
                     help="std of the extra `step_2px` model (mean |offset| ~1.6 px = E|2 randn|); 0 skips that leg")

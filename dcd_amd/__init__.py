@@ -21,6 +21,6 @@ __version__ = "0.1.0"
 # reductions with memset-cleared semaphores returned wrong sums in some replays of the graphed train step).  Round 5 first tried to
 # switch the solver off through MIOPEN_DEBUG_* variables: the name it exported is not read by the MIOpen build inside PyTorch, and
 # the three names that build does read (..._3D_CONV_IMPLICIT_GEMM_HIP_BWD_XDLOPS, ..._HIP_GROUP_BWD_XDLOPS, ..._HIP_BWD_XDLOPS) did
-# not keep the solver out either (tools/scratch/miopen_env_probe.py; tools/check_graph_memsets.sh caught it at bs 8).  What does:
+# not keep the solver out either (tools/probes/miopen_env_probe.py; tools/check_graph_memsets.sh caught it at bs 8).  What does:
 # a process that builds a whole-step graph runs these layers on our own kernels (ops.stride2_on_own_kernels, called by
 # engine.trainer.GraphedTrainStep) -- no MIOpen convolution is left in the captured step.  No environment is touched here.

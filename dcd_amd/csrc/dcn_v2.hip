@@ -802,7 +802,7 @@ __device__ __forceinline__ bool far_dominated(const unsigned *far_scal, int tota
     return (int64_t)far_scal[1] * 2 > (int64_t)total_tiles;
 }
 
-// Far coordinates (of B * 18 * HoWo) up to which the one-pass backward keeps the call.  Measured (tools/scratch/far_div_sweep.py,
+// Far coordinates (of B * 18 * HoWo) up to which the one-pass backward keeps the call.  Measured (tools/probes/far_div_sweep.py,
 // profiles/r04_far_div_b8.txt / _b1.txt): the one-pass kernel's time grows linearly with the far samples (64 -> 64 @ 96x320 x 8:
 // 0.91 ms + 41 ms per unit of far fraction), the generic kernels cost 2.6 - 3.4 ms whatever the fraction, so they take over
 // above ~1 in 24 coordinates; the wide-output layers' generic path is relatively dearer (1 in 16), and with few images the

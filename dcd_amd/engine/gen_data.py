@@ -44,7 +44,7 @@ def infer_records_batch(output, visualize_preds, image_of, n_images, cat="Car", 
     packed device buffer, ONE device-to-host copy for the batch (BASELINE config 4: 16 images x 50 detections).
     The records' values are numpy VIEWS of that host buffer (kpts_2d (73, 2), kpts_3d (73, 3), box (4,), ...): turning 800 x 73 x 5
     floats into nested Python lists costs more host time than the GPU needs for the whole batch (94 of 180 ms per 16 images,
-    tools/scratch/gen_phases.py), and the only consumer, `dump_gen_data_infer`, converts while it writes.  as_lists=True gives the
+    tools/probes/gen_phases.py), and the only consumer, `dump_gen_data_infer`, converts while it writes.  as_lists=True gives the
     reference's lists right away (DGDE/engine/inference.py:66-81)."""
     per_image = [[] for _ in range(n_images)]
     n = output.shape[0]

@@ -373,8 +373,11 @@ class GraphedTrainStep:
         (every few thousand steps costs nothing measurable: a capture is ~3 eager steps); `recapture()` does it on demand.  The
         count is per call of this object, so data-parallel ranks re-capture in the same call."""
         self.model, self.optimizer, self.clip, self.warmup = model, optimizer, grad_norm_clip, warmup
+        self._s2d_prev = None
         if any(p.is_cuda for p in model.parameters()):
-            ops.stride2_on_own_kernels()                   # no MIOpen backward-data solver (memset + accumulate) in the captured step
+            # no MIOpen backward-data solver (memset + accumulate) in the captured step; handed back when a capture fails and no
+            # graph of this object is left (the eager fallback then runs the faster stock solver again)
+            self._s2d_prev = ops.stride2_on_own_kernels()
         self.distributed, self.group = distributed, group
         self.recapture_every, self._replays = recapture_every, 0
         self._graphs = {}
@@ -555,6 +558,8 @@ class GraphedTrainStep:
             self.capture_error = e
             self._graphs.pop(key, None)
             self.optimizer.zero_grad(set_to_none=True)  # the flat views must not stay behind as .grad for an eager / DDP step
+            if not self._graphs and self._s2d_prev is not None:
+                ops.restore_stride2_mode(self._s2d_prev)
             return False
 
     def agree(self, ok):
@@ -569,6 +574,8 @@ class GraphedTrainStep:
         agreed = bool(flag.item())
         if not agreed:
             self._graphs.clear()
+            if self._s2d_prev is not None:
+                ops.restore_stride2_mode(self._s2d_prev)
         return agreed
 
     def recapture(self):

@@ -327,7 +327,7 @@ class _TrunkScaleShift(torch.autograd.Function):
         # sum y^2 = sum_k WG[r][k] Wd[r][k] depends on Wd twice: through the product and directly
         dWd = torch.addcmul(dWG @ GS.t(), dsums[:, 1:2], WG[:, :K])
         # (K, K + 1); the transposed view as the first operand makes hipBLASLt pick a 159 us fp64 kernel at DGDE's 2816 x 576 where
-        # the same product from a contiguous copy takes 59 (+ 8 for the copy): tools/scratch/f64_gemm_variants.py
+        # the same product from a contiguous copy takes 59 (+ 8 for the copy): tools/probes/f64_gemm_variants.py
         dGS = (Wd.t().contiguous() @ dWG) if Wd.is_cuda else Wd.t() @ dWG
         return dWd.float().view(T, O, K), dGS[:, K], dGS[:, :K], dgamma.view(T, O), dbeta.view(T, O), None, None, None
 
@@ -355,7 +355,7 @@ class _AffineRelu(torch.autograd.Function):
     """relu(y * scale + shift) for y (T, B, M, O) and per-(trunk, channel) scale / shift (T, O), with the gradients of scale and
     shift summed by `_sum_rows`.  As plain tensor operations the broadcast's backward is a one-step reduction over B x M rows with
     a memset-cleared semaphore: in the whole-step HIP graph it returned wrong sums in some replays (the trunk's BatchNorm gradients
-    up to 85x too large; a graphed training run left the eager trajectory after ~40 steps -- round 5, tools/scratch/graph_twin2.py)."""
+    up to 85x too large; a graphed training run left the eager trajectory after ~40 steps -- round 5, tools/probes/graph_twin2.py)."""
 
     @staticmethod
     def forward(ctx, y, scale, shift):

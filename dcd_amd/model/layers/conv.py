@@ -41,6 +41,7 @@ class Conv2d(nn.Conv2d):
                 and (x.shape[0] * x.shape[2] * x.shape[3] >= 1 << 16
                      or ops.conv3x3_bias_supported(x, self.weight, self.stride, self.padding, self.dilation))):
             return ops.conv2d_bias(x, self.weight, self.bias, self.stride, self.padding, self.dilation)
+        ops.stock_conv_in_capture(self, x)                  # raises for a stride-2 3x3 layer inside a stream capture
         return super().forward(x)
 
 

@@ -490,7 +490,7 @@ class _HeadOutAndGather(torch.autograd.Function):
         # NOT go.sum((0, 2)): with one class that is a flat reduction of B*H*W values into one, which ATen runs as a multi-block
         # kernel with a memset-initialised accumulator -- inside a replayed HIP graph it returned a wrong sum from the second replay
         # on (the hazard of profiles/r02_graph_memset_hazard.txt; found in round 5 as a training run that left the eager
-        # trajectory after ~40 graphed steps: tools/scratch/graph_lr0.py).  The two-stage sums of csrc/norm.hip zero-fill with kernels.
+        # trajectory after ~40 graphed steps: tools/probes/graph_lr0.py).  The two-stage sums of csrc/norm.hip zero-fill with kernels.
         gb = channel_sums(_f32c(gout)) if ctx.has_bias else None
         return gx.view(B, C, H, W), gw, gb, None
 
@@ -1274,11 +1274,35 @@ def stride2_on_own_kernels():
     DCD_CONV_S2D=1 selects at start-up).  Called by `engine.trainer.GraphedTrainStep`: MIOpen's pick for these layers' input
     gradient at bs 8 can be a composable-kernel solver that zero-fills its output with hipMemsetAsync and accumulates -- a memset
     node in the captured step -- and no MIOPEN_DEBUG_* switch of the MIOpen build inside PyTorch
-    turned it off reliably (tools/scratch/miopen_env_probe.py); with the layers on our kernels the traced bs-8 graph has no
+    turned it off reliably (tools/probes/miopen_env_probe.py); with the layers on our kernels the traced bs-8 graph has no
     memset and no MIOpen convolution left.  Costs the graphed fp32 step 0.4-0.6 ms (the regrouped filter's 4x multiplies)."""
     global _S2D_MODE
+    prev = _S2D_MODE
     if _S2D_MODE == "auto":
         _S2D_MODE = "1"
+    return prev
+
+
+def restore_stride2_mode(prev):
+    """Undo `stride2_on_own_kernels` (its return value): a `GraphedTrainStep` whose capture failed hands the process back to the
+    eager step, which in exact fp32 is faster on the stock solver (2.72 against 3.75 ms per bs-8 step)."""
+    global _S2D_MODE
+    if prev in ("auto", "0", "1"):
+        _S2D_MODE = prev
+
+
+def stock_conv_in_capture(module, x):
+    """Called by `layers.conv.Conv2d` right before it falls through to the stock convolution.  Inside a stream capture a stride-2
+    3x3 layer must not get there: MIOpen's backward-data pick for these layers can be a solver that zero-fills its output with
+    hipMemsetAsync and accumulates -- a memset node in the captured step, which on this stack returned wrong gradients in some
+    replays.  `GraphedTrainStep` keeps them on our kernels (`stride2_on_own_kernels`), but only for the
+    shapes `conv3x3_stride2_supported` takes (H % 4, W % 8, >= 16 input channels, a half-resolution map of >= 12 x 40): anything
+    else raises here, the capture fails cleanly and the caller falls back to the eager step."""
+    if (x.is_cuda and module.kernel_size == (3, 3) and module.stride == (2, 2) and torch.is_grad_enabled()
+            and (x.requires_grad or module.weight.requires_grad) and torch.cuda.is_current_stream_capturing()):
+        raise RuntimeError("stride-2 3x3 convolution %s on input %s would run on the stock solver inside a stream capture "
+                           "(possible memset node: wrong gradients in replays); use the eager step for this input size"
+                           % (tuple(module.weight.shape), tuple(x.shape)))
 
 
 def _s2d_index(K, C, device):
@@ -1329,6 +1353,11 @@ def conv3x3_stride2_supported(x, weight):
         return False                                   # exact fp32 keeps the stock solver (2.72 against 3.75 ms per bs-8 step) unless
                                                        # a whole-step graph is in use (stride2_on_own_kernels)
     H, W = x.shape[2], x.shape[3]
+    if _S2D_MODE == "1":
+        # a process that captures whole-step graphs (or DCD_CONV_S2D=1): EVERY stride-2 layer with at least 16 input channels, at any
+        # size -- maps off the alignment rules are zero-padded (conv3x3_stride2), small ones are slow but never on the stock solver
+        # inside a capture (DLA levels 4 / 5 at 96x320, inputs whose deep maps are below 24x80)
+        return 4 * weight.shape[1] >= 64
     return H % 4 == 0 and W % 8 == 0 and 4 * weight.shape[1] >= 64 and (H // 2) * (W // 2) >= _CONV_MIN_MAP
 
 
@@ -1340,7 +1369,16 @@ def conv3x3_stride2(x, weight):
     cores with 16x the fp32 rate and the kernels are bound by their transform arithmetic, i.e. by the 4 Cin channels at a quarter
     of the pixels = the cost of a stride-1 layer at full resolution.  Filter regrouping and its gradient are one gather / one
     scatter-add of 36 Cout Cin values (autograd)."""
-    return conv3x3(torch.nn.functional.pixel_unshuffle(x, 2), _S2DFilter.apply(weight))
+    H, W = x.shape[2], x.shape[3]
+    ph, pw = (-H) % 4, (-W) % 8
+    if ph or pw:
+        # zero rows / columns below and to the right: the outputs that exist for the original size read nothing but the zeros the
+        # convolution's own padding would have supplied there; the extra outputs are cut off
+        x = torch.nn.functional.pad(x, (0, pw, 0, ph))
+    y = conv3x3(torch.nn.functional.pixel_unshuffle(x, 2), _S2DFilter.apply(weight))
+    if ph or pw:
+        y = y[:, :, :(H + 1) // 2, :(W + 1) // 2].contiguous()
+    return y
 
 
 def conv3x3_wrw_only_supported(x, weight):

@@ -693,7 +693,8 @@ def test_conv1x1_fp32_argument_checks(cuda):
     assert L.dcd_conv1x1_wrw_f32(st, o.data_ptr(), x.data_ptr(), gw.data_ptr(), 8, 1, 16, 16, 32, ws.data_ptr(), n) == 1
 
 
-@pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80)])
+@pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80),
+                                       (2, 256, 512, 6, 20), (1, 64, 128, 13, 38)])      # off H % 4 / W % 8: the zero-padded form
 def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     """ops.conv3x3_stride2: the stride-2 / pad-1 3x3 convolution of the DLA levels as a stride-1 convolution of the pixel-unshuffled
     input with the regrouped filter, on our Winograd kernels -- output and both gradients against conv2d in fp64: exact-fp32 form
@@ -704,7 +705,7 @@ def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     g = torch.Generator().manual_seed(C + K)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
-    gy = torch.randn(B, K, H // 2, W // 2, generator=g)
+    gy = torch.randn(B, K, (H + 1) // 2, (W + 1) // 2, generator=g)
     ref = F.conv2d(x.double(), w.double(), None, 2, 1)
     ref_gx = torch.nn.grad.conv2d_input(x.shape, w.double(), gy.double(), stride=2, padding=1)
     ref_gw = torch.nn.grad.conv2d_weight(x.double(), w.shape, gy.double(), stride=2, padding=1)
@@ -723,6 +724,23 @@ def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     monkeypatch.setattr(ops, "conv3x3_stride2", lambda a, b: (calls.append(1), real(a, b))[1])
     conv(xd)
     assert not calls, "exact fp32 keeps the stock solver for the stride-2 layers"
+    aligned = H % 4 == 0 and W % 8 == 0 and (H // 2) * (W // 2) >= ops._CONV_MIN_MAP
     with _ext.precision_scope("bf16"):
         out = conv(xd)
-    assert calls and (out - F.conv2d(xd, conv.weight, None, 2, 1)).abs().max().item() <= 1.5e-2 * out.abs().max().item()
+    assert bool(calls) == aligned                        # the bf16 scope takes the own kernels for the shapes that pay
+    assert (out - F.conv2d(xd, conv.weight, None, 2, 1)).abs().max().item() <= 1.5e-2 * out.abs().max().item()
+    # a process that captures whole-step graphs (ops.stride2_on_own_kernels, round 6): EVERY size in exact fp32 too, and a stride-2
+    # layer that still reached the stock solver inside a capture would raise instead of recording a possible memset node
+    del calls[:]
+    monkeypatch.setattr(ops, "_S2D_MODE", "1")
+    out = conv(xd)
+    assert calls and (out - F.conv2d(xd, conv.weight, None, 2, 1)).abs().max().item() <= 2e-5 * out.abs().max().item()
+    narrow = Conv2d(8, 16, 3, stride=2, padding=1, bias=False).to(cuda)      # fewer than 16 input channels: not taken
+    xs = torch.randn(1, 8, 16, 32, device=cuda)
+    narrow(xs)                                                                # eager: stock op, fine
+    stream = torch.cuda.Stream()
+    graph = torch.cuda.CUDAGraph()
+    stream.wait_stream(torch.cuda.current_stream())
+    with pytest.raises(RuntimeError, match="inside a stream capture"):
+        with torch.cuda.graph(graph, stream=stream):
+            narrow(xs)

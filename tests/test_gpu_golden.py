@@ -434,7 +434,7 @@ def test_graphed_train_step_equals_eager(cuda, data_parallel):
         return [None if t is None else float(t.double().norm()) for t in ts]
     # Two losses sit behind the edge solver's top-1500 selection (DGDE/model/anno_encoder.py:355-377: pairs with the largest |dv|):
     # a near-tie at the 1500th pair flips with the 1e-7 noise of the forward (fp32 atomics in BN-at-positions / scatter-adds) and
-    # moves them by a few 1e-4 -- seen between two runs of the SAME eager code (tools/scratch/dp_graph_check.py: corner_loss
+    # moves them by a few 1e-4 -- seen between two runs of the SAME eager code (tools/probes/dp_graph_check.py: corner_loss
     # 0.200333 in five runs, 0.200249 in the sixth; every other loss unchanged).  Those two get the wider bar.
     behind_topk = ("corner_loss", "extra_kpts_depth_loss")
     for i, ((l0, g0, b0, w0, m0), (l1, g1, b1, w1, m1)) in enumerate(zip(eager, graph)):

@@ -59,7 +59,7 @@ def test_moments_equal_patch_matrix_form(cuda, monkeypatch):
 def test_batch_variance_error_with_a_dc_component(cuda, monkeypatch, shift, bound):
     """w^T G w / n - mean^2 is a cancellation form and G is accumulated in fp32 pieces of ~2000 products (advisor, round 2): the
     relative error of the batch variance grows LINEARLY with the input's mean / std.  Measured at 8 x 64 x 96 x 320
-    (tools/scratch/trunk_dc_error.py): 9e-8 at 0.7 (what a ReLU output has), 1.3e-4 at 1.7, 3.8e-4 at 3.7, 1.1e-3 at 10, 3.7e-3 at 30.
+    (tools/probes/trunk_dc_error.py): 9e-8 at 0.7 (what a ReLU output has), 1.3e-4 at 1.7, 3.8e-4 at 3.7, 1.1e-3 at 10, 3.7e-3 at 30.
     This test pins that curve from above on a smaller map, against the dense convolution's statistics in float64."""
     from torch.nn import functional as F
     from dcd_amd.model.head import trunk_moments as TM

@@ -1,5 +1,5 @@
 # Memset nodes in the CAPTURED train step (on this stack they are not ordered reliably inside a replayed
-# HIP graph).  Kernel trace of the graphed step in seven configurations; every count below must be 0.
+# HIP graph).  Kernel trace of the graphed step in eight configurations; every count below must be 0.
 #   bash tools/check_graph_memsets.sh            (on the GPU box; writes gpurun_out/graph_memsets.txt)
 cd $GRAFT_REPO_ROOT
 out=gpurun_out/graph_memsets.txt
@@ -13,4 +13,6 @@ EXTRA="" run memchk_ddp DCD_FORCE_DDP=1
 EXTRA="--batch 1" run memchk_b1 X=1
 EXTRA="--batch 2" run memchk_b2 X=1
 EXTRA="--batch 4" run memchk_b4 X=1
+# a size whose deep maps are off the space-to-depth path's alignment rules (DLA level 5 at 6x20): zero-padded form
+EXTRA="--batch 2 --input 320x96 --no-op-line --no-split-line" run memchk_96x320 X=1
 cat $out

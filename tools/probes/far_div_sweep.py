@@ -1,6 +1,6 @@
 """DCN backward time per layer against the far-sample hand-over limit (DCD_FAR_DIV / DCD_FAR_DIV_WIDE: the one-pass kernel keeps a
 call while at most 1 in DIV offset coordinates is displaced by 3 px or more) over offset scales: where the generic kernels
-start to pay.  python tools/scratch/far_div_sweep.py [B]"""
+start to pay.  python tools/probes/far_div_sweep.py [B]"""
 import os, subprocess, sys
 R = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 code = """

@@ -1,6 +1,6 @@
 """Kernel-trace durations per shape: runs each shape's prepared forward 12 times with a marker kernel (a tiny fill of n elements,
 n = shape index + 1) between shapes; prints per shape the median duration of the convolution kernels.  Run under
-rocprofv3 --kernel-trace and parse the csv with tools/scratch/trace_conv_parse.py"""
+rocprofv3 --kernel-trace and parse the csv with tools/probes/trace_conv_parse.py"""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))))
 import torch
