@@ -355,10 +355,10 @@ def run_gpu(args):
             "unit": "images/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": 1000.0 * elapsed / args.steps, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": {"f32": "f32", "bf16x3": "bf16x3", "bf16": "bf16"}[prec], "data": "synthetic",
-            "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI " + size_hw + " + random kpts_ann "
+            "config": {"workload": "DGDE train bs=%d %s on %dxMI355X, synthetic KITTI %s + random kpts_ann "
                                    "(DGDE.yaml, DLA-34+DCNv2, %d objects/image)" % (
                                        global_batch, "bf16 matrix operands, fp32 accumulate / storage (MODEL.FP16)" if args.amp
-                                       else "fp32", world, args.objects),
+                                       else "fp32", world, size_hw, args.objects),
                        "global_batch": global_batch, "per_gpu_batch": per_rank, "input": size_hw,
                        "parallelism": "dp%d" % world, "dcn_precision": prec, "step_launch": step_launch,
                        "sync_bn": bool(data_parallel)},

@@ -85,7 +85,8 @@ def check_loss_computation(device, tol, through_row_kernel=False):
     assert rel(reg.grad.abs().sum((0, 2, 3)).cpu().numpy(), g["grad_reg_abs_per_channel"]) <= tol
 
 
-def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2, decode_min_match=0.8, sparse_tol=1e-4):
+def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_tol=2e-2, decode_min_match=0.8, sparse_tol=1e-4,
+                grads_out=None):
     """Whole KeypointDetector vs a fixture of the reference's run: `truth` = "model_96x320" (the reference in fp32 on the CPU)
     or "model_96x320_f64" (the reference in float64: the exact result up to ~1e-12).  tol: activations; loss_tol: the 13
     losses (default tol); gtol: per-parameter gradient norms, relative to the norm (floored at 1e-4 of the largest)."""
@@ -136,6 +137,8 @@ def check_model(device, tol, gtol, truth="model_96x320", loss_tol=None, decode_t
         dev_ = abs(got - ref) / max(ref, 1e-4 * max(norms.values()))
         if dev_ > worst:
             worst, worst_name = dev_, n
+    if grads_out is not None:                                  # name -> gradient, for comparisons between two runs of this check
+        grads_out.update({n: p.grad.detach().clone() for n, p in model.named_parameters() if p.grad is not None})
     if os.environ.get("DCD_TEST_PRINT_GRAD_DEV"):
         print("worst gradient-norm deviation %.3e at %s" % (worst, worst_name))
     assert worst <= gtol, "per-parameter gradient norms deviate by %.3e (%s)" % (worst, worst_name)
