@@ -15,7 +15,7 @@ pytestmark = pytest.mark.gpu
 
 # test_whole_model_in_mixed_bf16_precision: every large gradient tensor of the mixed-precision run against the fp32 run of the same
 # model (cosine, norm ratio); calibrated on MI355X, see the test
-MIXED_GRAD_COS, MIXED_GRAD_RATIO = 0.5, 1.6
+MIXED_GRAD_COS, MIXED_GRAD_RATIO = 0.45, 1.35      # measured over three runs: worst cosine 0.565-0.570, worst ratio 1.19-1.21
 
 
 def _one_image(preds, i):
@@ -160,27 +160,40 @@ def test_whole_model_in_mixed_bf16_precision(cuda):
     at least a third of the rows must match."""
     from dcd_amd import _ext
     torch.backends.cudnn.benchmark = False
-    g32, g16 = {}, {}
-    H.check_model(cuda, 1e-4, 6e-3, truth="model_96x320_f64", loss_tol=3e-4, grads_out=g32)          # the exact-fp32 run, for its gradients
     with _ext.precision_scope("bf16"):
-        H.check_model(cuda, 0.15, 0.9, truth="model_96x320_f64", loss_tol=0.08, decode_tol=0.1, decode_min_match=0.3, sparse_tol=0.1,
-                      grads_out=g16)
+        H.check_model(cuda, 0.15, 0.9, truth="model_96x320_f64", loss_tol=0.08, decode_tol=0.1, decode_min_match=0.3, sparse_tol=0.1)
     assert _ext.get_precision() == "f32"
-    # DIRECTION and SIZE of every large gradient against the fp32 run of the same model (ADVICE r5: the norm bar above would pass a
-    # sign or scale error in one of the bf16 backward kernels -- direct weight gradient, 1x1 weight gradient, one-product DCN
-    # sweep).  bf16 noise through ~90 layers leaves the weight gradients of the convolutions well aligned with the fp32 ones
-    # (measured: see the printed line with DCD_TEST_PRINT_GRAD_DEV); a flipped sign gives -1, a factor 2 a norm ratio of 2.
+    # DIRECTION and SIZE of every large gradient tensor against the exact-fp32 run of the same model (ADVICE r5: the norm bar above
+    # would pass a sign or scale error in one of the bf16 backward kernels -- direct weight gradient, 1x1 weight gradient,
+    # one-product DCN sweep).  Measured (tools/probes/amp_grad_by_loss.py): at this random initialisation the backbone gradient
+    # of EVERY loss taken alone has cosine 0.62-0.70 and norm ratio 0.95-1.10 against fp32 (BatchNorm's backward cancels most of
+    # each layer's incoming gradient, bf16's 2^-9 is relative to the uncancelled size); `keypoint_depth_loss` (depth = f h / the
+    # predicted keypoint height, a division by a random net's near-zero output) is the one chaotic term: ratio 0.48, cosine 0.39.
+    # So: gradient of the other twelve losses, per tensor.  A flipped sign gives about -0.65, a factor 2 a ratio of 2.
+    from dcd_amd.model.detector import KeypointDetector
+    model = KeypointDetector(H.small_cfg(str(cuda))).to(cuda).train()
+    images, targets = gi.model_inputs()
+    images, targets = images.to(cuda), [t.to(cuda) for t in targets]
+    keys = [k for k in H.LOSS_KEYS if k != "keypoint_depth_loss"]
+
+    def grads(prec):
+        gi.name_hashed_init(model)
+        model.zero_grad()
+        with _ext.precision_scope(prec):
+            ld, _ = model(images, targets)
+        sum(ld[k] for k in keys).backward()
+        return {n: p.grad.detach().double().flatten() for n, p in model.named_parameters() if p.grad is not None and p.numel() >= 4096}
+    g32, g16 = grads("f32"), grads("bf16")
+    top = max(float(v.norm()) for v in g32.values())
     worst_cos, worst_ratio, n_big = 1.0, 1.0, 0
     for n, a in g32.items():
-        b = g16.get(n)
-        if b is None or a.numel() < 4096 or float(a.norm()) < 1e-6 * max(float(v.norm()) for v in g32.values()):
+        if float(a.norm()) < 1e-6 * top:
             continue
+        b = g16[n]
         n_big += 1
-        cos = float(torch.dot(a.flatten().double(), b.flatten().double()) / (a.double().norm() * b.double().norm()))
-        ratio = float(b.double().norm() / a.double().norm())
-        worst_cos = min(worst_cos, cos)
-        worst_ratio = max(worst_ratio, ratio, 1.0 / ratio)
-        if os.environ.get("DCD_TEST_PRINT_GRAD_DEV") and (cos < 0.9 or max(ratio, 1 / ratio) > 1.2):
+        cos, ratio = float(torch.dot(a, b) / (a.norm() * b.norm())), float(b.norm() / a.norm())
+        worst_cos, worst_ratio = min(worst_cos, cos), max(worst_ratio, ratio, 1.0 / ratio)
+        if os.environ.get("DCD_TEST_PRINT_GRAD_DEV") and (cos < 0.6 or max(ratio, 1 / ratio) > 1.15):
             print("%-60s cos %.3f ratio %.3f" % (n, cos, ratio))
     if os.environ.get("DCD_TEST_PRINT_GRAD_DEV"):
         print("mixed vs fp32 gradients over %d large tensors: worst cosine %.3f, worst norm ratio %.3f" % (n_big, worst_cos, worst_ratio))
@@ -191,19 +204,22 @@ def test_whole_model_in_mixed_bf16_precision(cuda):
 def test_whole_model_in_split_bf16_precision(cuda, monkeypatch):
     """The same model with every split-bf16 kernel on (`_ext.set_precision("bf16x3")`: DCNv2 forward / backward incl. the dense
     path's GEMMs, and the Winograd 3x3 convolutions on every map size) against the float64 reference run, at north_star's bound:
-    1e-3 on activations and losses (measured ~2e-5 / 1e-4), 3e-2 on the per-parameter gradient norms (measured 2e-2, below)."""
+    1e-3 on activations and losses (measured ~2e-5 / 1e-4), 2.2e-2 on the per-parameter gradient norms (measured 1.94-1.98e-2)."""
     from dcd_amd import _ext, ops
     torch.backends.cudnn.benchmark = False
     monkeypatch.setattr(ops, "_CONV_SPLIT_MIN_MAP", 0)
+    # the stride-2 layers on our kernels too: MIOpen's implicit GEMMs for them split K with atomics, the one part of this run that
+    # did not repeat (VERDICT r5 item 7: a deterministic path instead of a wider bar)
+    monkeypatch.setattr(ops, "_S2D_MODE", "1")
     _ext.set_precision("bf16x3")
     try:
         # (decode: which of the nearly-equal scores of a random net make the top 50 moves with the 1e-5 of the split products AND
         # with the atomics of the edge-fusion scatter from run to run: 39-45 of 50 rows seen; the decode itself is pinned exactly
         # on fixed maps by check_post_processor)
-        # gradient norms: 3e-2.  The worst parameter is always the FIRST BatchNorm's weight (backbone.base.base_layer.1), where the
-        # rounding of every later layer has accumulated: 1.90e-2 .. 2.03e-2 over eight runs of this commit (the exact-fp32 run of
-        # the same check: 2e-3) -- at the former 2e-2 bar the test passed or failed by the run
-        H.check_model(cuda, 1e-3, 3e-2, truth="model_96x320_f64", loss_tol=1e-3, decode_min_match=0.7)
+        # gradient norms: the worst parameter is always the FIRST BatchNorm's weight (backbone.base.base_layer.1), where the
+        # rounding of every later layer has accumulated: 1.94e-2 .. 1.98e-2 over the runs of this commit (the exact-fp32 run of
+        # the same check: 2e-3; rounds 4-5, with the stock solver's atomics in the run: 1.90e-2 .. 2.03e-2 around a 2e-2 bar)
+        H.check_model(cuda, 1e-3, 2.2e-2, truth="model_96x320_f64", loss_tol=1e-3, decode_min_match=0.7)
     finally:
         _ext.set_precision("f32")
 
