@@ -140,7 +140,7 @@ def test_bf16x3_dense_path_is_the_split_gemm(cuda):
 
 @pytest.mark.parametrize("geom", [(64, 64, 96, 320), (128, 64, 48, 160), (256, 256, 24, 80)])
 def test_full_size_bf16x3(cuda, oracle_dcn, geom):
-    """BASELINE batch (8) in split precision: image 0 against the fp32 oracle, forward and all five gradients."""
+    """PARITY (image 0 of 8 against the fp32 oracle at 1e-4).  BASELINE batch (8) in split precision: forward and all five gradients."""
     from dcd_amd import _ext
     C, Co, H, W = geom
     x, w, b, off, m, gy = make_case(8, C, Co, H, W, seed=7, off_scale=0.5)
@@ -203,7 +203,8 @@ def test_bf16_path_is_the_one_product_kernel(cuda, shape):
 
 @pytest.mark.parametrize("geom", [(64, 64, 96, 320), (256, 128, 24, 80)])
 def test_full_size_bf16(cuda, oracle_dcn, geom):
-    """BASELINE batch (8) in mixed precision: image 0 against the fp32 oracle, forward and all five gradients; the other images
+    """PARITY (image 0 of 8 against the fp32 oracle at 1e-2) + PROPERTY (additivity of the batch for the other seven).
+    BASELINE batch (8) in mixed precision: image 0 against the fp32 oracle, forward and all five gradients; the other images
     through additivity of the batch (grad_weight / grad_bias of the batch = sum over single-image calls, to summation order)."""
     from dcd_amd import _ext
     C, Co, H, W = geom
@@ -500,7 +501,8 @@ DGDE_GEOMETRIES = [(512, 256, 12, 40), (256, 256, 24, 80), (256, 128, 24, 80), (
 @pytest.mark.parametrize("off_scale", [0.5, 2.0])
 @pytest.mark.parametrize("geom", DGDE_GEOMETRIES)
 def test_full_size_layer_properties(cuda, oracle_dcn, geom, off_scale):
-    """BASELINE size (every DGDE layer geometry, bs 8): size-independent properties instead of a full oracle run.
+    """PARITY (image 0 of 8 against the oracle: 2e-5 forward / 5e-5 gradients) + PROPERTY (additivity of the batch for the other seven).
+    BASELINE size (every DGDE layer geometry, bs 8): size-independent properties instead of a full oracle run.
     The kernel dispatch depends on the size (tiled kernels need H >= 16, W >= 32; Cin <= 64 / Cout <= 64 pick other
     variants; the deep layers run the generic kernels and the far-only passes), so each geometry is its own case, at
     sub-pixel offsets (0.5 px: everything from the staged windows) and at 2 px (far samples, list fallbacks).
