@@ -5,7 +5,7 @@ cd $GRAFT_REPO_ROOT
 out=gpurun_out/graph_memsets.txt
 : > $out
 run() { tag=$1; shift; env "$@" bash tools/prof_step.sh $tag ${EXTRA} > /dev/null 2>&1; \
-        echo "$tag: $(grep -c fillBuffer gpurun_out/r05_step_${tag}_sequence.txt) memset launches per traced step ($(python3 -c "import json;d=json.load(open('gpurun_out/r05_step_${tag}.json'));print(d['config']['step_launch'])"))" >> $out; }
+        echo "$tag: $(grep -c fillBuffer gpurun_out/step_${tag}_sequence.txt) memset launches per traced step ($(python3 -c "import json;d=json.load(open('gpurun_out/step_${tag}.json'));print(d['config']['step_launch'])"))" >> $out; }
 EXTRA="" run memchk_b8 DCD_STEP_GRAPH=1
 EXTRA="--amp" run memchk_amp DCD_STEP_GRAPH=1
 EXTRA="--precision bf16x3" run memchk_x3 DCD_STEP_GRAPH=1

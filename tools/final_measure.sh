@@ -1,4 +1,4 @@
-# Round-end measurement set (one GPU):  bash tools/final_measure.sh <tag>     -> gpurun_out/<tag>_*.json, r05_step_<tag>*_kernels.csv
+# Round-end measurement set (one GPU):  bash tools/final_measure.sh <tag>     -> gpurun_out/<tag>_*.json, step_<tag>*_kernels.csv
 tag=$1
 R=$GRAFT_REPO_ROOT
 cd $R
