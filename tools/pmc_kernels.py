@@ -116,7 +116,8 @@ def main():
             comp = e["mfma_busy"] + e["valu_frac"] if f32_mfma else max(e["mfma_busy"], e["valu_frac"])
             e["hbm_frac"] = e.get("hbm_bytes_per_dispatch", 0) / HBM_BPS / (us * 1e-6)
             if g("SQ_LDS_IDX_ACTIVE") and g("SQ_BUSY_CU_CYCLES"):
-                e["lds_busy"] = e["SQ_LDS_IDX_ACTIVE"] / (4.0 * e["SQ_BUSY_CU_CYCLES"])
+                e["lds_busy"] = e["SQ_LDS_IDX_ACTIVE"] / e["SQ_BUSY_CU_CYCLES"]         # one LDS pipe per CU
+            e["waves_per_simd"] = g("SQ_WAVE_CYCLES", 0) / max(g("SQ_BUSY_CU_CYCLES", 1), 1)
             e["composite_frac"] = min(1.0, max(comp, e["hbm_frac"], e.get("lds_busy", 0.0)))
             e["floor_us"] = e["composite_frac"] * us
             e["bound_by"] = ("mfma+valu" if f32_mfma else "max(mfma, valu)") if e["composite_frac"] == min(1.0, comp) else (
@@ -150,8 +151,9 @@ def main():
             e.get("bound_by", "-"), e.get("wait_frac", 0), e.get("issue_stall_frac", 0),
             e.get("lds_issue_stall_frac", 0), e.get("active_frac", 0), e.get("lds_conflict_frac", 0), e.get("l2_hit", 0),
             e.get("hbm_bytes_per_dispatch", 0) / 1e6,
-            # resident waves per SIMD, time average: wave-resident quad-cycles over the CU-busy quad-cycles of four SIMDs
-            e.get("SQ_WAVE_CYCLES", 0) / max(4.0 * e.get("SQ_BUSY_CU_CYCLES", 1), 1)))
+            # resident waves per SIMD, time average (as this rocprofv3 reports the two: one-wave-per-SIMD kernels read 1.00, the
+            # forward tile kernels with __launch_bounds__(256, 2) read 2.0)
+            e.get("SQ_WAVE_CYCLES", 0) / max(e.get("SQ_BUSY_CU_CYCLES", 1), 1)))
 
 
 if __name__ == "__main__":
