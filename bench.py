@@ -967,8 +967,8 @@ def main():
     ap.add_argument("--input", default="1280x384", help="WxH of the synthetic frames (the metric's size is 1280x384; other sizes are for "
                                                         "checks such as tools/check_graph_memsets.sh -- their line is not the metric)")
     ap.add_argument("--offset-std", type=float, default=0.01, help="std of the conv_offset_mask initialisation (SURVEY 8d: 0.01)")
-    ap.add_argument("--offset-std-2px", type=float, default=0.033,
-                    help="std of the extra `step_2px` model (mean |offset| ~1.6 px = E|2 randn|); 0 skips that leg")
+    ap.add_argument("--offset-std-2px", type=float, default=0.08,
+                    help="std of the extra `step_2px` model (0.08: mean |offset| 1.6 px = E|2 randn|, profiles/r06_offset_std.txt); 0 skips that leg")
     ap.add_argument("--recapture-every", type=int, default=0,
                     help="graphed step: capture the whole-step graph again every N replays (a captured graph freezes the DCN launch "
                          "policy of its capture; long runs refresh it)")

@@ -33,3 +33,7 @@ except Exception as e:
     print("$f", "failed", e)
 P
 done
+# round 6: the probes DESIGN.md section R6 cites
+python tools/time_conv1x1.py 8 2>&1 | grep -v amdgpu > gpurun_out/${tag}_conv1x1_f32.txt
+bash tools/route_probe.sh 2>&1 | grep -v amdgpu > gpurun_out/${tag}_route_probe.txt
+python tools/offset_std_probe.py 0.01 0.033 0.06 0.08 0.1 2>&1 | grep "^std" > gpurun_out/${tag}_offset_std.txt
