@@ -619,7 +619,9 @@ def test_conv1x1_of_cat_in_the_bf16_scope(cuda, monkeypatch, B, cs, O, H, W):
 
 @pytest.mark.parametrize("B,cs,O,H,W", [(2, (64, 64), 64, 24, 80), (1, (128, 128, 64, 128), 128, 12, 40), (2, (64,), 128, 16, 20),
                                         (1, (512, 512, 256), 512, 12, 40), (3, (16, 32), 48, 6, 10), (2, (32,), 64, 96, 320),
-                                        (8, (64, 64), 64, 96, 320)])
+                                        (8, (64, 64), 64, 96, 320),
+                                        (2, (80, 16), 96, 10, 14),      # ragged everywhere: 96 = 1.5 blocks of 64 inputs, 140 pixels
+                                        (1, (16,), 16, 2, 2)])          # one chunk, one group of four pixels
 def test_conv1x1_of_cat_on_the_fp32_pointwise_kernels(cuda, monkeypatch, B, cs, O, H, W):
     """ops.conv1x1_of_cat in exact fp32 on csrc/conv1x1_f32.inc (round 6: forward, input gradients and weight gradient as own
     kernels instead of batched library GEMMs) against conv2d(cat(...)) in fp64 at 2e-5 of the output scale (the bar of the other

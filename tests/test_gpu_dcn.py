@@ -431,6 +431,17 @@ def test_far_dominated_wide_layers_take_the_column_buffer_path(cuda, oracle_dcn)
         assert far_reported() == 0
         run(off, "fourth call (near again: one-pass kernel)")
         assert far_reported() == 0
+        # the same route in the two bf16 precisions (the column-buffer path's GEMMs in split / one-product form): against the fp32
+        # oracle at their own bars
+        for prec, tol in (("bf16x3", 1e-4), ("bf16", 1e-2)):
+            L.dcd_dcn_v2_forget(dev[1].data_ptr())
+            ref = oracle_dcn.dcn_v2_backward(x, w, b, off_far, m, gy, *a)
+            for call in ("armed", "column buffer"):
+                got = _ext.dcn_v2_backward(dev[0], dev[1], dev[2], off_far.to(cuda), dev[4], dev[5], *a, precision=prec)
+                for name, g_, r_ in zip(names, got, ref):
+                    close(g_.cpu(), r_, tol, "%s, %s call: %s" % (prec, call, name))
+                assert far_reported() == n_far
+        L.dcd_dcn_v2_forget(dev[1].data_ptr())
         _ext.set_handover("never")                                        # pinned: the route is never taken, results unchanged
         run(off_far, "pinned never")
         _ext.set_handover("always")
