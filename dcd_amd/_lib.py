@@ -76,6 +76,10 @@ SIGNATURES = {
     "dcd_conv1x1_bf16": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_bf16_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_bf16": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t]),
+    "dcd_conv3x3_s2_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "dcd_conv3x3_s2_f32_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
+    "dcd_conv3x3_s2_f32_wrw_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
+    "dcd_conv3x3_s2_f32_wrw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t]),
     "dcd_conv1x1_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t]),

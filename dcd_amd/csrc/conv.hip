@@ -441,6 +441,7 @@ __device__ __forceinline__ void wino_prep_split_body(const float *__restrict__ w
 #include "conv_direct_bf16.inc"
 #include "conv1x1_bf16.inc"
 #include "conv1x1_f32.inc"
+#include "conv_s2_f32.inc"
 
 // NP = 3: split-bf16 (hi*hi + hi*lo + lo*hi).  NP = 1 (DCD_PREC_BF16): ONE bf16 product per operand pair -- both operands rounded
 // to bf16 (round to nearest even), fp32 accumulate: the mixed-precision form (MODEL.FP16); the lo halves of the prepared weights
@@ -1580,6 +1581,83 @@ int dcd_conv1x1_wrw_f32(void *stream_, const float *grad_output, const float *in
     if (!lds_limit.raise((int)ldsb, pw_wrw_f32)) return DCD_ERR_LAUNCH;
     hipLaunchKernelGGL(pw_wrw_f32, dim3(S, ncg, nog), dim3(PWW_NT), ldsb, stream, grad_output, input, (float *)workspace, B, O, C, HW, S);
     hipLaunchKernelGGL(pw_wrw_reduce_f32, dim3(64, 4 * ncg, nog), dim3(256), 0, stream, (const float *)workspace, grad_weight, O, C, ldw, S, ncg);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+// ---- 3x3 / stride 2 / pad 1 in exact fp32 (conv_s2_f32.inc)
+static bool s2_args_ok(int B, int Cin, int H, int W, int Cout)
+{
+    return B > 0 && Cin > 0 && Cout > 0 && H > 0 && W > 0 && (H & 1) == 0 && (W & 7) == 0 && (Cin & 15) == 0 &&
+           (int64_t)Cin * H * W < (1ll << 29) && (int64_t)Cout * (H / 2) * (W / 2) < (1ll << 29);
+}
+
+int dcd_conv3x3_s2_f32(void *stream_, const float *input, const float *weight, float *output, int B, int Cin, int H, int W, int Cout)
+{
+    (void)hipGetLastError();
+    if (!input || !weight || !output || !s2_args_ok(B, Cin, H, W, Cout)) return DCD_ERR_BAD_ARG;
+    S2Args a;
+    a.x = input; a.w = weight; a.y = output; a.B = B; a.C = Cin; a.H = H; a.W = W; a.K = Cout; a.Ho = H / 2; a.Wo = W / 2;
+    // four output pixels per lane (512 per workgroup) unless that leaves fewer workgroups than CUs: then two (the small maps)
+    const int zb = (Cout + 31) / 32;
+    const bool small = (int64_t)((a.Ho * a.Wo + 511) / 512) * B * zb < (int64_t)device_cus();
+    if (small) hipLaunchKernelGGL(s2_conv_f32<2>, dim3((unsigned)((a.Ho * a.Wo + 255) / 256), B, zb), dim3(S2_NT), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(s2_conv_f32<4>, dim3((unsigned)((a.Ho * a.Wo + 511) / 512), B, zb), dim3(S2_NT), 0, (hipStream_t)stream_, a);
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+int dcd_conv3x3_s2_f32_backward_data(void *stream_, const float *grad_output, const float *weight, float *grad_input, int B, int Cin, int H,
+                                     int W, int Cout)
+{
+    (void)hipGetLastError();
+    if (!grad_output || !weight || !grad_input || !s2_args_ok(B, Cin, H, W, Cout) || (Cout & 15)) return DCD_ERR_BAD_ARG;
+    S2Args a;
+    a.x = grad_output; a.w = weight; a.y = grad_input; a.B = B; a.C = Cin; a.H = H; a.W = W; a.K = Cout; a.Ho = H / 2; a.Wo = W / 2;
+    const int zb = (Cin + 31) / 32;
+    const bool small = (int64_t)((a.Ho * a.Wo + 511) / 512) * B * zb < (int64_t)device_cus();
+    if (small) {
+        dim3 grid((unsigned)((a.Ho * a.Wo + 255) / 256), B, zb);
+        hipLaunchKernelGGL((s2_dgrad_f32<0, 2>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
+        hipLaunchKernelGGL((s2_dgrad_f32<1, 2>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
+    } else {
+        dim3 grid((unsigned)((a.Ho * a.Wo + 511) / 512), B, zb);
+        hipLaunchKernelGGL((s2_dgrad_f32<0, 4>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
+        hipLaunchKernelGGL((s2_dgrad_f32<1, 4>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
+    }
+    return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
+}
+
+static int s2_wrw_splits(int B, int Cin, int H, int W, int Cout)
+{
+    const int nblk = ((Cout + 31) / 32) * ((Cin + 31) / 32);
+    const int64_t groups = (int64_t)B * (H / 2) * (W / 2) / 8;
+    int64_t S = (8 * (int64_t)device_cus() + nblk - 1) / nblk;       // two waves per SIMD over the chip
+    if (S > groups / 8) S = groups / 8;                               // at least eight iterations per wave
+    if (S < 1) S = 1;
+    return (int)S;
+}
+
+size_t dcd_conv3x3_s2_f32_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout)
+{
+    if (!s2_args_ok(B, Cin, H, W, Cout)) return 0;
+    return (size_t)s2_wrw_splits(B, Cin, H, W, Cout) * 9 * Cout * Cin * sizeof(float);
+}
+
+int dcd_conv3x3_s2_f32_wrw(void *stream_, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
+                           int Cout, void *workspace, size_t workspace_bytes)
+{
+    hipStream_t stream = (hipStream_t)stream_;
+    (void)hipGetLastError();
+    if (!input || !grad_output || !grad_weight || !workspace || !s2_args_ok(B, Cin, H, W, Cout) || ((H / 2) & 1)) return DCD_ERR_BAD_ARG;
+    if ((int64_t)B * (Cin > Cout ? (int64_t)Cin * H * W : (int64_t)Cout * (H / 2) * (W / 2)) >= (1ll << 29)) return DCD_ERR_BAD_ARG;
+    S2WrwArgs a;
+    a.x = input; a.gy = grad_output; a.part = (float *)workspace; a.B = B; a.C = Cin; a.H = H; a.W = W; a.K = Cout; a.Ho = H / 2; a.Wo = W / 2;
+    a.S = s2_wrw_splits(B, Cin, H, W, Cout);
+    a.ncb = (Cin + 31) / 32;
+    if (workspace_bytes < (size_t)a.S * 9 * Cout * Cin * sizeof(float)) return DCD_ERR_WORKSPACE;
+    const int items = ((Cout + 31) / 32) * a.ncb * a.S;
+    hipLaunchKernelGGL(s2_wrw_f32, dim3((items + 3) / 4), dim3(S2_NT), 0, stream, a);
+    const int n = 9 * Cout * Cin;
+    hipLaunchKernelGGL(s2_wrw_reduce, dim3((n + 15) / 16), dim3(256), 0, stream, (const float *)workspace, grad_weight, Cout, Cin, a.S);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

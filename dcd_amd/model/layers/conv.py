@@ -29,6 +29,10 @@ class Conv2d(nn.Conv2d):
             return ops.conv3x3_stock_forward(x, self.weight)
         if (_ENABLED and self.bias is None and self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1)
                 and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
+                and ops.conv3x3_stride2_native_supported(x, self.weight)):
+            return ops.conv3x3_stride2_native(x, self.weight)              # exact fp32: csrc/conv_s2_f32.inc (round 6)
+        if (_ENABLED and self.bias is None and self.kernel_size == (3, 3) and self.stride == (2, 2) and self.padding == (1, 1)
+                and self.dilation == (1, 1) and self.groups == 1 and self.padding_mode == "zeros"
                 and ops.conv3x3_stride2_supported(x, self.weight)):
             return ops.conv3x3_stride2(x, self.weight)
         if (_ENABLED and _STEM and self.bias is None and self.padding_mode == "zeros" and not isinstance(self.padding, str)

@@ -1381,6 +1381,77 @@ def conv3x3_stride2(x, weight):
     return y
 
 
+# ----------------------------------------------------------------------------------------------
+# ... and natively in exact fp32 (csrc/conv_s2_f32.inc, round 6): no space-to-depth copies, no 4x multiplies, no stock solver
+# ----------------------------------------------------------------------------------------------
+_S2_NATIVE = os.environ.get("DCD_CONV_S2_NATIVE", "1") != "0"          # 0: exact fp32 keeps the stock solver / the space-to-depth form (A/B)
+_S2_NATIVE_MIN_PIXELS = int(os.environ.get("DCD_CONV_S2_NATIVE_MIN_PIXELS", "15360"))
+
+
+def conv3x3_stride2_native_supported(x, weight):
+    """Stride-2 layers the native fp32 kernels take: exact fp32, even H (H % 4 for the weight gradient), W % 8 == 0, channel counts
+    that are multiples of 16, and at least 15 360 output pixels per launch -- DLA levels 1-4 at 384x1280 x 8 (forward 120 / 106 / 103 /
+    100 us against the stock solver's 217 / 173 / 152 / 131, input gradient 231 / 124 / 119 / 135 against 233 / 177 / 180 / 155; the
+    12x40 outputs of level 5 stay where they were: 144 against 125; one image: levels 1 and 2)."""
+    if not (_S2_NATIVE and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
+        return False
+    if _conv_prec(x) != PREC_F32:
+        return False
+    B, C, H, W = x.shape
+    K = weight.shape[0]
+    return (H % 4 == 0 and W % 8 == 0 and C % 16 == 0 and K % 16 == 0 and B * (H // 2) * (W // 2) >= _S2_NATIVE_MIN_PIXELS
+            and B * max(C * H * W, K * (H // 2) * (W // 2)) < (1 << 29))
+
+
+class _Conv3x3S2Native(torch.autograd.Function):
+    """conv2d(x, weight, stride 2, padding 1) on csrc/conv_s2_f32.inc: forward, input gradient, weight gradient.  The weight gradient
+    of the layers with at least 64 input channels stays on the stock solver in eager steps (131 / 122 / 119 us against 143 / 138 /
+    139 for DLA levels 3-5) unless the process captures whole-step graphs (`_S2D_MODE == "1"`: nothing of the stock solver inside a
+    capture)."""
+
+    @staticmethod
+    def forward(ctx, x, weight):
+        _lib.require_cuda(x, weight)
+        x, weight = _f32c(x), _f32c(weight)
+        B, C, H, W = x.shape
+        K = weight.shape[0]
+        y = torch.empty((B, K, H // 2, W // 2), dtype=torch.float32, device=x.device)
+        _lib.check(_lib.lib().dcd_conv3x3_s2_f32(_lib.stream_of(x), x.data_ptr(), weight.data_ptr(), y.data_ptr(), B, C, H, W, K),
+                   "dcd_conv3x3_s2_f32")
+        ctx.save_for_backward(x, weight)
+        return y
+
+    @staticmethod
+    @torch.autograd.function.once_differentiable
+    def backward(ctx, gy):
+        x, weight = ctx.saved_tensors
+        gy = _f32c(gy)
+        L = _lib.lib()
+        B, C, H, W = x.shape
+        K = weight.shape[0]
+        st = _lib.stream_of(x)
+        gx = gw = None
+        if ctx.needs_input_grad[0]:
+            gx = torch.empty_like(x)
+            _lib.check(L.dcd_conv3x3_s2_f32_backward_data(st, gy.data_ptr(), weight.data_ptr(), gx.data_ptr(), B, C, H, W, K),
+                       "dcd_conv3x3_s2_f32_backward_data")
+        if ctx.needs_input_grad[1]:
+            if C >= 64 and _S2D_MODE != "1" and not torch.cuda.is_current_stream_capturing():
+                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
+                                                         [False, True, False])[1]
+            else:
+                gw = torch.empty_like(weight)
+                n = L.dcd_conv3x3_s2_f32_wrw_workspace_bytes(B, C, H, W, K)
+                ws = torch.empty(max(n, 16), dtype=torch.uint8, device=x.device)
+                _lib.check(L.dcd_conv3x3_s2_f32_wrw(st, x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, C, H, W, K, ws.data_ptr(), n),
+                           "dcd_conv3x3_s2_f32_wrw")
+        return gx, gw
+
+
+def conv3x3_stride2_native(x, weight):
+    return _Conv3x3S2Native.apply(x, weight)
+
+
 def conv3x3_wrw_only_supported(x, weight):
     """Maps below the forward kernel's limit (only when DCD_CONV_MIN_MAP raises it) where the weight-gradient kernel still
     wins (256->256 @ 24x80: 0.14 vs 0.18 ms incl. the stock path's transposes, tools/time_conv.py)."""

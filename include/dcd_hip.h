@@ -571,6 +571,20 @@ size_t dcd_conv1x1_wrw_f32_workspace_bytes(int B, int O, int C, long long HW);
 int dcd_conv1x1_wrw_f32(void *stream, const float *grad_output, const float *input, float *grad_weight, int ldw, int B, int O, int C,
                         long long HW, void *workspace, size_t workspace_bytes);
 
+/* 3x3 / stride 2 / pad 1 convolution in exact fp32 (csrc/conv_s2_f32.inc, round 6): the first convolution of every DLA level
+ * (DGDE/model/backbone/dla_dcn.py:76-78, 313-326: `nn.Conv2d(c, k, 3, stride=2, padding=1, bias=False)`).  No LDS for the
+ * activations: a lane's nine taps x four output pixels are 27 registers of one channel.  input (B, Cin, H, W) -> output
+ * (B, Cout, H/2, W/2); H even, W % 8 == 0, Cin % 16 == 0. */
+int dcd_conv3x3_s2_f32(void *stream, const float *input, const float *weight, float *output, int B, int Cin, int H, int W, int Cout);
+/* ... its input gradient (grad_output (B, Cout, H/2, W/2) -> grad_input (B, Cin, H, W), every element written; Cout % 16 == 0 too) and
+ * its weight gradient (grad_weight (Cout, Cin, 3, 3) overwritten; partial sums per pixel split in a fixed order; H % 4 == 0;
+ * workspace: dcd_conv3x3_s2_f32_wrw_workspace_bytes). */
+int dcd_conv3x3_s2_f32_backward_data(void *stream, const float *grad_output, const float *weight, float *grad_input, int B, int Cin, int H,
+                                     int W, int Cout);
+size_t dcd_conv3x3_s2_f32_wrw_workspace_bytes(int B, int Cin, int H, int W, int Cout);
+int dcd_conv3x3_s2_f32_wrw(void *stream, const float *input, const float *grad_output, float *grad_weight, int B, int Cin, int H, int W,
+                           int Cout, void *workspace, size_t workspace_bytes);
+
 /* Weight gradient of the same convolution (torch's `convolution_backward(..., output_mask=[0,1,0])` for those call sites),
  * also in the Winograd domain: grad_weight (Cout,Cin,3,3) = correlation of input (B,Cin,H,W) with grad_output (B,Cout,H,W).
  * Overwrites grad_weight; the partial sums of the workgroups are added in a fixed order (bitwise reproducible).

@@ -696,6 +696,53 @@ def test_conv1x1_fp32_argument_checks(cuda):
 
 
 @pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80),
+                                       (1, 256, 512, 12, 40), (3, 16, 48, 8, 16), (8, 16, 32, 384, 1280), (8, 64, 128, 96, 320)])
+def test_stride2_conv_native_fp32_kernels(cuda, monkeypatch, B, C, K, H, W):
+    """csrc/conv_s2_f32.inc (round 6): the stride-2 / pad-1 3x3 convolutions of the DLA levels in exact fp32 -- forward, input gradient
+    (both row phases, both forms: four and two pixels per lane) and weight gradient against conv2d in fp64 at 2e-5 of each
+    result's scale: DLA's five channel pairs, 48 outputs (a partial block of 32), one-chunk layers, the full-size first two levels;
+    the module dispatch takes them in exact fp32 only, and the library refuses the shapes the kernels cannot run."""
+    from dcd_amd import _ext, _lib, ops
+    from dcd_amd.model.layers.conv import Conv2d
+    monkeypatch.setattr(ops, "_S2_NATIVE_MIN_PIXELS", 0)
+    monkeypatch.setattr(ops, "_S2D_MODE", "1")                   # own weight gradient for every width (as in a graph process)
+    g = torch.Generator().manual_seed(C * 3 + K)
+    x = torch.randn(B, C, H, W, generator=g)
+    w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
+    gy = torch.randn(B, K, H // 2, W // 2, generator=g)
+    nb = min(B, 2)                                              # fp64 reference of the activations on two images (the full-size cases)
+    ref = F.conv2d(x[:nb].double(), w.double(), None, 2, 1)
+    ref_gx = torch.nn.grad.conv2d_input(x[:nb].shape, w.double(), gy[:nb].double(), stride=2, padding=1)
+    ref_gw = torch.nn.grad.conv2d_weight(x.to(cuda).double(), w.shape, gy.to(cuda).double(), stride=2, padding=1).cpu()
+    assert ops.conv3x3_stride2_native_supported(x.to(cuda), w.to(cuda))
+    xd, wd = x.to(cuda).requires_grad_(True), w.to(cuda).requires_grad_(True)
+    y = ops.conv3x3_stride2_native(xd, wd)
+    y.backward(gy.to(cuda))
+    _close(y.detach()[:nb].cpu(), ref, "native stride-2 forward", 2e-5)
+    _close(xd.grad[:nb].cpu(), ref_gx, "native stride-2 grad_input", 2e-5)
+    _close(wd.grad.cpu(), ref_gw, "native stride-2 grad_weight", 2e-5)
+    conv = Conv2d(C, K, 3, stride=2, padding=1, bias=False).to(cuda)
+    calls = []
+    real = ops.conv3x3_stride2_native
+    monkeypatch.setattr(ops, "conv3x3_stride2_native", lambda a, b: (calls.append(1), real(a, b))[1])
+    out = conv(x.to(cuda))
+    assert calls and (out - F.conv2d(x.to(cuda), conv.weight, None, 2, 1)).abs().max().item() <= 2e-5 * out.abs().max().item()
+    del calls[:]
+    with _ext.precision_scope("bf16"):
+        conv(x.to(cuda))
+    assert not calls, "the bf16 scope keeps the space-to-depth form on the bf16 kernels"
+    L = _lib.lib()
+    st = _lib.stream_of(xd)
+    bad = torch.randn(1, 16, 6, 12, device=cuda)                 # W % 8 != 0
+    assert L.dcd_conv3x3_s2_f32(st, bad.data_ptr(), wd.data_ptr(), bad.data_ptr(), 1, 16, 6, 12, 16) == 1
+    assert L.dcd_conv3x3_s2_f32(st, xd.data_ptr(), wd.data_ptr(), None, B, C, H, W, K) == 1
+    assert L.dcd_conv3x3_s2_f32(st, xd.data_ptr(), wd.data_ptr(), y.data_ptr(), B, 24, H, W, K) == 1          # Cin % 16
+    n = L.dcd_conv3x3_s2_f32_wrw_workspace_bytes(B, C, H, W, K)
+    ws = torch.empty(n, dtype=torch.uint8, device=cuda)
+    assert L.dcd_conv3x3_s2_f32_wrw(st, xd.data_ptr(), y.data_ptr(), wd.grad.data_ptr(), B, C, H, W, K, ws.data_ptr(), n - 1) == 2
+
+
+@pytest.mark.parametrize("B,C,K,H,W", [(2, 16, 32, 48, 80), (1, 32, 64, 24, 80), (2, 64, 128, 24, 80), (1, 128, 256, 24, 80),
                                        (2, 256, 512, 6, 20), (1, 64, 128, 13, 38)])      # off H % 4 / W % 8: the zero-padded form
 def test_stride2_conv_through_space_to_depth(cuda, monkeypatch, B, C, K, H, W):
     """ops.conv3x3_stride2: the stride-2 / pad-1 3x3 convolution of the DLA levels as a stride-1 convolution of the pixel-unshuffled
