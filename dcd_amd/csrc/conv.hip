@@ -1647,7 +1647,7 @@ int dcd_conv3x3_s2_f32_wrw(void *stream_, const float *input, const float *grad_
 {
     hipStream_t stream = (hipStream_t)stream_;
     (void)hipGetLastError();
-    if (!input || !grad_output || !grad_weight || !workspace || !s2_args_ok(B, Cin, H, W, Cout) || ((H / 2) & 1)) return DCD_ERR_BAD_ARG;
+    if (!input || !grad_output || !grad_weight || !workspace || !s2_args_ok(B, Cin, H, W, Cout) || ((H / 2) & 1) || W < 16) return DCD_ERR_BAD_ARG;
     if ((int64_t)B * (Cin > Cout ? (int64_t)Cin * H * W : (int64_t)Cout * (H / 2) * (W / 2)) >= (1ll << 29)) return DCD_ERR_BAD_ARG;
     S2WrwArgs a;
     a.x = input; a.gy = grad_output; a.part = (float *)workspace; a.B = B; a.C = Cin; a.H = H; a.W = W; a.K = Cout; a.Ho = H / 2; a.Wo = W / 2;

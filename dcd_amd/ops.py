@@ -1390,9 +1390,9 @@ _S2_NATIVE_MIN_PIXELS = int(os.environ.get("DCD_CONV_S2_NATIVE_MIN_PIXELS", "153
 
 def conv3x3_stride2_native_supported(x, weight):
     """Stride-2 layers the native fp32 kernels take: exact fp32, even H (H % 4 for the weight gradient), W % 8 == 0, channel counts
-    that are multiples of 16, and at least 15 360 output pixels per launch -- DLA levels 1-4 at 384x1280 x 8 (forward 120 / 106 / 103 /
-    100 us against the stock solver's 217 / 173 / 152 / 131, input gradient 231 / 124 / 119 / 135 against 233 / 177 / 180 / 155; the
-    12x40 outputs of level 5 stay where they were: 144 against 125; one image: levels 1 and 2)."""
+    that are multiples of 16, and at least 15 360 output pixels per launch -- DLA levels 1-4 at 384x1280 x 8 (forward 120 / 105 / 102 /
+    98 us against the stock solver's 218 / 177 / 150 / 132, input gradient 232 / 124 / 117 / 132 against 250 / 198 / 190 / 168; the
+    12x40 outputs of level 5 stay where they were: 142 against 126; one image: levels 1 and 2).  profiles/r06_stride2.txt."""
     if not (_S2_NATIVE and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
         return False
     if _conv_prec(x) != PREC_F32:
@@ -1404,10 +1404,8 @@ def conv3x3_stride2_native_supported(x, weight):
 
 
 class _Conv3x3S2Native(torch.autograd.Function):
-    """conv2d(x, weight, stride 2, padding 1) on csrc/conv_s2_f32.inc: forward, input gradient, weight gradient.  The weight gradient
-    of the layers with at least 64 input channels stays on the stock solver in eager steps (131 / 122 / 119 us against 143 / 138 /
-    139 for DLA levels 3-5) unless the process captures whole-step graphs (`_S2D_MODE == "1"`: nothing of the stock solver inside a
-    capture)."""
+    """conv2d(x, weight, stride 2, padding 1) on csrc/conv_s2_f32.inc: forward, input gradient, weight gradient (224 / 177 / 125 / 119 us
+    for DLA levels 1-4 at bs 8 against the stock solver's 368 / 203 / 125 / 122)."""
 
     @staticmethod
     def forward(ctx, x, weight):
@@ -1436,15 +1434,11 @@ class _Conv3x3S2Native(torch.autograd.Function):
             _lib.check(L.dcd_conv3x3_s2_f32_backward_data(st, gy.data_ptr(), weight.data_ptr(), gx.data_ptr(), B, C, H, W, K),
                        "dcd_conv3x3_s2_f32_backward_data")
         if ctx.needs_input_grad[1]:
-            if C >= 64 and _S2D_MODE != "1" and not torch.cuda.is_current_stream_capturing():
-                gw = torch.ops.aten.convolution_backward(gy, x, weight, None, [2, 2], [1, 1], [1, 1], False, [0, 0], 1,
-                                                         [False, True, False])[1]
-            else:
-                gw = torch.empty_like(weight)
-                n = L.dcd_conv3x3_s2_f32_wrw_workspace_bytes(B, C, H, W, K)
-                ws = torch.empty(max(n, 16), dtype=torch.uint8, device=x.device)
-                _lib.check(L.dcd_conv3x3_s2_f32_wrw(st, x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, C, H, W, K, ws.data_ptr(), n),
-                           "dcd_conv3x3_s2_f32_wrw")
+            gw = torch.empty_like(weight)
+            n = L.dcd_conv3x3_s2_f32_wrw_workspace_bytes(B, C, H, W, K)
+            ws = torch.empty(max(n, 16), dtype=torch.uint8, device=x.device)
+            _lib.check(L.dcd_conv3x3_s2_f32_wrw(st, x.data_ptr(), gy.data_ptr(), gw.data_ptr(), B, C, H, W, K, ws.data_ptr(), n),
+                       "dcd_conv3x3_s2_f32_wrw")
         return gx, gw
 
 

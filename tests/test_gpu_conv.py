@@ -705,7 +705,6 @@ def test_stride2_conv_native_fp32_kernels(cuda, monkeypatch, B, C, K, H, W):
     from dcd_amd import _ext, _lib, ops
     from dcd_amd.model.layers.conv import Conv2d
     monkeypatch.setattr(ops, "_S2_NATIVE_MIN_PIXELS", 0)
-    monkeypatch.setattr(ops, "_S2D_MODE", "1")                   # own weight gradient for every width (as in a graph process)
     g = torch.Generator().manual_seed(C * 3 + K)
     x = torch.randn(B, C, H, W, generator=g)
     w = torch.randn(K, C, 3, 3, generator=g) / (C * 9) ** 0.5
