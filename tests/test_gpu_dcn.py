@@ -9,6 +9,16 @@ import torch
 pytestmark = pytest.mark.gpu
 
 
+@pytest.fixture(autouse=True)
+def _fresh_launch_policy(cuda):
+    """The DCN backward's per-layer launch policy is keyed by the weight's device address, and the caching allocator hands a freed
+    address to the next test: a test would inherit the far-sample history of whichever test used that block before it (results
+    never depend on it, launch SEQUENCES do -- and some tests here assert on the sequence).  Every test starts with no history."""
+    from dcd_amd import _lib
+    _lib.lib().dcd_dcn_v2_forget(None)
+    yield
+
+
 def close(got, ref, rel, what):
     got = got.detach().float().cpu()
     ref = ref.detach().float().cpu()
