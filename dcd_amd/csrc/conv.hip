@@ -1613,16 +1613,9 @@ int dcd_conv3x3_s2_f32_backward_data(void *stream_, const float *grad_output, co
     S2Args a;
     a.x = grad_output; a.w = weight; a.y = grad_input; a.B = B; a.C = Cin; a.H = H; a.W = W; a.K = Cout; a.Ho = H / 2; a.Wo = W / 2;
     const int zb = (Cin + 31) / 32;
-    const bool small = (int64_t)((a.Ho * a.Wo + 511) / 512) * B * zb < (int64_t)device_cus();
-    if (small) {
-        dim3 grid((unsigned)((a.Ho * a.Wo + 255) / 256), B, zb);
-        hipLaunchKernelGGL((s2_dgrad_f32<0, 2>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
-        hipLaunchKernelGGL((s2_dgrad_f32<1, 2>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
-    } else {
-        dim3 grid((unsigned)((a.Ho * a.Wo + 511) / 512), B, zb);
-        hipLaunchKernelGGL((s2_dgrad_f32<0, 4>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
-        hipLaunchKernelGGL((s2_dgrad_f32<1, 4>), grid, dim3(S2_NT), 0, (hipStream_t)stream_, a);
-    }
+    const bool small = (int64_t)((a.Ho * a.Wo + 511) / 512) * B * 2 * zb < (int64_t)device_cus();
+    if (small) hipLaunchKernelGGL(s2_dgrad_f32<2>, dim3((unsigned)((a.Ho * a.Wo + 255) / 256), B, 2 * zb), dim3(S2_NT), 0, (hipStream_t)stream_, a);
+    else hipLaunchKernelGGL(s2_dgrad_f32<4>, dim3((unsigned)((a.Ho * a.Wo + 511) / 512), B, 2 * zb), dim3(S2_NT), 0, (hipStream_t)stream_, a);
     return hipGetLastError() == hipSuccess ? DCD_OK : DCD_ERR_LAUNCH;
 }
 

@@ -1385,14 +1385,15 @@ def conv3x3_stride2(x, weight):
 # ... and natively in exact fp32 (csrc/conv_s2_f32.inc, round 6): no space-to-depth copies, no 4x multiplies, no stock solver
 # ----------------------------------------------------------------------------------------------
 _S2_NATIVE = os.environ.get("DCD_CONV_S2_NATIVE", "1") != "0"          # 0: exact fp32 keeps the stock solver / the space-to-depth form (A/B)
-_S2_NATIVE_MIN_PIXELS = int(os.environ.get("DCD_CONV_S2_NATIVE_MIN_PIXELS", "15360"))
+_S2_NATIVE_MIN_PIXELS = int(os.environ.get("DCD_CONV_S2_NATIVE_MIN_PIXELS", "3840"))
 
 
 def conv3x3_stride2_native_supported(x, weight):
-    """Stride-2 layers the native fp32 kernels take: exact fp32, even H (H % 4 for the weight gradient), W % 8 == 0, channel counts
-    that are multiples of 16, and at least 15 360 output pixels per launch -- DLA levels 1-4 at 384x1280 x 8 (forward 120 / 105 / 102 /
-    98 us against the stock solver's 218 / 177 / 150 / 132, input gradient 232 / 124 / 117 / 132 against 250 / 198 / 190 / 168; the
-    12x40 outputs of level 5 stay where they were: 142 against 126; one image: levels 1 and 2).  profiles/r06_stride2.txt."""
+    """Stride-2 layers the native fp32 kernels take: exact fp32, H % 4 == 0, W % 8 == 0 (and >= 16), channel counts that are multiples of
+    16, at least 3 840 output pixels per launch -- all five DLA levels at 384x1280 x 8, levels 1-3 at one image.  Per level at bs 8
+    (profiles/r06_stride2.txt): forward 124 / 110 / 104 / 107 / 125 us against the stock solver's 221 / 174 / 150 / 131 / 128, input
+    gradient 227 / 121 / 124 / 132 / 148 against 243 / 186 / 180 / 157 / 164, weight gradient 231 / 178 / 126 / 121 / 127 against
+    368 / 203 / 125 / 122 / 116: 2.1 ms for the five layers where the stock solver takes 2.7 and the space-to-depth form 3.75."""
     if not (_S2_NATIVE and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
         return False
     if _conv_prec(x) != PREC_F32:
