@@ -1400,7 +1400,7 @@ def conv3x3_stride2_native_supported(x, weight):
         return False
     B, C, H, W = x.shape
     K = weight.shape[0]
-    return (H % 4 == 0 and W % 8 == 0 and C % 16 == 0 and K % 16 == 0 and B * (H // 2) * (W // 2) >= _S2_NATIVE_MIN_PIXELS
+    return (H % 4 == 0 and W % 8 == 0 and W >= 16 and C % 16 == 0 and K % 16 == 0 and B * (H // 2) * (W // 2) >= _S2_NATIVE_MIN_PIXELS
             and B * max(C * H * W, K * (H // 2) * (W // 2)) < (1 << 29))
 
 
