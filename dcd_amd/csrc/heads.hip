@@ -33,6 +33,44 @@ __device__ __forceinline__ void pair_from_index(int q, int K, int &i, int &j)
     j = q - ii * (2 * K - ii - 1) / 2 + ii + 1;
 }
 
+// value of lane ^ M (M = 1 .. 32) without the LDS crossbar
+template <int M>
+__device__ __forceinline__ unsigned xor_lane(unsigned v, int lane)
+{
+    if constexpr (M == 1) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0xB1, 0xF, 0xF, false);            // quad_perm [1,0,3,2]
+    } else if constexpr (M == 2) {
+        return (unsigned)__builtin_amdgcn_update_dpp(0, (int)v, 0x4E, 0xF, 0xF, false);            // quad_perm [2,3,0,1]
+    } else if constexpr (M == 4) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x1B, 0xF, 0xF, false);               // quad_perm [3,2,1,0]: i ^ 3
+        return (unsigned)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);                // row_half_mirror: 7 - i   -> i ^ 4
+    } else if constexpr (M == 8) {
+        const int t = __builtin_amdgcn_update_dpp(0, (int)v, 0x140, 0xF, 0xF, false);              // row_mirror: 15 - i
+        return (unsigned)__builtin_amdgcn_update_dpp(0, t, 0x141, 0xF, 0xF, false);                // row_half_mirror          -> i ^ 8
+    } else if constexpr (M == 16) {
+        // v_permlane16_swap: the odd rows of the first operand <-> the even rows of the second
+        const auto r = __builtin_amdgcn_permlane16_swap(v, v, false, false);
+        return (lane & 16) ? r[0] : r[1];
+    } else {
+        // v_permlane32_swap: the upper half of the first operand <-> the lower half of the second
+        const auto r = __builtin_amdgcn_permlane32_swap(v, v, false, false);
+        return (lane & 32) ? r[0] : r[1];
+    }
+}
+
+constexpr int EDGE_E = 8;                 // keys per thread of the register form of the sort (EDGE_E * EDGE_THREADS = 4 096 padded pairs)
+
+template <int M>
+__device__ __forceinline__ void edge_lane_stage(unsigned long long (&key)[EDGE_E], bool take_max, int tid)
+{
+#pragma unroll
+    for (int r = 0; r < EDGE_E; ++r) {
+        const unsigned lo = xor_lane<M>((unsigned)key[r], tid), hi = xor_lane<M>((unsigned)(key[r] >> 32), tid);
+        const unsigned long long other = ((unsigned long long)hi << 32) | lo;
+        key[r] = ((key[r] > other) == take_max) ? key[r] : other;
+    }
+}
+
 // ---------------------------------------------------------------------------------------------
 // Edge-constraint depth solve, forward.  DGDE/model/anno_encoder.py:326-390, GMW/main.py:373-416.
 // ---------------------------------------------------------------------------------------------
@@ -94,20 +132,76 @@ __global__ __launch_bounds__(EDGE_THREADS) void edge_depth_fwd(const float *__re
         return;
     }
 
-    // bitonic sort, descending by (|dv|, lower pair index first)
-    for (int size = 2; size <= npad; size <<= 1) {
-        for (int stride = size >> 1; stride > 0; stride >>= 1) {
-            for (int t = tid; t < (npad >> 1); t += EDGE_THREADS) {
-                const int lo = ((t / stride) * stride * 2) + (t % stride);
-                const int hi = lo + stride;
-                const bool desc = ((lo & size) == 0);
-                const unsigned long long a = skey[lo], b = skey[hi];
-                if ((a < b) == desc) {
-                    skey[lo] = b;
-                    skey[hi] = a;
+    // bitonic sort, descending by (|dv|, lower pair index first).  4 096 keys (the reference's 73 keypoints: 2 628 pairs) on 512
+    // threads: a thread owns the eight consecutive positions 8 tid .. 8 tid + 7 in registers, so the strides 1 / 2 / 4 are register
+    // compare-exchanges, 8 .. 256 are lane exchanges inside the wave, and only 512 / 1 024 / 2 048 (6 of the 78 stages) go through
+    // LDS and a barrier -- as 78 LDS passes with a barrier each the launch took 113 us whatever the batch.  The keys are distinct (the
+    // pair index is their low half), so every correct network gives the same order.
+    if (npad == EDGE_E * EDGE_THREADS) {
+        unsigned long long key[EDGE_E];
+        __syncthreads();                                    // (skey is rewritten below as the exchange buffer)
+#pragma unroll
+        for (int r = 0; r < EDGE_E; ++r) key[r] = skey[tid * EDGE_E + r];
+        __syncthreads();
+        for (int size = 2; size <= npad; size <<= 1) {
+            const bool desc = ((tid * EDGE_E) & size) == 0;     // (for the strides >= EDGE_E: size >= 2 EDGE_E)
+            for (int stride = size >> 1; stride >= EDGE_E * 64; stride >>= 1) {
+                const int m = stride / EDGE_E;                  // partner thread = tid ^ m (another wave), same register
+                const bool take_max = (((tid * EDGE_E) & stride) == 0) == desc;
+                unsigned long long other[EDGE_E];
+#pragma unroll
+                for (int r = 0; r < EDGE_E; ++r) skey[r * EDGE_THREADS + tid] = key[r];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < EDGE_E; ++r) other[r] = skey[r * EDGE_THREADS + (tid ^ m)];
+                __syncthreads();
+#pragma unroll
+                for (int r = 0; r < EDGE_E; ++r) key[r] = ((key[r] > other[r]) == take_max) ? key[r] : other[r];
+            }
+            // partner lane = lane ^ M: data-parallel-primitive moves and the gfx950 row / half swaps, all on the vector ALU
+            // (as ds_bpermute_b32 -- what __shfl_xor compiles to -- the 624 exchanges of a wave were 34 of the launch's 41 us)
+            if (32 * EDGE_E < size) edge_lane_stage<32>(key, (((tid * EDGE_E) & (32 * EDGE_E)) == 0) == desc, tid);
+            if (16 * EDGE_E < size) edge_lane_stage<16>(key, (((tid * EDGE_E) & (16 * EDGE_E)) == 0) == desc, tid);
+            if (8 * EDGE_E < size) edge_lane_stage<8>(key, (((tid * EDGE_E) & (8 * EDGE_E)) == 0) == desc, tid);
+            if (4 * EDGE_E < size) edge_lane_stage<4>(key, (((tid * EDGE_E) & (4 * EDGE_E)) == 0) == desc, tid);
+            if (2 * EDGE_E < size) edge_lane_stage<2>(key, (((tid * EDGE_E) & (2 * EDGE_E)) == 0) == desc, tid);
+            if (1 * EDGE_E < size) edge_lane_stage<1>(key, (((tid * EDGE_E) & (1 * EDGE_E)) == 0) == desc, tid);
+#pragma unroll
+            for (int st = EDGE_E / 2; st >= 1; st >>= 1) {
+                if (st < size) {
+#pragma unroll
+                    for (int r = 0; r < EDGE_E; ++r) {
+                        if ((r & st) == 0) {
+                            const bool desc = ((tid * EDGE_E + r) & size) == 0;
+                            const unsigned long long a = key[r], b = key[r | st];
+                            const bool sw = (a < b) == desc;
+                            key[r] = sw ? b : a;
+                            key[r | st] = sw ? a : b;
+                        }
+                    }
                 }
             }
-            __syncthreads();
+        }
+        // back to LDS in rank order: the output loop below walks the ranks with consecutive threads (coalesced stores, three
+        // dependent mask loads per thread instead of eight)
+#pragma unroll
+        for (int e = 0; e < EDGE_E; ++e) skey[tid * EDGE_E + e] = key[e];
+        __syncthreads();
+    } else {
+        for (int size = 2; size <= npad; size <<= 1) {
+            for (int stride = size >> 1; stride > 0; stride >>= 1) {
+                for (int t = tid; t < (npad >> 1); t += EDGE_THREADS) {
+                    const int lo = ((t / stride) * stride * 2) + (t % stride);
+                    const int hi = lo + stride;
+                    const bool desc = ((lo & size) == 0);
+                    const unsigned long long a = skey[lo], b = skey[hi];
+                    if ((a < b) == desc) {
+                        skey[lo] = b;
+                        skey[hi] = a;
+                    }
+                }
+                __syncthreads();
+            }
         }
     }
 
