@@ -63,6 +63,22 @@ def test_edge_depth_train_topk_exact(cuda, N):
     np.testing.assert_allclose(depth.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
 
 
+@pytest.mark.parametrize("K,topk", [(64, 1500), (65, 1500), (91, 1500), (91, 4095), (92, 1500), (20, 100)])
+def test_edge_depth_topk_order_at_both_forms_of_the_sort(cuda, K, topk):
+    """PARITY.  The ordering runs as a register / lane-exchange network when the pairs pad to 4 096 (65 <= K <= 91: the reference's
+    73 keypoints) and as LDS passes otherwise: the pair indices are bit-exact on both sides of both boundaries, with ties."""
+    from dcd_amd import ops
+    from oracle import heads_oracle as ho
+    N = 7
+    kps, k3, rot, P, _ = synth_objects(N, K, seed=K, noise=0.3)
+    kps[:, K // 2:, 1] = kps[:, K // 2:K // 2 + 1, 1]          # half the keypoints share a row: ties at dv == 0
+    ref, _, ridx = ho.pairs_kpts_depth(kps, k3, rot, P, training=True, num_k=topk)
+    t = [torch.from_numpy(a).to(cuda) for a in (kps, k3, rot, P)]
+    depth, idx, _ = ops._PairsDepth.apply(t[0], t[1], t[2], t[3], None, topk, 2.0, 80.0, 0, 1)
+    assert np.array_equal(idx.cpu().numpy().astype(np.int64), ridx)
+    np.testing.assert_allclose(depth.cpu().numpy(), ref, rtol=2e-4, atol=2e-4)
+
+
 def test_edge_depth_ties_lower_index_first(cuda):
     """Many identical v (degenerate keypoints) -> ties in |dv|; rule: lower pair index first."""
     from dcd_amd import ops
