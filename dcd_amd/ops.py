@@ -1396,9 +1396,11 @@ def conv3x3_stride2_native_supported(x, weight):
     368 / 203 / 125 / 122 / 116: 2.1 ms for the five layers where the stock solver takes 2.7 and the space-to-depth form 3.75."""
     if not (_S2_NATIVE and x.is_cuda and x.dtype == torch.float32 and weight.dim() == 4 and tuple(weight.shape[2:]) == (3, 3)):
         return False
-    # (inside a bf16 / split-bf16 precision scope as well: the scopes permit reduced products, they do not oblige them, and the exact
-    # kernels are the faster ones here -- 2.1 ms for the five layers against 2.4 for the bf16 space-to-depth form with its
-    # pixel_unshuffle copies and 4x the channels, 3.75 for the split one)
+    # inside the split-bf16 scope as well (a scope permits reduced products, it does not oblige them): the exact kernels take 2.1 ms
+    # for the five layers where the split space-to-depth form takes 3.75 -- bf16x3 step 34.4 -> 33.2 ms.  Not inside the bf16 scope:
+    # the one-product space-to-depth form is the faster one there (everything but DCN 18.3 ms against 18.5-19.1 with these kernels)
+    if _conv_prec(x) == PREC_BF16:
+        return False
     B, C, H, W = x.shape
     K = weight.shape[0]
     return (H % 4 == 0 and W % 8 == 0 and W >= 16 and C % 16 == 0 and K % 16 == 0 and B * (H // 2) * (W // 2) >= _S2_NATIVE_MIN_PIXELS

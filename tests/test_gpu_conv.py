@@ -701,7 +701,7 @@ def test_stride2_conv_native_fp32_kernels(cuda, monkeypatch, B, C, K, H, W):
     """csrc/conv_s2_f32.inc (round 6): the stride-2 / pad-1 3x3 convolutions of the DLA levels in exact fp32 -- forward, input gradient
     (both row phases, both forms: four and two pixels per lane) and weight gradient against conv2d in fp64 at 2e-5 of each
     result's scale: DLA's five channel pairs, 48 outputs (a partial block of 32), one-chunk layers, the full-size first two levels;
-    the module dispatch takes them in every precision scope (the results are the exact-fp32 ones), and the library refuses the shapes the kernels cannot run."""
+    the module dispatch takes them in exact fp32 and inside the split-bf16 scope (same results), not inside the bf16 scope, and the library refuses the shapes the kernels cannot run."""
     from dcd_amd import _ext, _lib, ops
     from dcd_amd.model.layers.conv import Conv2d
     monkeypatch.setattr(ops, "_S2_NATIVE_MIN_PIXELS", 0)
@@ -727,9 +727,13 @@ def test_stride2_conv_native_fp32_kernels(cuda, monkeypatch, B, C, K, H, W):
     out = conv(x.to(cuda))
     assert calls and (out - F.conv2d(x.to(cuda), conv.weight, None, 2, 1)).abs().max().item() <= 2e-5 * out.abs().max().item()
     del calls[:]
-    with _ext.precision_scope("bf16"):                           # a scope permits reduced products, it does not oblige them: the exact kernels
-        out16 = conv(x.to(cuda))                                 # are the faster ones for these layers (ops.conv3x3_stride2_native_supported)
-    assert calls and torch.equal(out16, out), "inside the bf16 scope the same exact-fp32 kernels run"
+    with _ext.precision_scope("bf16x3"):                         # a scope permits reduced products, it does not oblige them: the exact kernels
+        out3 = conv(x.to(cuda))                                  # are the faster ones for these layers (ops.conv3x3_stride2_native_supported)
+    assert calls and torch.equal(out3, out), "inside the split-bf16 scope the same exact-fp32 kernels run"
+    del calls[:]
+    with _ext.precision_scope("bf16"):
+        conv(x.to(cuda))
+    assert not calls, "the bf16 scope keeps the space-to-depth form on the bf16 kernels"
     L = _lib.lib()
     st = _lib.stream_of(xd)
     bad = torch.randn(1, 16, 6, 12, device=cuda)                 # W % 8 != 0
