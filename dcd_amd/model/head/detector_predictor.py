@@ -47,6 +47,12 @@ class EdgeBranch(nn.Sequential):
                                    bn.num_batches_tracked, bn.momentum, bn.eps, relu).squeeze(-1)
         else:
             y = act(bn(y))
+        if (isinstance(conv2, nn.Conv1d) and conv2.kernel_size == (1,) and conv2.stride == (1,) and conv2.padding == (0,)
+                and conv2.dilation == (1,) and conv2.groups == 1 and conv2.bias is not None):
+            # the k1 convolution as the batched GEMM it is: the stock solver ran its weight gradient as an NHWC implicit GEMM between two
+            # transposes and a zero fill, with atomics (the last MIOpen rows of the step, and not reproducible run to run)
+            w2 = conv2.weight.squeeze(-1)
+            return torch.baddbmm(conv2.bias.view(1, -1, 1), w2.unsqueeze(0).expand(y.shape[0], -1, -1), y)
         return conv2(y)
 _HEAD_FUSED = os.environ.get("DCD_HEAD_FUSED", "1") != "0"      # 0: stock 1x1 conv + separate gather (A/B timing)
 _HEAD_ROWS = os.environ.get("DCD_HEAD_ROWS", "1") != "0"        # 0: one F.linear per regression head (A/B timing, CPU tests)
