@@ -80,6 +80,9 @@ SIGNATURES = {
     "dcd_conv3x3_s2_f32_backward_data": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int]),
     "dcd_conv3x3_s2_f32_wrw_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int, c_int]),
     "dcd_conv3x3_s2_f32_wrw": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int, c_void_p, c_size_t]),
+    "dcd_clip_adamw_workspace_bytes": (c_size_t, [c_int, c_void_p]),
+    "dcd_clip_grad_norm_scalars": (c_int, [c_void_p, c_int, c_void_p, c_void_p, c_float, c_void_p, c_size_t, c_void_p]),
+    "dcd_adamw_apply": (c_int, [c_void_p, c_int] + [c_void_p] * 7 + [c_double] * 4 + [c_void_p]),
     "dcd_conv1x1_f32": (c_int, [c_void_p, c_void_p, c_int, c_int, c_int, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_f32_workspace_bytes": (c_size_t, [c_int, c_int, c_int, c_int64]),
     "dcd_conv1x1_wrw_f32": (c_int, [c_void_p, c_void_p, c_void_p, c_void_p, c_int, c_int, c_int, c_int, c_int64, c_void_p, c_size_t]),

@@ -655,6 +655,28 @@ int dcd_encode_targets(void *stream, const double *objs, const double *kpts3d, c
                        double filter_size, double edge_heatmap_ratio, int num_bin, int n_classes, void *const *outputs,
                        int n_outputs);
 
+/* ------------------------------------------------------------------------------------------------
+ * The optimizer end of the train step (csrc/optim.hip): `torch.nn.utils.clip_grad_norm_(model.parameters(), max_norm)` followed by
+ * `AdamW.step()` (DGDE/engine/trainer.py:144-147; DGDE/solver/__init__.py:10-62: AdamW, betas (0.9, 0.99), one learning rate per
+ * parameter) over LISTS of fp32 tensors.  The host arrays of pointers / element counts are read during the call only (they travel
+ * in the kernel arguments); every tensor has fewer than 2^31 elements.
+ *
+ * dcd_clip_grad_norm_scalars: 2-norm over all listed gradients -> scal[0] = the norm, scal[1] = min(1, max_norm / (norm + 1e-6))
+ *   (1 when max_norm <= 0: no clipping), scal[2] = 1 when the norm is not finite else 0; three floats on the device.  The gradients
+ *   are not touched here.  workspace: dcd_clip_adamw_workspace_bytes(ntensors, numel) bytes, dead after the call.
+ * dcd_adamw_apply: one parameter group.  Unless scal[2] is set (then NOTHING changes: the library's found_inf contract), every
+ *   listed step counter (a float on the device each, as the library's capturable AdamW keeps them) += 1 and
+ *     g *= scal[1] (written back only when < 1)         p -= lr * weight_decay * p
+ *     m = beta1 m + (1 - beta1) g                       v = beta2 v + (1 - beta2) g^2
+ *     p -= (lr / (1 - beta1^step)) * m / (sqrt(v) / sqrt(1 - beta2^step) + eps)
+ *   in the library's fused kernel's order and types (double hyper-parameters against float operands).  lr: a float on the device. */
+size_t dcd_clip_adamw_workspace_bytes(int ntensors, const int64_t *numel);
+int dcd_clip_grad_norm_scalars(void *stream, int ntensors, const void *const *grads, const int64_t *numel, float max_norm, void *workspace,
+                               size_t workspace_bytes, float *scal);
+int dcd_adamw_apply(void *stream, int ntensors, void *const *params, void *const *grads, void *const *exp_avg, void *const *exp_avg_sq,
+                    void *const *steps, const int64_t *numel, const float *lr, double beta1, double beta2, double eps, double weight_decay,
+                    const float *scal);
+
 #ifdef __cplusplus
 }
 #endif
